@@ -1,0 +1,97 @@
+/*
+ * pangulu_amd_ext.h -- additions of the MI355X-native build around the reference API (include/pangulu.h).
+ *
+ * Nothing here exists in the reference; these calls replace what the reference gets from MPI_COMM_WORLD
+ * (rank/size/transport), expose what it only prints under -DPANGULU_PERF (structural flop count, phase times,
+ * src/pangulu.c:241-262), and give tests and bench.py access to the factor blocks and to the roofline model
+ * of SURVEY.md §8d.
+ */
+#ifndef PANGULU_AMD_EXT_H
+#define PANGULU_AMD_EXT_H
+
+#include "pangulu.h"
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+    /* ---- process group ---------------------------------------------------------------------------- */
+#define PANGULU_AMD_TRANSPORT_HOST 0 /* block records staged through host memory over TCP (127.0.0.1) */
+#define PANGULU_AMD_TRANSPORT_RCCL 1 /* device-to-device ncclSend/ncclRecv over xGMI, TCP control plane */
+    /* One process per GPU.  `base_port + rank` is the TCP port this rank listens on for the control plane
+     * (headers, barriers, broadcasts).  For RCCL, `nccl_unique_id` is the 128-byte ncclUniqueId rank 0 made
+     * (pangulu_amd_rccl_unique_id) and the launcher distributed.  Returns 0 on success. */
+    int pangulu_amd_comm_init(int rank, int size, const char *addr, int base_port, int transport,
+                              const void *nccl_unique_id);
+    int pangulu_amd_rccl_unique_id(void *out128);
+    void pangulu_amd_comm_barrier(void);
+    void pangulu_amd_comm_finalize(void);
+    int pangulu_amd_comm_rank(void);
+    int pangulu_amd_comm_size(void);
+
+    /* ---- back-end selection ------------------------------------------------------------------------- */
+    /* The product always runs on the built-in HIP platform (PANGULU_PLATFORM_GPU_HIP) and aborts when no
+     * device is present.  TEST HOOK: route the 21 platform operators to another shared object exporting
+     * pangulu_platform_<7-digit id>_<name> (the tests pass oracle/_build/libpangulu_oracle_*.so with id
+     * 0x0100000 to run the scheduler on the CPU restatement).  Returns 0 on success. */
+    int pangulu_amd_use_platform_library(const char *so_path, unsigned int platform_id);
+    unsigned int pangulu_amd_active_platform(void);
+
+    /* ---- analysis options (set before pangulu_init) -------------------------------------------------- */
+#define PANGULU_AMD_ORDER_IDENTITY 0 /* what the reference does without METIS/MC64 */
+#define PANGULU_AMD_ORDER_ND 1       /* built-in nested dissection on the graph of A+A^T (default)   */
+#define PANGULU_AMD_ORDER_USER 2     /* permutation supplied with pangulu_amd_set_user_perm           */
+    void pangulu_amd_set_ordering(int kind);
+    /* perm[new] = old, length n; copied */
+    void pangulu_amd_set_user_perm(const sparse_index_t *perm, sparse_index_t n);
+    /* optional vertex coordinates (dim = 2 or 3, n*dim doubles, vertex-major) turn ORDER_ND into a geometric
+     * dissection; copied; cleared after the next pangulu_init */
+    void pangulu_amd_set_coordinates(const double *xyz, sparse_index_t n, int dim);
+    /* 0 (default): device-resident numeric phase, factors downloaded once when gstrs / block export needs
+     * them.  1: reference behaviour, every finished panel block is copied back to the host at once. */
+    void pangulu_amd_set_eager_host_mirror(int on);
+
+    /* ---- introspection -------------------------------------------------------------------------------- */
+    typedef struct pangulu_amd_info_t
+    {
+        unsigned long long n, nnz, nb, block_length;
+        unsigned long long symbolic_nnz;      /* nnz(L+U) incl. diagonal once, as src/pangulu_symbolic.c:242          */
+        long long flop;                       /* structural flop count F = sum_k (c_k + 2 c_k^2), SURVEY.md §8a a9     */
+        unsigned long long nblocks_nondiag;   /* non-empty off-diagonal blocks, whole matrix                          */
+        unsigned long long nblocks_owned;     /* records this rank owns (diagonal halves count once each)             */
+        unsigned long long ntask_getrf, ntask_tstrf, ntask_gessm, ntask_ssssm; /* this rank                           */
+        unsigned long long owned_bytes;       /* bytes of block records this rank owns                                */
+        unsigned long long recv_blocks;       /* remote blocks this rank receives during gstrf                        */
+        unsigned long long sent_bytes, recv_bytes;
+        double time_reorder, time_symbolic, time_preprocess, time_numeric, time_solve;
+        double time_numeric_host_sched;       /* seconds the compute thread spent outside platform calls              */
+        /* roofline model of SURVEY.md §8d for this rank's tasks: sum over tasks of algorithmic bytes / flops,
+         * split by which bound is larger per task at (hbm_gbs, fp_tflops) given to pangulu_amd_model_roofline */
+        double model_bytes_total, model_flop_total;
+        double model_tmin_hbm_bound, model_tmin_fp_bound; /* seconds */
+        unsigned long long batches;           /* platform hybrid_batched calls issued by the scheduler                */
+    } pangulu_amd_info_t;
+    void pangulu_amd_get_info(void **pangulu_handle, pangulu_amd_info_t *out);
+    /* evaluate T* = sum_t max(bytes_t / BW, flop_t / P) over this rank's task list (structure only) */
+    void pangulu_amd_model_roofline(void **pangulu_handle, double hbm_gbytes_per_s, double fp_tflops);
+
+    /* ---- factor access (tests) ------------------------------------------------------------------------ */
+    /* Block records this rank owns, in storage order.  Pointers are host pointers into the record and stay
+     * valid until pangulu_finalize.  After pangulu_gstrf the values are the factors (downloaded on demand).
+     * For is_upper==1 diagonal halves colptr/rowidx are the CSR row pointer / column index. */
+    long long pangulu_amd_owned_block_count(void **pangulu_handle);
+    int pangulu_amd_owned_block(void **pangulu_handle, long long idx, sparse_index_t *brow, sparse_index_t *bcol,
+                                int *is_upper, unsigned long long *nnz, const pangulu_inblock_ptr **colptr,
+                                const pangulu_inblock_idx **rowidx, const calculate_type **value);
+    /* the symmetric permutation used: perm[new] = old (length n) */
+    const sparse_index_t *pangulu_amd_get_perm(void **pangulu_handle);
+    /* y = L*(U*x) with the (downloaded) factors of a single-rank run, in the permuted ordering; used for the
+     * reference's factor check ||L(U.1) - A.1|| / ||A.1|| (src/pangulu_numeric.c:1082-1341) */
+    int pangulu_amd_apply_lu(void **pangulu_handle, const calculate_type *x, calculate_type *y);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PANGULU_AMD_EXT_H */

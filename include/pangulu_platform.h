@@ -1,0 +1,243 @@
+/*
+ * pangulu_platform.h -- C-ABI of the MI355X (gfx950) HIP back-end, platform id 0201001 "GPU_HIP".
+ *
+ * This is the drop-in boundary of the build.  The 21 entry points below are exactly the
+ * operator table the reference generates from build_helper.py:8-32 and dispatches through
+ * src/pangulu_platform_helper.c:7-27; the reference's CUDA implementation of the same table is
+ * src/platforms/02_NONSHAREDMEM/01_GPU/000_CUDA/pangulu_platform_0201000.cu:52-979 and its CPU
+ * implementation src/platforms/01_SHAREDMEM/00_CPU/000_CPU/pangulu_platform_0100000.c:14-506.
+ *
+ * The two descriptor structs are ABI-identical to the reference's (compiled with -DGPU_OPEN):
+ *   pangulu_storage_slot_t  <- src/pangulu_common.h:207-231   (144 bytes)
+ *   pangulu_task_t          <- src/pangulu_common.h:233-243   ( 48 bytes)
+ * so a reference host built with PANGULU_DEFAULT_PLATFORM = PANGULU_PLATFORM_GPU_HIP can link this library
+ * unchanged (INTEGRATION.md shows the three lines a maintainer adds).
+ *
+ * Value type is fixed at compile time like the reference (src/pangulu_common.h:11-33):
+ *   -DCALCULATE_TYPE_R64 (default) | _R32 | _CR64 | _CR32
+ */
+#ifndef PANGULU_PLATFORM_H
+#define PANGULU_PLATFORM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+/* ---- scalar types (src/pangulu_common.h:35-70) ------------------------------------------------------- */
+typedef long long int pangulu_int64_t;
+typedef unsigned long long int pangulu_uint64_t;
+typedef int pangulu_int32_t;
+typedef unsigned int pangulu_uint32_t;
+typedef short int pangulu_int16_t;
+typedef unsigned short int pangulu_uint16_t;
+
+typedef pangulu_uint64_t pangulu_exblock_ptr; /* pointer into the global (whole-matrix) CSC        */
+typedef pangulu_uint32_t pangulu_exblock_idx; /* global row/column or block-row/block-column index */
+typedef pangulu_uint32_t pangulu_inblock_ptr; /* pointer inside one nb x nb block                  */
+typedef pangulu_uint16_t pangulu_inblock_idx; /* row/column inside one block (nb <= 65535)         */
+
+#if defined(CALCULATE_TYPE_CR64)
+#define PANGULU_COMPLEX 1
+typedef double calculate_real_type;
+#elif defined(CALCULATE_TYPE_CR32)
+#define PANGULU_COMPLEX 1
+typedef float calculate_real_type;
+#elif defined(CALCULATE_TYPE_R32)
+typedef float calculate_real_type;
+#else
+#ifndef CALCULATE_TYPE_R64
+#define CALCULATE_TYPE_R64
+#endif
+typedef double calculate_real_type;
+#endif
+
+#ifdef PANGULU_COMPLEX
+#if defined(__cplusplus)
+/* layout-compatible with C99 `T _Complex` (re, im adjacent) */
+typedef struct pangulu_complex_t
+{
+    calculate_real_type re, im;
+} calculate_type;
+#elif defined(CALCULATE_TYPE_CR64)
+typedef double _Complex calculate_type;
+#else
+typedef float _Complex calculate_type;
+#endif
+#else
+typedef calculate_real_type calculate_type;
+#endif
+
+/* ---- task ids, data states, tolerances (src/pangulu_common.h:124-134) --------------------------------- */
+#define PANGULU_TASK_GETRF 1
+#define PANGULU_TASK_TSTRF 2
+#define PANGULU_TASK_GESSM 3
+#define PANGULU_TASK_SSSSM 4
+#define PANGULU_LOWER 0
+#define PANGULU_UPPER 1
+#define PANGULU_DATA_INVALID 0
+#define PANGULU_DATA_PREPARING 1
+#define PANGULU_DATA_READY 2
+#define PANGULU_TOL 1e-16
+#define PANGULU_SPTRSV_TOL 1e-16
+
+/* platform ids: <shared/nonshared 2 digits><device class 2><implementation 3>, build_helper.py:60-87 */
+#define PANGULU_PLATFORM_CPU_NAIVE 0x0100000
+#define PANGULU_PLATFORM_GPU_CUDA 0x0201000
+#define PANGULU_PLATFORM_GPU_HIP 0x0201001
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+    typedef struct pangulu_aggregate_queue_t
+    {
+        unsigned long long capacity;
+        unsigned long long length;
+        void *task_descriptors;
+    } pangulu_aggregate_queue_t;
+
+    /*
+     * Block descriptor.  Host fields describe the host copy of the block record, d_* fields the device
+     * copy.  Conventions the kernels rely on (src/pangulu_storage.c:247-421, pangulu_communication.c:1805-1895):
+     *   off-diagonal block : CSC  -> columnpointer / rowindex / value          (d_columnpointer / d_rowindex / d_value)
+     *   lower block only   : +CSR view -> rowpointer / columnindex / idx_of_csc_value_for_csr (and d_*)
+     *   diagonal, lower    : strictly-lower CSC, is_upper = 0, same fields as an off-diagonal block
+     *   diagonal, upper    : upper-incl-diagonal CSR (diagonal entry first in each row), is_upper = 1;
+     *                        host fields are still named columnpointer/rowindex, the DEVICE fields are
+     *                        d_rowpointer / d_columnindex (d_columnpointer is unset)
+     *   related_block links the two halves of a diagonal block.
+     * `value` points 32 bytes into the contiguous record (header: u64 nnz @-32, u32 brow @-24, u32 bcol @-20,
+     * u32 is_upper @-16).
+     */
+    typedef struct pangulu_storage_slot_t
+    {
+        pangulu_exblock_idx brow_pos;
+        pangulu_exblock_idx bcol_pos;
+        pangulu_inblock_ptr *columnpointer;
+        pangulu_inblock_idx *rowindex;
+        calculate_type *value;
+        pangulu_inblock_ptr *rowpointer;
+        pangulu_inblock_idx *columnindex;
+        pangulu_inblock_ptr *idx_of_csc_value_for_csr;
+        volatile char data_status;
+        struct pangulu_storage_slot_t *related_block;
+        pangulu_int32_t is_upper;
+        pangulu_int32_t bin_id;
+        pangulu_int32_t slot_idx;
+        pangulu_aggregate_queue_t *task_queue;
+        pangulu_inblock_ptr *d_columnpointer;
+        pangulu_inblock_idx *d_rowindex;
+        calculate_type *d_value;
+        pangulu_inblock_ptr *d_rowpointer;
+        pangulu_inblock_idx *d_columnindex;
+        pangulu_inblock_ptr *d_idx_of_csc_value_for_csr;
+    } pangulu_storage_slot_t;
+
+    typedef struct pangulu_task_t
+    {
+        pangulu_exblock_idx row;
+        pangulu_exblock_idx col;
+        pangulu_int16_t kernel_id;
+        pangulu_exblock_idx task_level;
+        pangulu_int64_t compare_flag;
+        pangulu_storage_slot_t *opdst;
+        pangulu_storage_slot_t *op1;
+        pangulu_storage_slot_t *op2;
+    } pangulu_task_t;
+
+#if defined(__cplusplus)
+    static_assert(sizeof(pangulu_storage_slot_t) == 144, "slot ABI must match src/pangulu_common.h:207-231 (GPU_OPEN)");
+    static_assert(offsetof(pangulu_storage_slot_t, value) == 24, "slot ABI");
+    static_assert(offsetof(pangulu_storage_slot_t, related_block) == 64, "slot ABI");
+    static_assert(offsetof(pangulu_storage_slot_t, d_columnpointer) == 96, "slot ABI");
+    static_assert(offsetof(pangulu_storage_slot_t, d_value) == 112, "slot ABI");
+    static_assert(sizeof(pangulu_task_t) == 48, "task ABI must match src/pangulu_common.h:233-243");
+    static_assert(offsetof(pangulu_task_t, opdst) == 24, "task ABI");
+#endif
+
+    /* Globals the reference host defines (src/pangulu.c:7-9) and its GPU back-end reads
+     * (pangulu_platform_0201000.cu:7-9).  This library defines them WEAK so it links both against the
+     * reference host (whose strong definitions win) and stand-alone.  The HIP kernels size their
+     * workgroups for 64-wide wavefronts themselves; the two "warp_per_block" knobs are accepted and used as
+     * wavefronts-per-workgroup hints. set_default_device() writes pangulu_gpu_shared_mem_size. */
+    extern int pangulu_gpu_kernel_warp_per_block;
+    extern int pangulu_gpu_data_move_warp_per_block;
+    extern int pangulu_gpu_shared_mem_size;
+
+    /* ---- the 21 operators, one per row of build_helper.py:8-32 ------------------------------------- */
+    /* runtime shims: replaces pangulu_platform_0201000.cu:52-163 */
+    void pangulu_platform_0201001_malloc(void **platform_address, size_t size);
+    void pangulu_platform_0201001_malloc_pinned(void **platform_address, size_t size);
+    void pangulu_platform_0201001_synchronize(void);
+    void pangulu_platform_0201001_memset(void *s, int c, size_t n);
+    void pangulu_platform_0201001_create_stream(void **stream);
+    /* kind: 0 = host->device, 1 = device->host, 2 = device->device (…0201000.cu:82-103) */
+    void pangulu_platform_0201001_memcpy(void *dst, const void *src, size_t count, unsigned int kind);
+    void pangulu_platform_0201001_memcpy_async(void *dst, const void *src, size_t count, unsigned int kind, void *stream);
+    void pangulu_platform_0201001_free(void *devptr);
+    void pangulu_platform_0201001_get_device_num(int *device_num);
+    void pangulu_platform_0201001_set_default_device(int device_num);
+    void pangulu_platform_0201001_get_device_name(char *name, int device_num);
+    void pangulu_platform_0201001_get_device_memory_usage(size_t *used_byte);
+
+    /* numeric kernels: replaces …0201000.cu:547-909 (CPU semantics: …0100000.c:57-431) */
+    void pangulu_platform_0201001_getrf(pangulu_inblock_idx nb, pangulu_storage_slot_t *opdst, int tid);
+    void pangulu_platform_0201001_tstrf(pangulu_inblock_idx nb, pangulu_storage_slot_t *opdst, pangulu_storage_slot_t *opdiag, int tid);
+    void pangulu_platform_0201001_gessm(pangulu_inblock_idx nb, pangulu_storage_slot_t *opdst, pangulu_storage_slot_t *opdiag, int tid);
+    void pangulu_platform_0201001_ssssm(pangulu_inblock_idx nb, pangulu_storage_slot_t *opdst, pangulu_storage_slot_t *op1, pangulu_storage_slot_t *op2, int tid);
+    void pangulu_platform_0201001_ssssm_batched(pangulu_inblock_idx nb, pangulu_uint64_t ntask, pangulu_task_t *tasks);
+    void pangulu_platform_0201001_hybrid_batched(pangulu_inblock_idx nb, pangulu_uint64_t ntask, pangulu_task_t *tasks);
+
+    /* solve-side kernels: the reference's GPU versions are empty stubs (…0201000.cu:958-979); these are
+     * real device kernels with the CPU semantics of …0100000.c:435-506 (x, y are DEVICE pointers). */
+    void pangulu_platform_0201001_spmv(pangulu_inblock_idx nb, pangulu_storage_slot_t *a, calculate_type *x, calculate_type *y);
+    void pangulu_platform_0201001_vecadd(pangulu_int64_t length, calculate_type *bval, calculate_type *xval);
+    void pangulu_platform_0201001_sptrsv(pangulu_inblock_idx nb, pangulu_storage_slot_t *s, calculate_type *xval, pangulu_int64_t uplo);
+
+    /* ---- extensions (not in the reference table; safe to ignore) ----------------------------------- */
+    /* Behaviour switches of the back-end.
+     *   PANGULU_HIP_OPT_HOST_MIRROR (default 1): after GETRF/TSTRF/GESSM copy the block's values back into
+     *     slot->value like …0201000.cu:639-640,680,714 does (the reference host's MPI send and SpTRSV read
+     *     host memory).  The native host keeps factors device-resident and sets 0.
+     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 1000): SSSSM triples whose three blocks have at
+     *     least this fill (nnz*1000/nb^2) go to the f64/f32 MFMA dense kernel; 1000 = only completely full
+     *     blocks, the reference's cuBLAS-direct rule (…0201000.cu:827).
+     */
+#define PANGULU_HIP_OPT_HOST_MIRROR 1
+#define PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE 2
+    /*   PANGULU_HIP_OPT_PROFILE (default 0): time every kernel launch with hipEvents (see get_stats).
+     *   PANGULU_HIP_OPT_ASSUME_INDEPENDENT (default 0): the caller guarantees that the tasks of one
+     *     hybrid_batched call do not depend on each other (other than SSSSM tasks sharing a destination, which
+     *     must then be adjacent in the array); skips the hazard scan that otherwise splits the array into
+     *     dependent phases.  The native scheduler sets it. */
+#define PANGULU_HIP_OPT_PROFILE 3
+#define PANGULU_HIP_OPT_ASSUME_INDEPENDENT 4
+    int pangulu_platform_0201001_set_option(int option, long long value);
+    /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
+     * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an
+     * allocation and three small copies inside the factorisation).  `diag` may be either half. */
+    void pangulu_platform_0201001_prepare_diag(pangulu_inblock_idx nb, pangulu_storage_slot_t *diag);
+    /* stream all numeric kernels are launched on (a hipStream_t); for event timing in bench.py */
+    void *pangulu_platform_0201001_get_stream(void);
+    /* Cumulative per-kernel-class counters since the last reset.  Classes: 1 GETRF, 2 TSTRF, 3 GESSM,
+     * 4 SSSSM (sparse LDS-accumulator kernel), 5 SSSSM (dense MFMA kernel); index 0 unused.
+     *   alg_bytes : algorithmic HBM bytes of the launched tasks (SURVEY.md §8d formulas, from nnz only)
+     *   flops     : structural flops the kernels executed (counted on the device for the sparse kernels,
+     *               2*nb^3 per task for the dense kernel)
+     *   elapsed_ms: sum of launch durations from hipEvents on the back-end stream; only collected while
+     *               PANGULU_HIP_OPT_PROFILE is 1 (it adds two event records per launch)                  */
+    typedef struct pangulu_hip_stats_t
+    {
+        unsigned long long launches[6];
+        unsigned long long tasks[6];
+        double alg_bytes[6];
+        double flops[6];
+        double elapsed_ms[6];
+    } pangulu_hip_stats_t;
+    void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PANGULU_PLATFORM_H */

@@ -1,0 +1,273 @@
+// pg_host.h -- internal declarations of the native host (analysis, storage, scheduler, transport).
+//
+// Restates, MI355X-first, the host side of the reference's hot path:
+//   block records        src/pangulu_communication.c:1290-1393, src/pangulu_storage.c:199-426
+//   dependency counters  src/pangulu_preprocessing.c:132-315, 443-556
+//   heap + aggregator    src/pangulu_task.c:7-472
+//   scheduler            src/pangulu_numeric.c:6-1080
+//   p2p block exchange   src/pangulu_communication.c:93-105, 1786-1944
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/pangulu_amd_ext.h"
+
+namespace pg
+{
+
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i32 = int32_t;
+using i64 = int64_t;
+using val_t = calculate_type;
+using slot_t = pangulu_storage_slot_t;
+using task_t = pangulu_task_t;
+
+[[noreturn]] void fatal(const char *fmt, ...);
+double wall_seconds();
+
+// ---------------------------------------------------------------------------------------------------------
+// platform operator table (the reference's generated switch, src/pangulu_platform_helper.c:7-27)
+// ---------------------------------------------------------------------------------------------------------
+struct Platform
+{
+    unsigned id = 0;
+    bool host_memory = false; // true: "device" pointers are host pointers (CPU platform)
+    void *dl_handle = nullptr;
+    void (*malloc_)(void **, size_t) = nullptr;
+    void (*malloc_pinned)(void **, size_t) = nullptr;
+    void (*synchronize)() = nullptr;
+    void (*memset_)(void *, int, size_t) = nullptr;
+    void (*create_stream)(void **) = nullptr;
+    void (*memcpy_)(void *, const void *, size_t, unsigned) = nullptr;
+    void (*memcpy_async)(void *, const void *, size_t, unsigned, void *) = nullptr;
+    void (*free_)(void *) = nullptr;
+    void (*get_device_num)(int *) = nullptr;
+    void (*set_default_device)(int) = nullptr;
+    void (*get_device_name)(char *, int) = nullptr;
+    void (*get_device_memory_usage)(size_t *) = nullptr;
+    void (*getrf)(pangulu_inblock_idx, slot_t *, int) = nullptr;
+    void (*tstrf)(pangulu_inblock_idx, slot_t *, slot_t *, int) = nullptr;
+    void (*gessm)(pangulu_inblock_idx, slot_t *, slot_t *, int) = nullptr;
+    void (*ssssm)(pangulu_inblock_idx, slot_t *, slot_t *, slot_t *, int) = nullptr;
+    void (*ssssm_batched)(pangulu_inblock_idx, pangulu_uint64_t, task_t *) = nullptr;
+    void (*hybrid_batched)(pangulu_inblock_idx, pangulu_uint64_t, task_t *) = nullptr;
+    void (*spmv)(pangulu_inblock_idx, slot_t *, val_t *, val_t *) = nullptr;
+    void (*vecadd)(pangulu_int64_t, val_t *, val_t *) = nullptr;
+    void (*sptrsv)(pangulu_inblock_idx, slot_t *, val_t *, pangulu_int64_t) = nullptr;
+    // extension of the HIP back-end (nullptr elsewhere)
+    int (*set_option)(int, long long) = nullptr;
+    void (*prepare_diag)(pangulu_inblock_idx, slot_t *) = nullptr;
+};
+Platform &active_platform();               // built-in HIP unless the test hook replaced it
+bool platform_is_builtin_hip();
+
+// ---------------------------------------------------------------------------------------------------------
+// analysis
+// ---------------------------------------------------------------------------------------------------------
+struct CscMatrix
+{
+    u32 n = 0;
+    std::vector<u64> colptr;
+    std::vector<u32> rowidx;
+    std::vector<val_t> value;
+    u64 nnz() const { return colptr.empty() ? 0 : colptr.back(); }
+};
+
+// perm[new] = old
+void order_identity(u32 n, std::vector<u32> &perm);
+void order_nested_dissection(const CscMatrix &A, const double *coords, int dim, std::vector<u32> &perm);
+// B = P A P^T with sorted columns
+void permute_symmetric(const CscMatrix &A, const std::vector<u32> &perm, CscMatrix &B);
+
+// Fill pattern of the LU factors of a matrix with the symmetrised pattern of A (the reference's
+// pangulu_symbolic_symmetric, src/pangulu_symbolic.c:132-247): lower triangle incl. diagonal, CSC, sorted.
+struct Symbolic
+{
+    u32 n = 0;
+    std::vector<u64> ptr;
+    std::vector<u32> idx;
+    u64 symbolic_nnz = 0; // 2*nnz(L) - n
+    i64 flop = 0;         // sum_k (c_k + 2 c_k^2)
+};
+void symbolic_factorize(const CscMatrix &A, Symbolic &S);
+
+// Whole-matrix block structure (every rank holds it; it is small: a few words per non-empty block).
+struct BlockPattern
+{
+    u32 nb = 0, nbk = 0, n = 0;
+    // lower block pattern incl. diagonal blocks, block-CSC: block rows >= bc, ascending
+    std::vector<u64> lcolptr;
+    std::vector<u32> lrowidx;
+    std::vector<u32> lnnz; // nnz of each lower block (diagonal block: strictly-lower + diagonal entries)
+    // all non-diagonal blocks, block-CSC (U blocks br<bc first, then L blocks br>bc) and block-CSR
+    std::vector<u64> colptr, first_after_diag;
+    std::vector<u32> rowidx;
+    std::vector<u64> rowptr, first_after_diag_csr, csr_to_csc;
+    std::vector<u32> colidx;
+    std::vector<u32> nnz;              // per non-diagonal block (block-CSC index)
+    std::vector<u32> diag_lower_nnz;   // strictly lower entries of diagonal block k
+    std::vector<u32> diag_upper_nnz;   // upper incl. diagonal
+    // locate block (br, bc), br != bc, in block-CSC order; returns ~0ull when structurally empty
+    u64 find(u32 br, u32 bc) const;
+};
+void build_block_pattern(const Symbolic &S, u32 nb, BlockPattern &P);
+
+// ---------------------------------------------------------------------------------------------------------
+// storage: owned block records + size-classed receive bins (src/pangulu_storage.c)
+// ---------------------------------------------------------------------------------------------------------
+size_t record_bytes(u32 nb, u64 nnz, bool lower_offdiag); // incl. 32-byte header, 8-byte padded
+// lay the slot's host/device pointers over a record that starts at (hrec, drec)
+void bind_record(slot_t &s, u32 nb, u64 nnz, char *hrec, char *drec, bool lower_offdiag, bool diag_upper);
+
+struct RecvBin
+{
+    size_t slot_capacity = 0;
+    std::vector<slot_t> slots;
+    std::vector<i32> free_list;
+    char *hbuf = nullptr, *dbuf = nullptr;
+};
+
+struct Storage
+{
+    u32 nb = 0;
+    std::vector<slot_t> owned;        // bin 0: off-diagonal owned blocks first, then diagonal halves (lower, upper)
+    size_t n_owned_nondiag = 0;
+    char *harena = nullptr, *darena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<RecvBin> bins;        // bins[0] unused; 1..6 receive classes
+    std::mutex mutex;
+    slot_t *allocate(size_t bytes);   // first bin with capacity >= bytes and a free slot; nullptr if none
+    void recycle(slot_t *s);
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// priority heap of panel tasks + per-destination SSSSM aggregation (src/pangulu_task.c)
+// ---------------------------------------------------------------------------------------------------------
+struct TaskHeap
+{
+    std::vector<task_t> store;
+    std::vector<i64> heap;
+    std::vector<i64> free_ids;
+    std::mutex mutex;
+    void reserve(size_t cap);
+    void clear();
+    void push(const task_t &t);
+    bool pop(task_t &out);
+    bool empty();
+    size_t size();
+    static bool before(const task_t &a, const task_t &b); // strategy 0 of pangulu_task_compare
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// transport
+// ---------------------------------------------------------------------------------------------------------
+struct BlockHeader // the 32-byte record header as it travels (src/pangulu_communication.c:1929-1942)
+{
+    u64 nnz;
+    u32 brow, bcol;
+    u32 is_upper;
+    u32 bytes_lo; // total record bytes (ours: the reference derives it from MPI_Get_count)
+    u64 reserved;
+};
+static_assert(sizeof(BlockHeader) == 32, "record header is 32 bytes");
+
+class Comm
+{
+public:
+    int rank = 0, size = 1;
+    int transport = PANGULU_AMD_TRANSPORT_HOST;
+    virtual ~Comm() {}
+    virtual void barrier() = 0;
+    virtual void bcast(void *buf, size_t bytes, int root) = 0;
+    virtual void allreduce_sum_i64(i64 *v, int count) = 0;
+    virtual void allreduce_max_f64(double *v, int count) = 0;
+    // small tagged host messages (SpTRSV partial sums), blocking
+    virtual void send_bytes(int dst, int tag, const void *buf, size_t bytes) = 0;
+    virtual void recv_bytes(int src, int tag, void *buf, size_t bytes) = 0;
+    // block records: post a send of the record behind `s` (header + payload) to dst; returns at once
+    virtual void isend_block(slot_t *s, const BlockHeader &h, int dst) = 0;
+    // poll for an incoming block header; true when one is available (then recv_block must follow)
+    virtual bool probe_block(BlockHeader &h, int &src) = 0;
+    // receive the announced record into the slot's buffers (host mirror and/or device)
+    virtual void recv_block(slot_t *s, const BlockHeader &h, int src) = 0;
+    // make sure everything posted has left (called before the slot memory may be reused / at the end)
+    virtual void flush_sends() = 0;
+    u64 sent_bytes = 0, recv_bytes_total = 0;
+};
+Comm *world();             // never null: a 1-rank loopback by default
+void set_world(Comm *c);   // takes ownership
+Comm *make_socket_comm(int rank, int size, const char *addr, int base_port, int transport, const void *nccl_id);
+
+// ---------------------------------------------------------------------------------------------------------
+// the solver instance behind the opaque handle
+// ---------------------------------------------------------------------------------------------------------
+struct Options
+{
+    int ordering = PANGULU_AMD_ORDER_ND;
+    std::vector<u32> user_perm;
+    std::vector<double> coords;
+    int coord_dim = 0;
+    bool eager_host_mirror = false;
+};
+Options &pending_options();
+
+struct TaskModel // SURVEY.md §8d algorithmic bytes / flops of the rank's tasks
+{
+    double bytes[5] = {0, 0, 0, 0, 0};
+    double flop[5] = {0, 0, 0, 0, 0};
+    u64 count[5] = {0, 0, 0, 0, 0};
+};
+
+struct Solver
+{
+    // configuration
+    u32 n = 0, nb = 0, nbk = 0;
+    int rank = 0, nproc = 1, p = 1, q = 1;
+    float recv_buffer_level = 0.5f;
+    bool eager_host_mirror = false;
+    // analysis products
+    std::vector<u32> perm, iperm;
+    Symbolic sym;
+    BlockPattern pat;
+    CscMatrix Aperm;                       // kept for the factor check and residuals (rank 0 / all ranks)
+    // numeric state
+    Storage storage;
+    std::vector<slot_t *> slot_of;         // per non-diagonal block: owned / received slot, nullptr otherwise
+    std::vector<slot_t *> diag_lower, diag_upper;
+    std::vector<i32> remain;               // per non-diagonal block (reference: nondiag_remain_task_count)
+    std::vector<i32> remain_diag;          // per level
+    std::vector<i32> remain0, remain_diag0; // pristine copies (gstrf may be called once per init, kept for checks)
+    i64 rank_remain_task = 0, rank_remain_task0 = 0;
+    i64 rank_remain_recv = 0, rank_remain_recv0 = 0;
+    TaskHeap heap;
+    std::mutex info_mutex;
+    // per-destination pending SSSSM tasks (the aggregator); index = owned slot index of the destination
+    std::vector<std::vector<task_t>> pending;
+    std::vector<u32> pending_dirty;        // owned slot indices with non-empty queues, in first-touch order
+    u64 pending_total = 0;
+    bool factored = false, host_values_current = true;
+    // statistics
+    pangulu_amd_info_t info;
+    TaskModel model;
+    int owner(u32 br, u32 bc) const { return (int)((br % (u32)p) * (u32)q + (bc % (u32)q)); }
+    ~Solver();
+};
+
+void preprocess(Solver &S, const CscMatrix &Aperm);       // records, counters, bins, upload
+void numeric_factorize(Solver &S);                        // the hot path
+void download_factors(Solver &S);                         // device -> host mirror of owned values
+void triangular_solve(Solver &S, val_t *rhs_permuted);    // forward + backward block sweeps (host kernels)
+void compute_task_model(Solver &S);
+
+} // namespace pg

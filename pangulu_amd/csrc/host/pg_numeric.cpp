@@ -1,0 +1,692 @@
+// pg_numeric.cpp -- the synchronisation-free numeric factorisation (the hot path's host side).
+//
+// Same dependency-counter scheme as the reference (src/pangulu_numeric.c:6-1080, src/pangulu_task.c:7-472,
+// counters described in SURVEY.md §3.4), re-designed around an asynchronous device:
+//   * panel tasks (GETRF / TSTRF / GESSM) go through the priority heap (strategy 0 of pangulu_task_compare,
+//     src/pangulu_task.c:268-281) and are drained into ONE platform hybrid_batched call per drain, GETRFs
+//     included (the reference runs every GETRF alone, src/pangulu_numeric.c:987-991);
+//   * SSSSM updates never enter the heap.  The reference pushes each one twice (heap + per-tile aggregator,
+//     src/pangulu_task.c:373-385) and the heap copy's only effect when popped is "if the tile's counter is 1,
+//     push its panel task" (src/pangulu_numeric.c:602-650).  Counters only decrease, so that test is made
+//     right when the update is queued: identical task graph, no heap traffic for the most numerous task;
+//   * queued updates of a tile are flushed, as one batch together with those of every other tile of the
+//     drain, right before the tile's panel task (src/pangulu_numeric.c:311) or when the rank is idle
+//     (src/pangulu_task.c:93-177);
+//   * single-rank runs never synchronise with the device inside the loop: every batch goes to the back-end's
+//     one in-order stream, so program order is dependency order and the host simply runs ahead.
+#include <algorithm>
+#include <chrono>
+#include <unistd.h>
+
+#include "pg_host.h"
+
+namespace pg
+{
+
+// ---------------------------------------------------------------------------------------------------------
+// heap
+// ---------------------------------------------------------------------------------------------------------
+bool TaskHeap::before(const task_t &a, const task_t &b)
+{
+    if (a.compare_flag != b.compare_flag)
+        return a.compare_flag < b.compare_flag;
+    i64 ka = (i64)a.row + (i64)a.col - a.compare_flag;
+    i64 kb = (i64)b.row + (i64)b.col - b.compare_flag;
+    return ka < kb;
+}
+
+void TaskHeap::reserve(size_t cap)
+{
+    store.reserve(cap);
+    heap.reserve(cap);
+}
+
+void TaskHeap::clear()
+{
+    std::lock_guard<std::mutex> g(mutex);
+    store.clear();
+    heap.clear();
+    free_ids.clear();
+}
+
+void TaskHeap::push(const task_t &t)
+{
+    std::lock_guard<std::mutex> g(mutex);
+    i64 id;
+    if (!free_ids.empty())
+    {
+        id = free_ids.back();
+        free_ids.pop_back();
+        store[(size_t)id] = t;
+    }
+    else
+    {
+        id = (i64)store.size();
+        store.push_back(t);
+    }
+    size_t son = heap.size();
+    heap.push_back(id);
+    while (son > 0)
+    {
+        size_t parent = (son - 1) / 2;
+        if (!before(store[(size_t)heap[son]], store[(size_t)heap[parent]]))
+            break;
+        std::swap(heap[son], heap[parent]);
+        son = parent;
+    }
+}
+
+bool TaskHeap::pop(task_t &out)
+{
+    std::lock_guard<std::mutex> g(mutex);
+    if (heap.empty())
+        return false;
+    i64 top = heap[0];
+    out = store[(size_t)top];
+    free_ids.push_back(top);
+    heap[0] = heap.back();
+    heap.pop_back();
+    size_t len = heap.size(), cur = 0;
+    while (true)
+    {
+        size_t l = 2 * cur + 1, r = l + 1, best = cur;
+        if (l < len && before(store[(size_t)heap[l]], store[(size_t)heap[best]]))
+            best = l;
+        if (r < len && before(store[(size_t)heap[r]], store[(size_t)heap[best]]))
+            best = r;
+        if (best == cur)
+            break;
+        std::swap(heap[cur], heap[best]);
+        cur = best;
+    }
+    return true;
+}
+
+bool TaskHeap::empty()
+{
+    std::lock_guard<std::mutex> g(mutex);
+    return heap.empty();
+}
+
+size_t TaskHeap::size()
+{
+    std::lock_guard<std::mutex> g(mutex);
+    return heap.size();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scheduler
+// ---------------------------------------------------------------------------------------------------------
+namespace
+{
+
+struct Sched
+{
+    Solver &S;
+    const BlockPattern &P;
+    Platform &plat;
+    Comm *comm;
+    std::vector<char> sent_flag;
+    std::vector<task_t> batch, ssssm_batch;
+    double t_platform = 0;
+    u64 batches = 0;
+    bool multi;
+
+    explicit Sched(Solver &s) : S(s), P(s.pat), plat(active_platform()), comm(world()), sent_flag((size_t)s.nproc, 0), multi(s.nproc > 1) {}
+
+    // ---- task creation -------------------------------------------------------------------------------
+    void push_panel(u32 row, u32 col, u32 level, int kernel, slot_t *dst, slot_t *op1)
+    {
+        task_t t;
+        memset(&t, 0, sizeof(t));
+        t.row = row;
+        t.col = col;
+        t.kernel_id = (pangulu_int16_t)kernel;
+        t.task_level = level;
+        t.compare_flag = level;
+        t.opdst = dst;
+        t.op1 = op1;
+        t.op2 = nullptr;
+        S.heap.push(t);
+    }
+
+    static u32 tile_index(const slot_t *dst)
+    {
+        // canonical owned-slot index of a destination tile (diagonal tiles: their lower half)
+        if (dst->brow_pos == dst->bcol_pos && dst->is_upper)
+            return (u32)dst->related_block->slot_idx;
+        return (u32)dst->slot_idx;
+    }
+
+    // Queue C(row,col) -= op1 * op2 on its destination tile, then run the check the reference performs when
+    // the heap copy of an SSSSM task is popped (src/pangulu_numeric.c:602-650).  Caller holds info_mutex and
+    // has already decremented the destination's counter.
+    void queue_update(u32 row, u32 col, u32 level, slot_t *dst, slot_t *op1, slot_t *op2, u64 dst_bidx)
+    {
+        task_t t;
+        memset(&t, 0, sizeof(t));
+        t.row = row;
+        t.col = col;
+        t.kernel_id = PANGULU_TASK_SSSSM;
+        t.task_level = level;
+        t.compare_flag = level;
+        t.opdst = dst;
+        t.op1 = op1;
+        t.op2 = op2;
+        u32 ti = tile_index(dst);
+        auto &q = S.pending[ti];
+        if (q.empty())
+            S.pending_dirty.push_back(ti);
+        q.push_back(t);
+        S.pending_total++;
+
+        if (row == col)
+        {
+            if (S.remain_diag[row] == 1)
+            {
+                S.remain_diag[row]--;
+                push_panel(row, col, row, PANGULU_TASK_GETRF, dst, nullptr);
+            }
+        }
+        else if (S.remain[dst_bidx] == 1)
+        {
+            u32 lv = std::min(row, col);
+            if (row < col)
+            {
+                slot_t *dl = S.diag_lower[lv];
+                if (dl && dl->data_status == PANGULU_DATA_READY)
+                {
+                    S.remain[dst_bidx]--;
+                    push_panel(row, col, lv, PANGULU_TASK_GESSM, dst, dl);
+                }
+            }
+            else
+            {
+                slot_t *du = S.diag_upper[lv];
+                if (du && du->data_status == PANGULU_DATA_READY)
+                {
+                    S.remain[dst_bidx]--;
+                    push_panel(row, col, lv, PANGULU_TASK_TSTRF, dst, du);
+                }
+            }
+        }
+    }
+
+    void send_once(slot_t *s, int target)
+    {
+        if (sent_flag[(size_t)target])
+            return;
+        sent_flag[(size_t)target] = 1;
+        BlockHeader h;
+        memset(&h, 0, sizeof(h));
+        h.nnz = s->columnpointer[S.nb];
+        h.brow = s->brow_pos;
+        h.bcol = s->bcol_pos;
+        h.is_upper = (u32)s->is_upper;
+        size_t bytes = record_bytes(S.nb, h.nnz, s->brow_pos > s->bcol_pos);
+        h.bytes_lo = (u32)bytes;
+        comm->isend_block(s, h, target);
+    }
+
+    // ---- successor release (all under info_mutex) ---------------------------------------------------------
+    // a factorised diagonal's U half is available (local GETRF or arrival): release the TSTRFs below it
+    void release_after_diag_upper(u32 level, slot_t *upper, bool do_sends)
+    {
+        if (do_sends)
+            std::fill(sent_flag.begin(), sent_flag.end(), 0);
+        for (u64 b = P.first_after_diag[level]; b < P.colptr[level + 1]; b++)
+        {
+            u32 brow = P.rowidx[b];
+            int target = S.owner(brow, level);
+            if (target == S.rank)
+            {
+                if (S.remain[b] == 1)
+                {
+                    S.remain[b]--;
+                    push_panel(brow, level, level, PANGULU_TASK_TSTRF, S.slot_of[b], upper);
+                }
+            }
+            else if (do_sends)
+            {
+                send_once(upper, target);
+            }
+        }
+    }
+
+    void release_after_diag_lower(u32 level, slot_t *lower, bool do_sends)
+    {
+        if (do_sends)
+            std::fill(sent_flag.begin(), sent_flag.end(), 0);
+        for (u64 r = P.first_after_diag_csr[level]; r < P.rowptr[level + 1]; r++)
+        {
+            u32 bcol = P.colidx[r];
+            u64 b = P.csr_to_csc[r];
+            int target = S.owner(level, bcol);
+            if (target == S.rank)
+            {
+                if (S.remain[b] == 1)
+                {
+                    S.remain[b]--;
+                    push_panel(level, bcol, level, PANGULU_TASK_GESSM, S.slot_of[b], lower);
+                }
+            }
+            else if (do_sends)
+            {
+                send_once(lower, target);
+            }
+        }
+    }
+
+    // a finished L block L(brow, level) is available: queue C(brow, bcol) -= L(brow,level) * U(level,bcol) for
+    // every bcol > level whose U(level,bcol) is already final, forward the block to the other owners in its
+    // process row and to the owner of diagonal (brow,brow) (src/pangulu_numeric.c:436-518, 84-138)
+    void release_after_L(slot_t *L, u32 brow, u32 level, bool do_sends)
+    {
+        if (do_sends)
+            std::fill(sent_flag.begin(), sent_flag.end(), 0);
+        u64 rb = P.rowptr[brow], re = P.rowptr[brow + 1];
+        // position of (brow, level) in block row brow
+        u64 pos = (u64)(std::lower_bound(P.colidx.begin() + (i64)rb, P.colidx.begin() + (i64)re, level) - P.colidx.begin());
+        u64 ub = P.first_after_diag_csr[level], ue = P.rowptr[level + 1]; // U blocks of block row `level`
+        slot_t *u_for_diag = nullptr;
+        u64 u = ub;
+        for (u64 r = pos + 1; r < re; r++)
+        {
+            u32 bcol = P.colidx[r];
+            int target = S.owner(brow, bcol);
+            if (target == S.rank)
+            {
+                while (u < ue && P.colidx[u] < bcol)
+                    u++;
+                if (u < ue && P.colidx[u] == bcol)
+                {
+                    slot_t *U = S.slot_of[P.csr_to_csc[u]];
+                    if (U && U->data_status == PANGULU_DATA_READY)
+                    {
+                        u64 d = P.csr_to_csc[r];
+                        S.remain[d]--;
+                        queue_update(brow, bcol, level, S.slot_of[d], L, U, d);
+                    }
+                }
+            }
+            else if (do_sends)
+            {
+                send_once(L, target);
+            }
+        }
+        // diagonal destination (brow, brow) needs U(level, brow)
+        {
+            u64 hit = (u64)(std::lower_bound(P.colidx.begin() + (i64)ub, P.colidx.begin() + (i64)ue, brow) - P.colidx.begin());
+            if (hit < ue && P.colidx[hit] == brow)
+                u_for_diag = S.slot_of[P.csr_to_csc[hit]];
+            int target = S.owner(brow, brow);
+            if (target == S.rank)
+            {
+                if (u_for_diag && u_for_diag->data_status == PANGULU_DATA_READY)
+                {
+                    S.remain_diag[brow]--;
+                    queue_update(brow, brow, level, S.diag_lower[brow], L, u_for_diag, ~0ull);
+                }
+            }
+            else if (do_sends)
+            {
+                send_once(L, target);
+            }
+        }
+    }
+
+    // mirror image for a finished U block U(level, bcol) (src/pangulu_numeric.c:519-601, 139-193)
+    void release_after_U(slot_t *U, u32 level, u32 bcol, bool do_sends)
+    {
+        if (do_sends)
+            std::fill(sent_flag.begin(), sent_flag.end(), 0);
+        u64 cb = P.colptr[bcol], ce = P.colptr[bcol + 1];
+        u64 pos = (u64)(std::lower_bound(P.rowidx.begin() + (i64)cb, P.rowidx.begin() + (i64)ce, level) - P.rowidx.begin());
+        u64 lb = P.first_after_diag[level], le = P.colptr[level + 1]; // L blocks of block column `level`
+        u64 l = lb;
+        for (u64 c = pos + 1; c < ce; c++)
+        {
+            u32 brow = P.rowidx[c];
+            int target = S.owner(brow, bcol);
+            if (target == S.rank)
+            {
+                while (l < le && P.rowidx[l] < brow)
+                    l++;
+                if (l < le && P.rowidx[l] == brow)
+                {
+                    slot_t *L = S.slot_of[l];
+                    if (L && L->data_status == PANGULU_DATA_READY)
+                    {
+                        S.remain[c]--;
+                        queue_update(brow, bcol, level, S.slot_of[c], L, U, c);
+                    }
+                }
+            }
+            else if (do_sends)
+            {
+                send_once(U, target);
+            }
+        }
+        {
+            slot_t *l_for_diag = nullptr;
+            u64 hit = (u64)(std::lower_bound(P.rowidx.begin() + (i64)lb, P.rowidx.begin() + (i64)le, bcol) - P.rowidx.begin());
+            if (hit < le && P.rowidx[hit] == bcol)
+                l_for_diag = S.slot_of[hit];
+            int target = S.owner(bcol, bcol);
+            if (target == S.rank)
+            {
+                if (l_for_diag && l_for_diag->data_status == PANGULU_DATA_READY)
+                {
+                    S.remain_diag[bcol]--;
+                    queue_update(bcol, bcol, level, S.diag_lower[bcol], l_for_diag, U, ~0ull);
+                }
+            }
+            else if (do_sends)
+            {
+                send_once(U, target);
+            }
+        }
+    }
+
+    // a remote diagonal is no longer needed once all my TSTRF/GESSM tasks of that level ran
+    void consume_remote_diag(u32 level)
+    {
+        if (S.owner(level, level) == S.rank)
+            return;
+        if (--S.remain_diag[level] == 0)
+        {
+            if (S.diag_upper[level])
+            {
+                S.storage.recycle(S.diag_upper[level]);
+                S.diag_upper[level] = nullptr;
+            }
+            if (S.diag_lower[level])
+            {
+                S.storage.recycle(S.diag_lower[level]);
+                S.diag_lower[level] = nullptr;
+            }
+        }
+    }
+
+    // ---- execution -------------------------------------------------------------------------------------
+    void run_platform_batch(std::vector<task_t> &tasks)
+    {
+        if (tasks.empty())
+            return;
+        double t0 = wall_seconds();
+        plat.hybrid_batched((pangulu_inblock_idx)S.nb, tasks.size(), tasks.data());
+        t_platform += wall_seconds() - t0;
+        batches++;
+    }
+
+    // move the queued updates of the given tiles into ssssm_batch (grouped by tile, queue order kept)
+    void take_pending(u32 tile)
+    {
+        auto &q = S.pending[tile];
+        if (q.empty())
+            return;
+        ssssm_batch.insert(ssssm_batch.end(), q.begin(), q.end());
+        S.pending_total -= q.size();
+        q.clear();
+    }
+
+    void run_updates_and_release_operands()
+    {
+        if (ssssm_batch.empty())
+            return;
+        run_platform_batch(ssssm_batch);
+        if (multi)
+        {
+            // operands received from other ranks are dropped once their last consumer has run
+            // (src/pangulu_numeric.c:226-251); the device must be done with them before the slot is reused
+            bool synced = false;
+            std::lock_guard<std::mutex> g(S.info_mutex);
+            for (auto &t : ssssm_batch)
+            {
+                slot_t *ops[2] = {t.op1, t.op2};
+                for (slot_t *op : ops)
+                {
+                    if (S.owner(op->brow_pos, op->bcol_pos) == S.rank)
+                        continue;
+                    u64 b = P.find(op->brow_pos, op->bcol_pos);
+                    if (--S.remain[b] == 0)
+                    {
+                        if (!synced)
+                        {
+                            plat.synchronize();
+                            synced = true;
+                        }
+                        S.storage.recycle(S.slot_of[b]);
+                        S.slot_of[b] = nullptr;
+                    }
+                }
+            }
+        }
+        ssssm_batch.clear();
+    }
+
+    void rebuild_dirty_list()
+    {
+        size_t w = 0;
+        for (size_t i = 0; i < S.pending_dirty.size(); i++)
+            if (!S.pending[S.pending_dirty[i]].empty())
+                S.pending_dirty[w++] = S.pending_dirty[i];
+        S.pending_dirty.resize(w);
+    }
+
+    void work_batched()
+    {
+        // (1) every update queued on a tile of this drain runs first, as one batch
+        {
+            std::lock_guard<std::mutex> g(S.info_mutex);
+            for (auto &t : batch)
+                take_pending(tile_index(t.opdst));
+            if (S.pending_dirty.size() > 4096)
+                rebuild_dirty_list();
+        }
+        run_updates_and_release_operands();
+        // (2) the panel tasks themselves
+        run_platform_batch(batch);
+        if (multi)
+        {
+            plat.synchronize(); // finished blocks are about to be sent
+        }
+        // (3) successor release
+        std::lock_guard<std::mutex> g(S.info_mutex);
+        for (auto &t : batch)
+        {
+            u32 level = t.task_level;
+            if (t.kernel_id == PANGULU_TASK_GETRF)
+            {
+                slot_t *up = t.opdst->is_upper ? t.opdst : t.opdst->related_block;
+                slot_t *lo = up->related_block;
+                up->data_status = PANGULU_DATA_READY;
+                lo->data_status = PANGULU_DATA_READY;
+                release_after_diag_upper(level, up, multi);
+                release_after_diag_lower(level, lo, multi);
+            }
+            else if (t.kernel_id == PANGULU_TASK_TSTRF)
+            {
+                t.opdst->data_status = PANGULU_DATA_READY;
+                consume_remote_diag(level);
+                release_after_L(t.opdst, t.row, level, multi);
+            }
+            else if (t.kernel_id == PANGULU_TASK_GESSM)
+            {
+                t.opdst->data_status = PANGULU_DATA_READY;
+                consume_remote_diag(level);
+                release_after_U(t.opdst, level, t.col, multi);
+            }
+        }
+    }
+
+    // nothing runnable: use the time for queued updates (src/pangulu_task.c:93-177)
+    bool idle_flush()
+    {
+        {
+            std::lock_guard<std::mutex> g(S.info_mutex);
+            if (S.pending_total == 0)
+                return false;
+            for (u32 tile : S.pending_dirty)
+                take_pending(tile);
+            S.pending_dirty.clear();
+        }
+        run_updates_and_release_operands();
+        return true;
+    }
+
+    void compute_loop()
+    {
+        if (!plat.host_memory && plat.set_default_device)
+        {
+            int ndev = 1;
+            plat.get_device_num(&ndev);
+            (void)ndev; // the device was selected at init; HIP's current device is per thread
+        }
+        while (S.rank_remain_task != 0)
+        {
+            batch.clear();
+            task_t t;
+            while (S.heap.pop(t))
+                batch.push_back(t);
+            if (batch.empty())
+            {
+                if (!idle_flush())
+                    usleep(20);
+                continue;
+            }
+            S.rank_remain_task -= (i64)batch.size();
+            work_batched();
+        }
+        // updates into tiles are always flushed by the tile's own panel task, so nothing can be left
+        if (S.pending_total != 0)
+            fatal("scheduler finished with %llu queued updates", (unsigned long long)S.pending_total);
+    }
+
+    // ---- arrivals (receive thread) -------------------------------------------------------------------------
+    void handle_arrival(slot_t *s, const BlockHeader &h)
+    {
+        std::lock_guard<std::mutex> g(S.info_mutex);
+        s->brow_pos = h.brow;
+        s->bcol_pos = h.bcol;
+        s->is_upper = (i32)h.is_upper;
+        s->data_status = PANGULU_DATA_READY;
+        if (h.brow == h.bcol)
+        {
+            u32 level = h.brow;
+            if (h.is_upper)
+            {
+                S.diag_upper[level] = s;
+                s->related_block = S.diag_lower[level];
+                if (S.diag_lower[level])
+                    S.diag_lower[level]->related_block = s;
+                release_after_diag_upper(level, s, false);
+            }
+            else
+            {
+                S.diag_lower[level] = s;
+                s->related_block = S.diag_upper[level];
+                if (S.diag_upper[level])
+                    S.diag_upper[level]->related_block = s;
+                release_after_diag_lower(level, s, false);
+            }
+            return;
+        }
+        u64 b = P.find(h.brow, h.bcol);
+        if (b == ~0ull)
+            fatal("received block (%u,%u) that is not in the block pattern", h.brow, h.bcol);
+        S.slot_of[b] = s;
+        if (h.brow > h.bcol)
+            release_after_L(s, h.brow, h.bcol, false);
+        else
+            release_after_U(s, h.brow, h.bcol, false);
+    }
+
+    void receive_loop()
+    {
+        while (S.rank_remain_recv != 0)
+        {
+            BlockHeader h;
+            int src = -1;
+            if (!comm->probe_block(h, src))
+            {
+                usleep(10);
+                continue;
+            }
+            size_t bytes = h.bytes_lo;
+            slot_t *s = nullptr;
+            int spins = 0;
+            while (!(s = S.storage.allocate(bytes)))
+            {
+                // all slots of every fitting class are in use: wait for the compute thread to retire consumers
+                if (++spins == 1)
+                    fprintf(stderr, "[pangulu_amd] rank %d: receive buffers exhausted, waiting (raise PANGULU_AMD_RECV_BUDGET_GB or mpi_recv_buffer_level)\n", S.rank);
+                usleep(200);
+                if (spins > 300000)
+                    fatal("receive buffers exhausted for 60 s: dependency deadlock");
+            }
+            bind_record(*s, S.nb, h.nnz, (char *)s->value - 32, (char *)s->d_value - 32, h.brow > h.bcol, h.brow == h.bcol && h.is_upper);
+            s->brow_pos = h.brow;
+            s->bcol_pos = h.bcol;
+            s->is_upper = (i32)h.is_upper;
+            comm->recv_block(s, h, src);
+            S.rank_remain_recv--;
+            handle_arrival(s, h);
+        }
+    }
+};
+
+} // namespace
+
+void numeric_factorize(Solver &S)
+{
+    if (S.factored)
+        fatal("pangulu_gstrf called twice on one handle (call pangulu_init again)");
+    Sched sch(S);
+    Comm *comm = world();
+    Platform &plat = active_platform();
+    if (plat.set_option)
+        plat.set_option(PANGULU_HIP_OPT_HOST_MIRROR, S.eager_host_mirror ? 1 : 0);
+    S.heap.clear();
+    S.pending_total = 0;
+    S.pending_dirty.clear();
+    comm->barrier();
+    double t0 = wall_seconds();
+    {
+        std::lock_guard<std::mutex> g(S.info_mutex);
+        for (u32 level = 0; level < S.nbk; level++)
+        {
+            if (S.owner(level, level) == S.rank && S.remain_diag[level] == 1)
+            {
+                S.remain_diag[level]--;
+                sch.push_panel(level, level, level, PANGULU_TASK_GETRF, S.diag_lower[level], nullptr);
+            }
+        }
+    }
+    S.host_values_current = plat.host_memory;
+    if (S.nproc > 1)
+    {
+        std::thread worker([&]()
+                           { sch.compute_loop(); });
+        sch.receive_loop();
+        worker.join();
+        plat.synchronize();
+        comm->flush_sends();
+    }
+    else
+    {
+        sch.compute_loop();
+        plat.synchronize();
+    }
+    comm->barrier();
+    S.info.time_numeric = wall_seconds() - t0;
+    S.info.time_numeric_host_sched = S.info.time_numeric - sch.t_platform;
+    S.info.batches = sch.batches;
+    S.info.sent_bytes = comm->sent_bytes;
+    S.info.recv_bytes = comm->recv_bytes_total;
+    S.factored = true;
+    if (S.eager_host_mirror && !plat.host_memory)
+        S.host_values_current = true;
+}
+
+} // namespace pg

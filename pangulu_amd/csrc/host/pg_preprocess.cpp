@@ -1,0 +1,643 @@
+// pg_preprocess.cpp -- block records, storage, dependency counters, receive bins.
+//
+// Restates the parts of the reference's set-up whose OUTPUT is an input contract of the hot path:
+//   record layout        src/pangulu_communication.c:1290-1322, 1340-1393; device mirror src/pangulu_storage.c:295-357
+//   dependency counters  src/pangulu_preprocessing.c:132-207 (owned), 443-556 (remote consumers), 209-315 (receives)
+//   receive bins         src/pangulu_preprocessing.c:319-366, src/pangulu_storage.c:171-197
+// Unlike the reference (rank 0 builds everything and ships it), every rank derives its own records from the
+// replicated symbolic pattern, in parallel, and uploads them with one copy.
+#include <algorithm>
+#include <omp.h>
+
+#include "pg_host.h"
+
+namespace pg
+{
+
+static inline size_t pad8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+size_t record_bytes(u32 nb, u64 nnz, bool lower_offdiag)
+{
+    size_t sz = 32 + sizeof(val_t) * nnz + sizeof(pangulu_inblock_ptr) * (nb + 1) + sizeof(pangulu_inblock_idx) * nnz;
+    sz = pad8(sz);
+    if (lower_offdiag)
+    {
+        sz += sizeof(pangulu_inblock_ptr) * nnz + sizeof(pangulu_inblock_ptr) * (nb + 1) + sizeof(pangulu_inblock_idx) * nnz;
+        sz = pad8(sz);
+    }
+    return sz;
+}
+
+void bind_record(slot_t &s, u32 nb, u64 nnz, char *hrec, char *drec, bool lower_offdiag, bool diag_upper)
+{
+    auto lay = [&](char *rec, bool device)
+    {
+        char *v = rec + 32;
+        char *cp = v + sizeof(val_t) * nnz;
+        char *ri = cp + sizeof(pangulu_inblock_ptr) * (nb + 1);
+        char *csr = rec + pad8(32 + sizeof(val_t) * nnz + sizeof(pangulu_inblock_ptr) * (nb + 1) + sizeof(pangulu_inblock_idx) * nnz);
+        if (!device)
+        {
+            s.value = (val_t *)v;
+            s.columnpointer = (pangulu_inblock_ptr *)cp;
+            s.rowindex = (pangulu_inblock_idx *)ri;
+            if (lower_offdiag)
+            {
+                s.idx_of_csc_value_for_csr = (pangulu_inblock_ptr *)csr;
+                s.rowpointer = (pangulu_inblock_ptr *)(csr + sizeof(pangulu_inblock_ptr) * nnz);
+                s.columnindex = (pangulu_inblock_idx *)(csr + sizeof(pangulu_inblock_ptr) * nnz + sizeof(pangulu_inblock_ptr) * (nb + 1));
+            }
+        }
+        else
+        {
+            s.d_value = (val_t *)v;
+            if (diag_upper)
+            {
+                // the device mirror names the CSR arrays of an upper diagonal half for what they are
+                s.d_rowpointer = (pangulu_inblock_ptr *)cp;
+                s.d_columnindex = (pangulu_inblock_idx *)ri;
+            }
+            else
+            {
+                s.d_columnpointer = (pangulu_inblock_ptr *)cp;
+                s.d_rowindex = (pangulu_inblock_idx *)ri;
+            }
+            if (lower_offdiag)
+            {
+                s.d_idx_of_csc_value_for_csr = (pangulu_inblock_ptr *)csr;
+                s.d_rowpointer = (pangulu_inblock_ptr *)(csr + sizeof(pangulu_inblock_ptr) * nnz);
+                s.d_columnindex = (pangulu_inblock_idx *)(csr + sizeof(pangulu_inblock_ptr) * nnz + sizeof(pangulu_inblock_ptr) * (nb + 1));
+            }
+        }
+    };
+    lay(hrec, false);
+    lay(drec, true);
+    BlockHeader *h = (BlockHeader *)hrec;
+    h->nnz = nnz;
+    h->brow = s.brow_pos;
+    h->bcol = s.bcol_pos;
+    h->is_upper = (u32)s.is_upper;
+}
+
+slot_t *Storage::allocate(size_t bytes)
+{
+    std::lock_guard<std::mutex> g(mutex);
+    for (size_t b = 1; b < bins.size(); b++)
+    {
+        RecvBin &bin = bins[b];
+        if (bin.slot_capacity >= bytes && !bin.free_list.empty())
+        {
+            i32 idx = bin.free_list.back();
+            bin.free_list.pop_back();
+            slot_t *s = &bin.slots[idx];
+            s->data_status = PANGULU_DATA_PREPARING;
+            s->bin_id = (i32)b;
+            s->slot_idx = idx;
+            return s;
+        }
+    }
+    return nullptr;
+}
+
+void Storage::recycle(slot_t *s)
+{
+    if (!s || s->bin_id <= 0)
+        return;
+    std::lock_guard<std::mutex> g(mutex);
+    RecvBin &bin = bins[s->bin_id];
+    i32 idx = s->slot_idx, bid = s->bin_id;
+    val_t *v = s->value, *dv = s->d_value;
+    memset((void *)s, 0, sizeof(slot_t));
+    s->value = v;
+    s->d_value = dv;
+    s->bin_id = bid;
+    s->slot_idx = idx;
+    s->data_status = PANGULU_DATA_INVALID;
+    bin.free_list.push_back(idx);
+}
+
+namespace
+{
+
+// transpose an in-block CSC pattern (colptr over nb columns) into CSR order, recording for every CSR
+// position the CSC position it came from
+void transpose_inblock(u32 nb, const pangulu_inblock_ptr *cp, const pangulu_inblock_idx *ri,
+                       pangulu_inblock_ptr *rp, pangulu_inblock_idx *ci, pangulu_inblock_ptr *from)
+{
+    u32 nnz = cp[nb];
+    for (u32 r = 0; r <= nb; r++)
+        rp[r] = 0;
+    for (u32 p = 0; p < nnz; p++)
+        rp[ri[p] + 1]++;
+    for (u32 r = 0; r < nb; r++)
+        rp[r + 1] += rp[r];
+    std::vector<pangulu_inblock_ptr> cur(rp, rp + nb);
+    for (u32 c = 0; c < nb; c++)
+        for (u32 p = cp[c]; p < cp[c + 1]; p++)
+        {
+            u32 o = cur[ri[p]]++;
+            ci[o] = (pangulu_inblock_idx)c;
+            if (from)
+                from[o] = p;
+        }
+}
+
+} // namespace
+
+void preprocess(Solver &S, const CscMatrix &A)
+{
+    const BlockPattern &P = S.pat;
+    const Symbolic &sym = S.sym;
+    Platform &plat = active_platform();
+    u32 nb = S.nb, nbk = S.nbk, n = S.n;
+    int me = S.rank;
+    u64 nblk = P.colptr[nbk];
+
+    // ---- owned slots: off-diagonal blocks in block-CSC order, then diagonal halves ---------------------
+    Storage &st = S.storage;
+    st.nb = nb;
+    std::vector<u64> owned_bidx;
+    for (u32 bc = 0; bc < nbk; bc++)
+        for (u64 b = P.colptr[bc]; b < P.colptr[bc + 1]; b++)
+            if (S.owner(P.rowidx[b], bc) == me)
+                owned_bidx.push_back(b);
+    std::vector<u32> owned_diag;
+    for (u32 k = 0; k < nbk; k++)
+        if (S.owner(k, k) == me)
+            owned_diag.push_back(k);
+    st.n_owned_nondiag = owned_bidx.size();
+    st.owned.assign(owned_bidx.size() + 2 * owned_diag.size(), slot_t());
+    for (auto &s : st.owned)
+        memset((void *)&s, 0, sizeof(slot_t));
+
+    // record offsets (64-byte aligned starts so value arrays are 32-byte aligned for vector/MFMA loads)
+    std::vector<size_t> off(st.owned.size() + 1, 0);
+    auto align64 = [](size_t x)
+    { return (x + 63) & ~(size_t)63; };
+    size_t cursor = 0;
+    for (size_t i = 0; i < owned_bidx.size(); i++)
+    {
+        u64 b = owned_bidx[i];
+        u32 br = P.rowidx[b];
+        // block column of b: recover by binary search over colptr
+        off[i] = cursor;
+        u32 bc = (u32)(std::upper_bound(P.colptr.begin(), P.colptr.end(), b) - P.colptr.begin() - 1);
+        cursor = align64(cursor + record_bytes(nb, P.nnz[b], br > bc));
+    }
+    for (size_t d = 0; d < owned_diag.size(); d++)
+    {
+        u32 k = owned_diag[d];
+        size_t i = owned_bidx.size() + 2 * d;
+        off[i] = cursor;
+        cursor = align64(cursor + record_bytes(nb, P.diag_lower_nnz[k], false));
+        off[i + 1] = cursor;
+        cursor = align64(cursor + record_bytes(nb, P.diag_upper_nnz[k], false));
+    }
+    st.arena_bytes = cursor ? cursor : 64;
+    if (posix_memalign((void **)&st.harena, 64, st.arena_bytes) != 0)
+        fatal("host arena allocation of %zu bytes failed", st.arena_bytes);
+    memset(st.harena, 0, st.arena_bytes);
+    if (plat.host_memory)
+    {
+        st.darena = st.harena;
+    }
+    else
+    {
+        plat.malloc_((void **)&st.darena, st.arena_bytes);
+    }
+
+    S.slot_of.assign(nblk, nullptr);
+    S.diag_lower.assign(nbk, nullptr);
+    S.diag_upper.assign(nbk, nullptr);
+    for (size_t i = 0; i < owned_bidx.size(); i++)
+    {
+        u64 b = owned_bidx[i];
+        u32 br = P.rowidx[b];
+        u32 bc = (u32)(std::upper_bound(P.colptr.begin(), P.colptr.end(), b) - P.colptr.begin() - 1);
+        slot_t &s = st.owned[i];
+        s.brow_pos = br;
+        s.bcol_pos = bc;
+        s.is_upper = 0;
+        s.bin_id = 0;
+        s.slot_idx = (i32)i;
+        s.data_status = PANGULU_DATA_PREPARING;
+        bind_record(s, nb, P.nnz[b], st.harena + off[i], st.darena + off[i], br > bc, false);
+        S.slot_of[b] = &s;
+    }
+    for (size_t d = 0; d < owned_diag.size(); d++)
+    {
+        u32 k = owned_diag[d];
+        size_t i = owned_bidx.size() + 2 * d;
+        slot_t &lo = st.owned[i], &up = st.owned[i + 1];
+        lo.brow_pos = lo.bcol_pos = up.brow_pos = up.bcol_pos = k;
+        lo.is_upper = 0;
+        up.is_upper = 1;
+        lo.slot_idx = (i32)i;
+        up.slot_idx = (i32)(i + 1);
+        lo.related_block = &up;
+        up.related_block = &lo;
+        lo.data_status = up.data_status = PANGULU_DATA_PREPARING;
+        bind_record(lo, nb, P.diag_lower_nnz[k], st.harena + off[i], st.darena + off[i], false, false);
+        bind_record(up, nb, P.diag_upper_nnz[k], st.harena + off[i + 1], st.darena + off[i + 1], false, true);
+        S.diag_lower[k] = &lo;
+        S.diag_upper[k] = &up;
+    }
+    S.info.nblocks_owned = st.owned.size();
+    S.info.owned_bytes = st.arena_bytes;
+
+    // ---- patterns: one sweep per block column over the symbolic lower pattern ------------------------
+    // lower block (br, bc), br > bc, is needed by its owner (CSC + CSR view) and by the owner of the upper
+    // block (bc, br), whose CSC is the transpose.
+#pragma omp parallel
+    {
+        std::vector<i64> local_of(nbk, -1);      // block row -> position in this column's lower block list
+        std::vector<std::vector<pangulu_inblock_idx>> tmp_ri;
+        std::vector<std::vector<pangulu_inblock_ptr>> tmp_cp;
+        std::vector<u32> cursor_nnz;
+#pragma omp for schedule(dynamic, 2)
+        for (i64 bc_ = 0; bc_ < (i64)nbk; bc_++)
+        {
+            u32 bc = (u32)bc_;
+            u64 l0 = P.lcolptr[bc], l1 = P.lcolptr[bc + 1];
+            size_t nl = (size_t)(l1 - l0);
+            // which of this column's lower blocks do I need?
+            std::vector<char> need(nl, 0);
+            bool any = false;
+            for (size_t t = 0; t < nl; t++)
+            {
+                u32 br = P.lrowidx[l0 + t];
+                bool mine = (br == bc) ? (S.owner(bc, bc) == me) : (S.owner(br, bc) == me || S.owner(bc, br) == me);
+                need[t] = mine;
+                any |= mine;
+                local_of[br] = (i64)t;
+            }
+            if (any)
+            {
+                tmp_ri.assign(nl, {});
+                tmp_cp.assign(nl, {});
+                for (size_t t = 0; t < nl; t++)
+                    if (need[t])
+                    {
+                        tmp_ri[t].reserve(P.lnnz[l0 + t]);
+                        tmp_cp[t].assign(nb + 1, 0);
+                    }
+                u32 j0 = bc * nb, j1 = std::min(n, j0 + nb);
+                for (u32 j = j0; j < j1; j++)
+                {
+                    u32 c = j - j0;
+                    for (u64 p = sym.ptr[j]; p < sym.ptr[j + 1]; p++)
+                    {
+                        u32 i = sym.idx[p];
+                        i64 t = local_of[i / nb];
+                        if (t >= 0 && need[(size_t)t])
+                        {
+                            tmp_ri[(size_t)t].push_back((pangulu_inblock_idx)(i % nb));
+                        }
+                    }
+                    for (size_t t = 0; t < nl; t++)
+                        if (need[t])
+                            tmp_cp[t][c + 1] = (pangulu_inblock_ptr)tmp_ri[t].size();
+                }
+                for (u32 c = j1 - j0; c < nb; c++)
+                    for (size_t t = 0; t < nl; t++)
+                        if (need[t])
+                            tmp_cp[t][c + 1] = (pangulu_inblock_ptr)tmp_ri[t].size();
+
+                for (size_t t = 0; t < nl; t++)
+                {
+                    if (!need[t])
+                        continue;
+                    u32 br = P.lrowidx[l0 + t];
+                    const auto &cp = tmp_cp[t];
+                    const auto &ri = tmp_ri[t];
+                    if (br == bc)
+                    {
+                        // diagonal block: strictly-lower CSC half + (diagonal first) CSR upper half whose row r
+                        // mirrors lower column r
+                        slot_t *lo = S.diag_lower[bc], *up = S.diag_upper[bc];
+                        u32 ol = 0, ou = 0;
+                        lo->columnpointer[0] = 0;
+                        up->columnpointer[0] = 0;
+                        for (u32 c = 0; c < nb; c++)
+                        {
+                            for (u32 p = cp[c]; p < cp[c + 1]; p++)
+                            {
+                                u32 r = ri[p];
+                                up->rowindex[ou++] = (pangulu_inblock_idx)r; // r == c first (diagonal), then r > c
+                                if (r != c)
+                                    lo->rowindex[ol++] = (pangulu_inblock_idx)r;
+                            }
+                            lo->columnpointer[c + 1] = ol;
+                            up->columnpointer[c + 1] = ou;
+                        }
+                        continue;
+                    }
+                    u64 bl = P.find(br, bc); // lower block (br, bc)
+                    u64 bu = P.find(bc, br); // its mirror, upper block (bc, br)
+                    slot_t *sl = S.slot_of[bl], *su = S.slot_of[bu];
+                    if (sl)
+                    {
+                        std::copy(cp.begin(), cp.end(), sl->columnpointer);
+                        std::copy(ri.begin(), ri.end(), sl->rowindex);
+                        transpose_inblock(nb, sl->columnpointer, sl->rowindex, sl->rowpointer, sl->columnindex, sl->idx_of_csc_value_for_csr);
+                    }
+                    if (su)
+                    {
+                        // CSC of U(bc, br) = CSR of L(br, bc) with the roles of row and column swapped
+                        transpose_inblock(nb, cp.data(), ri.data(), su->columnpointer, su->rowindex, nullptr);
+                    }
+                }
+            }
+            for (size_t t = 0; t < nl; t++)
+                local_of[P.lrowidx[l0 + t]] = -1;
+        }
+    }
+
+    // ---- values: scatter the permuted A into the owned patterns (zero elsewhere) ----------------------
+    // (the reference's pangulu_convert_block_fill_value_to_struct, src/pangulu_conversion.c:241-350)
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 j_ = 0; j_ < (i64)n; j_++)
+    {
+        u32 j = (u32)j_, bj = j / nb, c = j % nb;
+        for (u64 p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+        {
+            u32 i = A.rowidx[p], bi = i / nb, r = i % nb;
+            slot_t *s = nullptr;
+            bool csr_row_search = false;
+            if (bi == bj)
+            {
+                if (i > j)
+                    s = S.diag_lower[bj];
+                else
+                {
+                    s = S.diag_upper[bj];
+                    csr_row_search = true;
+                }
+            }
+            else
+            {
+                if (S.owner(bi, bj) != me)
+                    continue;
+                u64 b = P.find(bi, bj);
+                if (b == ~0ull)
+                    fatal("entry (%u,%u) of A outside the symbolic block pattern", i, j);
+                s = S.slot_of[b];
+            }
+            if (!s)
+                continue;
+            u32 major = csr_row_search ? r : c, minor = csr_row_search ? c : r;
+            const pangulu_inblock_idx *b0 = s->rowindex + s->columnpointer[major];
+            const pangulu_inblock_idx *b1 = s->rowindex + s->columnpointer[major + 1];
+            const pangulu_inblock_idx *hit = std::lower_bound(b0, b1, (pangulu_inblock_idx)minor);
+            if (hit == b1 || *hit != minor)
+                fatal("entry (%u,%u) of A outside the symbolic pattern", i, j);
+            s->value[hit - s->rowindex] = A.value[p];
+        }
+    }
+
+    // ---- dependency counters (src/pangulu_preprocessing.c:132-207, 443-556) ---------------------------
+    S.remain.assign(nblk, 0);
+    S.remain_diag.assign(nbk, 0);
+    // every structurally possible update L(a,k) * U(k,b) -> (a,b): a in Lcol(k), b in Lcol(k) (mirror)
+    // counted on the destination if I own it, and on each remote operand once per update of mine.
+    i64 my_ssssm = 0;
+#pragma omp parallel
+    {
+        std::vector<i64> pos(nbk, -1); // block row -> index (block-CSC) within destination column b
+#pragma omp for schedule(dynamic, 2) reduction(+ : my_ssssm)
+        for (i64 b_ = 0; b_ < (i64)nbk; b_++)
+        {
+            u32 b = (u32)b_;
+            for (u64 t = P.colptr[b]; t < P.colptr[b + 1]; t++)
+                pos[P.rowidx[t]] = (i64)t;
+            // k runs over the U blocks of column b: U(k,b), k < b
+            for (u64 t = P.colptr[b]; t < P.first_after_diag[b]; t++)
+            {
+                u32 k = P.rowidx[t];
+                u64 ukb = t;
+                // a runs over the L blocks of column k: L(a,k), a > k
+                for (u64 la = P.first_after_diag[k]; la < P.colptr[k + 1]; la++)
+                {
+                    u32 a = P.rowidx[la];
+                    bool dst_mine;
+                    if (a == b)
+                    {
+                        dst_mine = S.owner(b, b) == me;
+                        if (dst_mine)
+                        {
+#pragma omp atomic
+                            S.remain_diag[b]++;
+                        }
+                    }
+                    else
+                    {
+                        i64 d = pos[a];
+                        if (d < 0)
+                            continue; // destination block structurally empty: the product is structurally zero
+                        dst_mine = S.owner(a, b) == me;
+                        if (dst_mine)
+                            S.remain[(size_t)d]++; // column b is handled by this thread only
+                    }
+                    if (dst_mine)
+                    {
+                        my_ssssm++;
+                        if (S.owner(a, k) != me)
+                        {
+#pragma omp atomic
+                            S.remain[la]++;
+                        }
+                        if (S.owner(k, b) != me)
+                        {
+#pragma omp atomic
+                            S.remain[ukb]++;
+                        }
+                    }
+                }
+            }
+            for (u64 t = P.colptr[b]; t < P.colptr[b + 1]; t++)
+                pos[P.rowidx[t]] = -1;
+        }
+    }
+    // + 1 for the panel operation of every owned block; remote diagonals count my TSTRF/GESSM consumers
+    i64 my_tasks = 0, my_getrf = 0, my_tstrf = 0, my_gessm = 0, my_recv = 0;
+    for (u32 bc = 0; bc < nbk; bc++)
+    {
+        for (u64 t = P.colptr[bc]; t < P.colptr[bc + 1]; t++)
+        {
+            u32 br = P.rowidx[t];
+            if (S.owner(br, bc) == me)
+            {
+                S.remain[t] += 1;
+                my_tasks++;
+                u32 level = std::min(br, bc);
+                if (br > bc)
+                    my_tstrf++;
+                else
+                    my_gessm++;
+                if (S.owner(level, level) != me)
+                    S.remain_diag[level]++;
+            }
+            else if (S.remain[t] > 0)
+            {
+                my_recv++;
+            }
+        }
+    }
+    for (u32 k = 0; k < nbk; k++)
+    {
+        if (S.owner(k, k) == me)
+        {
+            S.remain_diag[k] += 1;
+            my_tasks++;
+            my_getrf++;
+        }
+        else if (S.remain_diag[k] > 0)
+        {
+            // a remote diagonal arrives as up to two records: the U half if I run TSTRFs below it, the L half
+            // if I run GESSMs right of it
+            bool need_u = false, need_l = false;
+            for (u64 t = P.first_after_diag[k]; t < P.colptr[k + 1] && !need_u; t++)
+                need_u = S.owner(P.rowidx[t], k) == me;
+            for (u64 t = P.first_after_diag_csr[k]; t < P.rowptr[k + 1] && !need_l; t++)
+                need_l = S.owner(k, P.colidx[t]) == me;
+            my_recv += (need_u ? 1 : 0) + (need_l ? 1 : 0);
+        }
+    }
+    S.rank_remain_task = my_tasks; // SSSSM updates bypass the heap in this build (see pg_numeric.cpp)
+    S.rank_remain_recv = my_recv;
+    S.remain0 = S.remain;
+    S.remain_diag0 = S.remain_diag;
+    S.rank_remain_task0 = S.rank_remain_task;
+    S.rank_remain_recv0 = S.rank_remain_recv;
+    S.info.ntask_getrf = (u64)my_getrf;
+    S.info.ntask_tstrf = (u64)my_tstrf;
+    S.info.ntask_gessm = (u64)my_gessm;
+    S.info.ntask_ssssm = (u64)my_ssssm;
+    S.info.recv_blocks = (u64)my_recv;
+    S.heap.reserve((size_t)my_tasks + 1);
+    S.pending.assign(st.owned.size(), {});
+
+    // ---- receive bins (src/pangulu_preprocessing.c:319-366) -------------------------------------------
+    st.bins.clear();
+    st.bins.resize(7);
+    if (S.nproc > 1)
+    {
+        // six size classes by nnz, as the reference: tiny, one entry per row/col x4, ~1% .. full
+        u64 full = (u64)nb * nb;
+        u64 cls_nnz[7] = {0,
+                          std::max<u64>(5, full / 1024),
+                          std::max<u64>(4ull * nb, full / 256),
+                          std::max<u64>((u64)nb * std::max<u32>(nb / 100, 8), full / 64),
+                          full / 16,
+                          full / 4,
+                          full};
+        for (int b = 1; b <= 6; b++)
+            cls_nnz[b] = std::min(cls_nnz[b], full);
+        // how many remote blocks of each class will I receive in total?  slots = level * that, floored
+        u64 need_cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+        auto classify = [&](u64 nnz)
+        {
+            for (int b = 1; b <= 6; b++)
+                if (nnz <= cls_nnz[b])
+                    return b;
+            return 6;
+        };
+        for (u32 bc = 0; bc < nbk; bc++)
+            for (u64 t = P.colptr[bc]; t < P.colptr[bc + 1]; t++)
+                if (S.owner(P.rowidx[t], bc) != me && S.remain[t] > 0)
+                    need_cnt[classify(P.nnz[t])]++;
+        for (u32 k = 0; k < nbk; k++)
+            if (S.owner(k, k) != me && S.remain_diag[k] > 0)
+                need_cnt[classify(P.diag_upper_nnz[k])] += 2;
+        // The reference sizes bins as a fraction of block_length (init_options.mpi_recv_buffer_level) and aborts
+        // when they run dry (src/pangulu_storage.c:109-132).  With 288 GB of HBM per GPU the safe choice is
+        // affordable: provision one slot per block this rank will ever receive as long as that stays within
+        // the budget (PANGULU_AMD_RECV_BUDGET_GB, default 48); beyond it fall back to the level-scaled share
+        // and let the receiver stop draining its peers while a class is exhausted.
+        float level = S.recv_buffer_level > 0 ? S.recv_buffer_level : 0.5f;
+        const char *budget_env = getenv("PANGULU_AMD_RECV_BUDGET_GB");
+        double budget = (budget_env ? atof(budget_env) : 48.0) * 1e9;
+        double full_bytes = 0;
+        for (int b = 1; b <= 6; b++)
+            full_bytes += (double)((record_bytes(nb, cls_nnz[b], true) + 63) & ~(size_t)63) * (double)(need_cnt[b] + 2);
+        bool provision_all = full_bytes <= budget;
+        for (int b = 1; b <= 6; b++)
+        {
+            RecvBin &bin = st.bins[b];
+            bin.slot_capacity = (record_bytes(nb, cls_nnz[b], true) + 63) & ~(size_t)63;
+            u64 want = (u64)(level * (float)need_cnt[b]) + 64;
+            u64 cnt = provision_all ? need_cnt[b] + 2 : std::min<u64>(need_cnt[b] + 2, want);
+            if (need_cnt[b] == 0)
+                cnt = 0;
+            size_t bytes = bin.slot_capacity * cnt;
+            bin.slots.assign(cnt, slot_t());
+            bin.free_list.clear();
+            if (cnt == 0)
+                continue;
+            if (posix_memalign((void **)&bin.hbuf, 64, bytes) != 0)
+                fatal("receive bin allocation failed");
+            if (plat.host_memory)
+                bin.dbuf = bin.hbuf;
+            else
+                plat.malloc_((void **)&bin.dbuf, bytes);
+            for (u64 i = 0; i < cnt; i++)
+            {
+                slot_t &s = bin.slots[i];
+                memset((void *)&s, 0, sizeof(slot_t));
+                s.value = (val_t *)(bin.hbuf + i * bin.slot_capacity + 32);
+                s.d_value = (val_t *)(bin.dbuf + i * bin.slot_capacity + 32);
+                s.bin_id = b;
+                s.slot_idx = (i32)i;
+                bin.free_list.push_back((i32)(cnt - 1 - i));
+            }
+        }
+    }
+
+    // ---- upload -------------------------------------------------------------------------------------------
+    if (!plat.host_memory)
+    {
+        plat.memcpy_(st.darena, st.harena, st.arena_bytes, 0);
+        plat.synchronize();
+        if (plat.prepare_diag)
+            for (u32 k : owned_diag)
+                plat.prepare_diag((pangulu_inblock_idx)nb, S.diag_lower[k]);
+    }
+    S.host_values_current = true;
+}
+
+void download_factors(Solver &S)
+{
+    if (S.host_values_current)
+        return;
+    Platform &plat = active_platform();
+    if (!plat.host_memory)
+    {
+        plat.synchronize();
+        // values are the only part of a record the numeric phase changes; one pass over the arena is simpler
+        // and, with records being value-dominated, barely more traffic than per-block copies
+        plat.memcpy_(S.storage.harena, S.storage.darena, S.storage.arena_bytes, 1);
+    }
+    S.host_values_current = true;
+}
+
+Solver::~Solver()
+{
+    Platform &plat = active_platform();
+    if (storage.harena)
+    {
+        if (!plat.host_memory && storage.darena)
+            plat.free_(storage.darena);
+        free(storage.harena);
+    }
+    for (auto &bin : storage.bins)
+    {
+        if (bin.hbuf)
+        {
+            if (!plat.host_memory && bin.dbuf)
+                plat.free_(bin.dbuf);
+            free(bin.hbuf);
+        }
+    }
+}
+
+} // namespace pg

@@ -1,0 +1,139 @@
+// pg_sptrsv.cpp -- block forward/backward substitution for pangulu_gstrs ("next" row f1 of SURVEY.md §8).
+//
+// Same sweep as the reference (src/pangulu_sptrsv.c:24-191): block row by block row, every rank of the
+// diagonal owner's process row adds the products of its own blocks, the diagonal owner sums the partial
+// vectors, solves with its diagonal half and broadcasts the finished segment.  Like the reference (which pins
+// the solve to PANGULU_PLATFORM_CPU_NAIVE, src/pangulu_sptrsv.c:62,94,126,159) it runs on the host copies of
+// the factors; the in-block kernels follow ...0100000.c:435-506.
+#include <cmath>
+
+#include "pg_host.h"
+
+namespace pg
+{
+
+namespace
+{
+
+#ifdef PANGULU_COMPLEX
+inline val_t vmul(val_t a, val_t b) { return val_t{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+inline val_t vsub(val_t a, val_t b) { return val_t{a.re - b.re, a.im - b.im}; }
+inline val_t vadd(val_t a, val_t b) { return val_t{a.re + b.re, a.im + b.im}; }
+inline val_t vdiv(val_t a, val_t b)
+{
+    calculate_real_type d = b.re * b.re + b.im * b.im;
+    return val_t{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+inline double vreal(val_t a) { return (double)a.re; }
+inline val_t vmake(double r) { return val_t{(calculate_real_type)r, 0}; }
+#else
+inline val_t vmul(val_t a, val_t b) { return a * b; }
+inline val_t vsub(val_t a, val_t b) { return a - b; }
+inline val_t vadd(val_t a, val_t b) { return a + b; }
+inline val_t vdiv(val_t a, val_t b) { return a / b; }
+inline double vreal(val_t a) { return (double)a; }
+inline val_t vmake(double r) { return (val_t)r; }
+#endif
+
+// y -= A x for a CSC block
+void block_spmv(u32 nb, const slot_t *a, const val_t *x, val_t *y)
+{
+    for (u32 c = 0; c < nb; c++)
+    {
+        val_t xc = x[c];
+        for (u32 p = a->columnpointer[c]; p < a->columnpointer[c + 1]; p++)
+            y[a->rowindex[p]] = vsub(y[a->rowindex[p]], vmul(a->value[p], xc));
+    }
+}
+
+void block_lower_solve(u32 nb, const slot_t *l, val_t *x)
+{
+    for (u32 c = 0; c < nb; c++)
+    {
+        val_t xc = x[c];
+        for (u32 p = l->columnpointer[c]; p < l->columnpointer[c + 1]; p++)
+            x[l->rowindex[p]] = vsub(x[l->rowindex[p]], vmul(l->value[p], xc));
+    }
+}
+
+void block_upper_solve(u32 nb, const slot_t *u, val_t *x)
+{
+    for (i64 r = (i64)nb - 1; r >= 0; r--)
+    {
+        u32 b = u->columnpointer[r], e = u->columnpointer[r + 1];
+        if (b == e)
+            continue;
+        val_t acc = x[r];
+        for (u32 p = b + 1; p < e; p++)
+            acc = vsub(acc, vmul(u->value[p], x[u->rowindex[p]]));
+        val_t d = u->value[b];
+        x[r] = (std::fabs(vreal(d)) > PANGULU_SPTRSV_TOL) ? vdiv(acc, d) : vdiv(acc, vmake(PANGULU_SPTRSV_TOL));
+    }
+}
+
+} // namespace
+
+void triangular_solve(Solver &S, val_t *rhs)
+{
+    download_factors(S);
+    Comm *comm = world();
+    const BlockPattern &P = S.pat;
+    u32 nb = S.nb, nbk = S.nbk;
+    int q = S.q, me = S.rank;
+    std::vector<val_t> x((size_t)nbk * nb, vmake(0)), acc(nb), tmp(nb);
+    std::copy(rhs, rhs + S.n, x.begin());
+    const int TAG_PART = 0x100000;
+
+    for (int pass = 0; pass < 2; pass++)
+    {
+        bool lower = pass == 0;
+        for (u32 step = 0; step < nbk; step++)
+        {
+            u32 brow = lower ? step : nbk - 1 - step;
+            val_t *seg = x.data() + (size_t)brow * nb;
+            int diag_rank = S.owner(brow, brow);
+            bool in_row = (me / q) == (diag_rank / q);
+            if (in_row)
+            {
+                std::fill(acc.begin(), acc.end(), vmake(0));
+                // my blocks of block row brow on the relevant side of the diagonal
+                u64 rb = lower ? P.rowptr[brow] : P.first_after_diag_csr[brow];
+                u64 re = lower ? P.first_after_diag_csr[brow] : P.rowptr[brow + 1];
+                for (u64 r = rb; r < re; r++)
+                {
+                    u32 bcol = P.colidx[r];
+                    if (S.owner(brow, bcol) != me)
+                        continue;
+                    slot_t *blk = S.slot_of[P.csr_to_csc[r]];
+                    block_spmv(nb, blk, x.data() + (size_t)bcol * nb, acc.data());
+                }
+                if (me == diag_rank)
+                {
+                    for (int r = (me / q) * q; r < (me / q + 1) * q; r++)
+                    {
+                        if (r == me)
+                            continue;
+                        comm->recv_bytes(r, TAG_PART + (int)(brow & 0xfffff), tmp.data(), sizeof(val_t) * nb);
+                        for (u32 i = 0; i < nb; i++)
+                            acc[i] = vadd(acc[i], tmp[i]);
+                    }
+                    for (u32 i = 0; i < nb; i++)
+                        seg[i] = vadd(seg[i], acc[i]);
+                    if (lower)
+                        block_lower_solve(nb, S.diag_lower[brow], seg);
+                    else
+                        block_upper_solve(nb, S.diag_upper[brow], seg);
+                }
+                else
+                {
+                    comm->send_bytes(diag_rank, TAG_PART + (int)(brow & 0xfffff), acc.data(), sizeof(val_t) * nb);
+                }
+            }
+            comm->bcast(seg, sizeof(val_t) * nb, diag_rank);
+        }
+        comm->barrier();
+    }
+    std::copy(x.begin(), x.begin() + S.n, rhs);
+}
+
+} // namespace pg

@@ -1,0 +1,1439 @@
+// pg_hip_platform.hip -- the MI355X (gfx950 / CDNA4) back-end behind the platform C-ABI (include/pangulu_platform.h).
+//
+// Replaces the reference's CUDA back-end (src/platforms/02_NONSHAREDMEM/01_GPU/000_CUDA/pangulu_platform_0201000.cu)
+// with kernels designed for 64-wide wavefronts, 160 KB of LDS per CU and the f64 matrix cores:
+//
+//   SSSSM  sparse : ONE launch per batch (the reference launches one kernel per task, ...0201000.cu:856-863, from a
+//                   serial host loop, :875-898).  Tasks are grouped by destination block; one wavefront owns one
+//                   destination column for ALL updates of the group: the column is scattered once into a dense LDS
+//                   vector, every op2 entry of that column streams the matching op1 column through it with
+//                   coalesced CSC walks, and the column is gathered back once.  No atomics at all (the reference
+//                   uses shared + global atomicAdd, :467-545), results are deterministic.
+//   SSSSM  dense  : destination, op1 and op2 completely full -> the value arrays ARE column-major nb x nb
+//                   matrices (reference rule ...0201000.cu:827); C -= sum_t A_t * B_t runs on
+//                   v_mfma_f64_16x16x4_f64 with the accumulators kept in registers across all tasks of a group.
+//   TSTRF / GESSM : one wavefront per row / column of the block in a dense LDS vector (batched over blocks).
+//   GETRF         : one 1024-thread workgroup per diagonal block, right-looking elimination on a dense scratch
+//                   image that is only ever touched on the block's (symbolically closed) pattern.
+//
+// CPU semantics being matched: ...01_SHAREDMEM/00_CPU/000_CPU/pangulu_platform_0100000.c:57-431 (incl. the
+// PANGULU_TOL pivot clamp of :79-84,152-157, which the reference's GPU path lacks).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../../include/pangulu_platform.h"
+
+typedef calculate_type val_t;
+typedef calculate_real_type real_t;
+typedef pangulu_storage_slot_t slot_t;
+typedef pangulu_task_t task_t;
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef unsigned long long u64;
+
+#define HIP_CHECK(expr)                                                                                              \
+    do                                                                                                               \
+    {                                                                                                                \
+        hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess)                                                                                        \
+        {                                                                                                            \
+            fprintf(stderr, "[PanguLU-AMD ERROR] HIP error at %s:%d %s (code=%d)\n", __FILE__, __LINE__,             \
+                    hipGetErrorString(e_), (int)e_);                                                                 \
+            exit(EXIT_FAILURE);                                                                                      \
+        }                                                                                                            \
+    } while (0)
+
+// weak: the reference host defines these (src/pangulu.c:7-9)
+extern "C"
+{
+    __attribute__((weak)) int pangulu_gpu_kernel_warp_per_block = 4;
+    __attribute__((weak)) int pangulu_gpu_data_move_warp_per_block = 4;
+    __attribute__((weak)) int pangulu_gpu_shared_mem_size = 0;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// value arithmetic (HIP has no _Complex; complex types are (re, im) pairs like the reference hand-expands)
+// -----------------------------------------------------------------------------------------------------------------
+#ifdef PANGULU_COMPLEX
+__host__ __device__ inline val_t v_make(real_t r) { return val_t{r, (real_t)0}; }
+__host__ __device__ inline val_t v_mul(val_t a, val_t b) { return val_t{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__host__ __device__ inline val_t v_sub(val_t a, val_t b) { return val_t{a.re - b.re, a.im - b.im}; }
+// a - b*c
+__host__ __device__ inline val_t v_submul(val_t a, val_t b, val_t c)
+{
+    return val_t{a.re - (b.re * c.re - b.im * c.im), a.im - (b.re * c.im + b.im * c.re)};
+}
+__host__ __device__ inline val_t v_div(val_t a, val_t b)
+{
+    real_t d = b.re * b.re + b.im * b.im;
+    return val_t{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+__host__ __device__ inline real_t v_realpart(val_t a) { return a.re; }
+#else
+__host__ __device__ inline val_t v_make(real_t r) { return r; }
+__host__ __device__ inline val_t v_mul(val_t a, val_t b) { return a * b; }
+__host__ __device__ inline val_t v_sub(val_t a, val_t b) { return a - b; }
+__host__ __device__ inline val_t v_submul(val_t a, val_t b, val_t c) { return a - b * c; } // contracts to one FMA
+__host__ __device__ inline val_t v_div(val_t a, val_t b) { return a / b; }
+__host__ __device__ inline real_t v_realpart(val_t a) { return a; }
+#endif
+
+// the CPU path's pivot clamp (...0100000.c:79-84): |real part| < 1e-16 -> +1e-16
+__device__ inline val_t clamp_pivot(val_t p)
+{
+    real_t r = v_realpart(p);
+    if ((r < 0 ? -r : r) < (real_t)PANGULU_TOL)
+        return v_make((real_t)PANGULU_TOL);
+    return p;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// device-side descriptors
+// -----------------------------------------------------------------------------------------------------------------
+struct BlkView // one compressed view of a block: pointer array over the major dimension, minor indices, values
+{
+    const u32 *ptr;
+    const u16 *idx;
+    val_t *val;
+};
+
+struct SsssmTaskD
+{
+    BlkView a; // op1 (L block), CSC
+    BlkView b; // op2 (U block), CSC
+};
+
+struct SsssmGroupD
+{
+    BlkView c;        // destination CSC (diagonal destination: its strictly-lower half)
+    // diagonal destination only: column view of the upper half (built once per diagonal block, see DiagAux)
+    const u32 *ucp;
+    const u16 *uri;
+    const u32 *uvi;
+    val_t *uval;
+    u32 task_begin, task_end;
+};
+
+struct TrsmTaskD
+{
+    // vectors of the block being solved: TSTRF walks rows (CSR view + map into the CSC values), GESSM columns
+    const u32 *vptr;
+    const u16 *vidx;
+    const u32 *vmap; // nullptr for GESSM
+    val_t *bval;
+    // triangular factor: TSTRF: upper half, CSR, diagonal first in each row; GESSM: strictly-lower CSC, unit diagonal
+    const u32 *tptr;
+    const u16 *tidx;
+    const val_t *tval;
+    u32 is_tstrf;
+    u32 pad_;
+};
+
+struct GetrfTaskD
+{
+    const u32 *lcp;
+    const u16 *lri;
+    val_t *lval;
+    const u32 *urp;
+    const u16 *uci;
+    val_t *uval;
+    val_t *dense; // nb*nb scratch, only touched on the pattern
+};
+
+__device__ inline u32 ptr0(const u32 *p, int i) { return i == 0 ? 0u : p[i]; }
+
+__device__ inline void wave_lds_fence()
+{
+    // LDS operations of one wavefront execute in order; this only stops the compiler from reordering them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ inline unsigned long long wave_sum(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// SSSSM, sparse.  grid = groups * ceil(nb / WAVES) workgroups of WAVES wavefronts; wave w of block (g, cb) owns
+// destination column cb*WAVES + w of group g.
+// -----------------------------------------------------------------------------------------------------------------
+#define SSSSM_WAVES 4
+
+__global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const SsssmGroupD *__restrict__ groups,
+                                                                         const SsssmTaskD *__restrict__ tasks, int nb,
+                                                                         unsigned long long *flop_counter)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    val_t *smem = reinterpret_cast<val_t *>(smem_raw);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int colblocks = (nb + SSSSM_WAVES - 1) / SSSSM_WAVES;
+    const int g = blockIdx.x / colblocks;
+    const int j = (blockIdx.x % colblocks) * SSSSM_WAVES + wave;
+    if (j >= nb)
+        return;
+    val_t *acc = smem + (size_t)wave * nb;
+    const SsssmGroupD G = groups[g];
+
+    // does any update of the group touch column j at all?  (cheap uniform scan; most columns of sparse blocks don't)
+    bool any = false;
+    for (u32 t = G.task_begin; t < G.task_end && !any; t++)
+    {
+        const u32 *bp = tasks[t].b.ptr;
+        any = bp[j + 1] > ptr0(bp, j);
+    }
+    if (!any)
+        return;
+
+    const u32 c0 = ptr0(G.c.ptr, j), c1 = G.c.ptr[j + 1];
+    for (u32 p = c0 + lane; p < c1; p += 64)
+        acc[G.c.idx[p]] = G.c.val[p];
+    u32 u0 = 0, u1 = 0;
+    if (G.ucp)
+    {
+        u0 = G.ucp[j];
+        u1 = G.ucp[j + 1];
+        for (u32 p = u0 + lane; p < u1; p += 64)
+            acc[G.uri[p]] = G.uval[G.uvi[p]];
+    }
+    wave_lds_fence();
+
+    unsigned long long fmas = 0;
+    for (u32 t = G.task_begin; t < G.task_end; t++)
+    {
+        const BlkView A = tasks[t].a, B = tasks[t].b;
+        const u32 b0 = ptr0(B.ptr, j), b1 = B.ptr[j + 1];
+        for (u32 qb = b0; qb < b1; qb += 64)
+        {
+            // one coalesced read of up to 64 entries of op2's column, then broadcast them one by one
+            const u32 cnt = min(64u, b1 - qb);
+            u32 my_k = 0, my_a0 = 0, my_a1 = 0;
+            val_t my_b = v_make(0);
+            if ((u32)lane < cnt)
+            {
+                my_k = B.idx[qb + lane];
+                my_b = B.val[qb + lane];
+                my_a0 = ptr0(A.ptr, (int)my_k);
+                my_a1 = A.ptr[my_k + 1];
+            }
+            for (u32 i = 0; i < cnt; i++)
+            {
+                const u32 a0 = __shfl(my_a0, (int)i, 64), a1 = __shfl(my_a1, (int)i, 64);
+#ifdef PANGULU_COMPLEX
+                val_t bv;
+                bv.re = __shfl(my_b.re, (int)i, 64);
+                bv.im = __shfl(my_b.im, (int)i, 64);
+#else
+                const val_t bv = __shfl(my_b, (int)i, 64);
+#endif
+                for (u32 r = a0 + lane; r < a1; r += 64)
+                {
+                    const u32 row = A.idx[r];
+                    acc[row] = v_submul(acc[row], A.val[r], bv);
+                    fmas++;
+                }
+                wave_lds_fence();
+            }
+        }
+    }
+
+    for (u32 p = c0 + lane; p < c1; p += 64)
+        G.c.val[p] = acc[G.c.idx[p]];
+    if (G.ucp)
+    {
+        for (u32 p = u0 + lane; p < u1; p += 64)
+            G.uval[G.uvi[p]] = acc[G.uri[p]];
+    }
+    fmas = wave_sum(fmas);
+    if (lane == 0 && fmas)
+        atomicAdd(flop_counter, 2ull * fmas);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// SSSSM, dense (R64): C(nb x nb) -= sum_t A_t * B_t on the f64 matrix cores.  Workgroup = 4 wavefronts = one
+// 128 x 128 tile of C, each wavefront a 64 x 64 sub-tile held as 4 x 4 accumulators of v_mfma_f64_16x16x4_f64
+// (A frag: lane l holds A[row l&15][k = l>>4]; B frag: B[k = l>>4][col l&15]; D: col = l&15, row = (l>>4) + 4*reg).
+// -----------------------------------------------------------------------------------------------------------------
+#if defined(CALCULATE_TYPE_R64)
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
+                                                               const SsssmTaskD *__restrict__ tasks, int nb)
+{
+    const int tiles = nb / 128;
+    const int g = blockIdx.x / (tiles * tiles);
+    const int tile = blockIdx.x % (tiles * tiles);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = (tile % tiles) * 128 + (wave & 1) * 64;
+    const int n0 = (tile / tiles) * 128 + (wave >> 1) * 64;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const SsssmGroupD G = groups[g];
+
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+            acc[mi][ni] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    for (u32 t = G.task_begin; t < G.task_end; t++)
+    {
+        const double *__restrict__ A = tasks[t].a.val;
+        const double *__restrict__ B = tasks[t].b.val;
+        const double *ap = A + (size_t)l4 * nb + m0 + l15;
+        const double *bp = B + (size_t)(n0 + l15) * nb + l4;
+#pragma unroll 2
+        for (int k = 0; k < nb; k += 4)
+        {
+            double a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                a[mi] = ap[(size_t)k * nb + mi * 16];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+                b[ni] = bp[(size_t)ni * 16 * nb + k];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+    double *__restrict__ C = G.c.val;
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+            {
+                const size_t off = (size_t)(n0 + ni * 16 + l15) * nb + (m0 + mi * 16 + l4 + 4 * r);
+                C[off] -= acc[mi][ni][r];
+            }
+}
+#endif
+
+// -----------------------------------------------------------------------------------------------------------------
+// TSTRF / GESSM.  grid = tasks * ceil(nb / 4); wave w owns one row (TSTRF) or column (GESSM) of the block.
+//   TSTRF (...0100000.c:137-175): for each structural entry c of the row, ascending: x_c /= U(c,c), then
+//                                 x_{c'} -= x_c * U(c,c') for the tail of U's row c.
+//   GESSM (...0100000.c:178-209): for each entry r of the column, ascending: x_{r'} -= x_r * L(r',r).
+// The pattern is closed under these updates, so every touched x entry belongs to the vector's own pattern.
+// -----------------------------------------------------------------------------------------------------------------
+#define TRSM_WAVES 4
+
+__global__ __launch_bounds__(TRSM_WAVES * 64) void trsm_sparse_kernel(const TrsmTaskD *__restrict__ tasks, int nb,
+                                                                       unsigned long long *flop_tstrf,
+                                                                       unsigned long long *flop_gessm)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    val_t *smem = reinterpret_cast<val_t *>(smem_raw);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int vblocks = (nb + TRSM_WAVES - 1) / TRSM_WAVES;
+    const int t = blockIdx.x / vblocks;
+    const int v = (blockIdx.x % vblocks) * TRSM_WAVES + wave;
+    if (v >= nb)
+        return;
+    const TrsmTaskD T = tasks[t];
+    const u32 s = ptr0(T.vptr, v), e = T.vptr[v + 1];
+    if (s == e)
+        return;
+    val_t *x = smem + (size_t)wave * nb;
+    for (u32 p = s + lane; p < e; p += 64)
+        x[T.vidx[p]] = T.bval[T.vmap ? T.vmap[p] : p];
+    wave_lds_fence();
+
+    unsigned long long ops = 0;
+    for (u32 pb = s; pb < e; pb += 64)
+    {
+        const u32 cnt = min(64u, e - pb);
+        u32 my_c = 0, my_t0 = 0, my_t1 = 0;
+        if ((u32)lane < cnt)
+        {
+            my_c = T.vidx[pb + lane];
+            my_t0 = T.tptr[my_c];
+            my_t1 = T.tptr[my_c + 1];
+        }
+        for (u32 i = 0; i < cnt; i++)
+        {
+            const u32 c = __shfl(my_c, (int)i, 64);
+            u32 t0 = __shfl(my_t0, (int)i, 64);
+            const u32 t1 = __shfl(my_t1, (int)i, 64);
+            val_t xc = x[c];
+            if (T.is_tstrf)
+            {
+                xc = v_div(xc, clamp_pivot(T.tval[t0]));
+                if (lane == 0)
+                {
+                    x[c] = xc;
+                    ops += 1;
+                }
+                t0++;
+            }
+            for (u32 r = t0 + lane; r < t1; r += 64)
+            {
+                const u32 k = T.tidx[r];
+                x[k] = v_submul(x[k], xc, T.tval[r]);
+                ops += 2;
+            }
+            wave_lds_fence();
+        }
+    }
+    for (u32 p = s + lane; p < e; p += 64)
+        T.bval[T.vmap ? T.vmap[p] : p] = x[T.vidx[p]];
+    ops = wave_sum(ops);
+    if (lane == 0 && ops)
+        atomicAdd(T.is_tstrf ? flop_tstrf : flop_gessm, ops);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// GETRF (...0100000.c:57-135): one workgroup per diagonal block.  The block is expanded into a column-major
+// dense image that is read and written ONLY on the block's pattern (closed under elimination), so it needs no
+// clearing; per pivot k: scale L(:,k), then the rank-1 update over L(:,k) x U(k,:) spread over the workgroup.
+// Every entry receives its updates in ascending k, the same order as the CPU merges.
+// -----------------------------------------------------------------------------------------------------------------
+#define GETRF_THREADS 1024
+
+__global__ __launch_bounds__(GETRF_THREADS) void getrf_kernel(const GetrfTaskD *__restrict__ tasks, int nb,
+                                                              unsigned long long *flop_counter)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    val_t *sL = reinterpret_cast<val_t *>(smem_raw); // nb values of L(:,k)
+    val_t *sU = sL + nb;                             // nb values of U(k,:)
+    u16 *sLi = reinterpret_cast<u16 *>(sU + nb);     // their rows
+    u16 *sUi = sLi + nb;                             // their columns
+    const GetrfTaskD T = tasks[blockIdx.x];
+    val_t *D = T.dense;
+    const int tid = threadIdx.x;
+
+    for (int c = tid; c < nb; c += GETRF_THREADS)
+    {
+        for (u32 p = T.lcp[c]; p < T.lcp[c + 1]; p++)
+            D[(size_t)c * nb + T.lri[p]] = T.lval[p];
+        for (u32 p = T.urp[c]; p < T.urp[c + 1]; p++) // here c is a row of the CSR half
+            D[(size_t)T.uci[p] * nb + c] = T.uval[p];
+    }
+    __syncthreads();
+
+    unsigned long long ops = 0;
+    for (int k = 0; k < nb; k++)
+    {
+        const u32 u0 = T.urp[k], u1 = T.urp[k + 1];
+        if (u0 == u1)
+            continue; // uniform
+        const u32 l0 = T.lcp[k], l1 = T.lcp[k + 1];
+        const int nL = (int)(l1 - l0), nU = (int)(u1 - u0 - 1);
+        if (nL == 0)
+            continue; // nothing below the pivot: neither L nor the trailing block changes
+        const val_t pivot = clamp_pivot(D[(size_t)k * nb + k]);
+        for (int i = tid; i < nL; i += GETRF_THREADS)
+        {
+            const u32 r = T.lri[l0 + i];
+            const val_t v = v_div(D[(size_t)k * nb + r], pivot);
+            D[(size_t)k * nb + r] = v;
+            sL[i] = v;
+            sLi[i] = (u16)r;
+            ops += 1;
+        }
+        for (int jx = tid; jx < nU; jx += GETRF_THREADS)
+        {
+            const u32 c = T.uci[u0 + 1 + jx];
+            sU[jx] = D[(size_t)c * nb + k];
+            sUi[jx] = (u16)c;
+        }
+        __syncthreads();
+        // rank-1 update over L(:,k) x U(k,:): a wavefront takes (a power-of-two group of) columns of U(k,:) and
+        // its lanes the rows of L(:,k); short L columns pack several U columns into one wavefront
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+            int lg = 0;
+            while ((1 << lg) < nL && lg < 6)
+                lg++;
+            const int P = 1 << lg;           // lanes per column (>= min(nL, 64), power of two)
+            const int cpw = 64 >> lg;        // columns per wavefront pass
+            const int isub = lane & (P - 1), jsub = lane >> lg;
+            for (int jx = wave * cpw + jsub; jx < nU; jx += (GETRF_THREADS / 64) * cpw)
+            {
+                const val_t u = sU[jx];
+                const size_t colbase = (size_t)sUi[jx] * nb;
+                for (int i = isub; i < nL; i += P)
+                {
+                    const size_t off = colbase + sLi[i];
+                    D[off] = v_submul(D[off], sL[i], u);
+                    ops += 2;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    for (int c = tid; c < nb; c += GETRF_THREADS)
+    {
+        for (u32 p = T.lcp[c]; p < T.lcp[c + 1]; p++)
+            T.lval[p] = D[(size_t)c * nb + T.lri[p]];
+        for (u32 p = T.urp[c]; p < T.urp[c + 1]; p++)
+            T.uval[p] = D[(size_t)T.uci[p] * nb + c];
+    }
+    ops = wave_sum(ops);
+    if ((tid & 63) == 0 && ops)
+        atomicAdd(flop_counter, ops);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// solve-side kernels (device pointers x, y), semantics of ...0100000.c:435-506
+// -----------------------------------------------------------------------------------------------------------------
+__global__ void spmv_kernel(int nb, const u32 *cp, const u16 *ri, const val_t *val, const val_t *x, val_t *y)
+{
+    // y -= A x; one thread per row would need CSR: instead one wavefront per column with atomics avoided by
+    // running columns sequentially inside a single workgroup (nb is small, this is a latency kernel)
+    for (int c = 0; c < nb; c++)
+    {
+        const val_t xc = x[c];
+        for (u32 p = ptr0(cp, c) + threadIdx.x; p < cp[c + 1]; p += blockDim.x)
+            y[ri[p]] = v_submul(y[ri[p]], val[p], xc);
+        __syncthreads();
+    }
+}
+
+__global__ void vecadd_kernel(long long n, val_t *b, const val_t *x)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+#ifdef PANGULU_COMPLEX
+        b[i].re += x[i].re;
+        b[i].im += x[i].im;
+#else
+        b[i] += x[i];
+#endif
+    }
+}
+
+__global__ void sptrsv_kernel(int nb, const u32 *ptr, const u16 *idx, const val_t *val, val_t *x, int upper)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    val_t *xs = reinterpret_cast<val_t *>(smem_raw);
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
+        xs[i] = x[i];
+    __syncthreads();
+    if (!upper)
+    {
+        for (int c = 0; c < nb; c++)
+        {
+            const val_t xc = xs[c];
+            for (u32 p = ptr[c] + threadIdx.x; p < ptr[c + 1]; p += blockDim.x)
+                xs[idx[p]] = v_submul(xs[idx[p]], val[p], xc);
+            __syncthreads();
+        }
+    }
+    else
+    {
+        // rows from the bottom; the row's dot product is reduced by one wavefront
+        for (int r = nb - 1; r >= 0; r--)
+        {
+            const u32 b = ptr[r], e = ptr[r + 1];
+            if (b == e)
+                continue;
+            if (threadIdx.x < 64)
+            {
+#ifdef PANGULU_COMPLEX
+                val_t part = v_make(0);
+                for (u32 p = b + 1 + threadIdx.x; p < e; p += 64)
+                {
+                    val_t m = v_mul(val[p], xs[idx[p]]);
+                    part.re += m.re;
+                    part.im += m.im;
+                }
+                for (int off = 32; off > 0; off >>= 1)
+                {
+                    part.re += __shfl_down(part.re, off, 64);
+                    part.im += __shfl_down(part.im, off, 64);
+                }
+#else
+                val_t part = 0;
+                for (u32 p = b + 1 + threadIdx.x; p < e; p += 64)
+                    part += val[p] * xs[idx[p]];
+                for (int off = 32; off > 0; off >>= 1)
+                    part += __shfl_down(part, off, 64);
+#endif
+                if (threadIdx.x == 0)
+                {
+                    val_t d = val[b];
+                    real_t dr = v_realpart(d);
+                    val_t num = v_sub(xs[r], part);
+                    xs[r] = ((dr < 0 ? -dr : dr) > (real_t)PANGULU_SPTRSV_TOL) ? v_div(num, d) : v_div(num, v_make((real_t)PANGULU_SPTRSV_TOL));
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
+        x[i] = xs[i];
+}
+
+// =================================================================================================================
+// host side of the back-end
+// =================================================================================================================
+namespace
+{
+
+struct DiagAux // column view of a diagonal block's upper (CSR) half, built on first use
+{
+    u32 *d_cp = nullptr;
+    u16 *d_ri = nullptr;
+    u32 *d_vi = nullptr;
+    u32 nnz = 0;
+    u32 brow = 0;
+};
+
+struct Ring // pinned staging + device mirror, reused segment by segment in stream order
+{
+    static const int NSEG = 8;
+    size_t seg_bytes = 0;
+    char *h = nullptr, *d = nullptr;
+    hipEvent_t ev[NSEG];
+    bool used[NSEG];
+    int cur = 0;
+};
+
+struct EventPair
+{
+    hipEvent_t a, b;
+    int cls;
+};
+
+struct Backend
+{
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nb_cfg = 0;
+    // options
+    long long opt_host_mirror = 1;
+    long long opt_dense_permille = 1000;
+    long long opt_profile = 0;
+    long long opt_assume_independent = 0;
+    // resources
+    Ring ring;
+    unsigned long long *d_flops = nullptr; // [6]
+    val_t *getrf_scratch = nullptr;
+    int getrf_scratch_slots = 0;
+    std::unordered_map<const void *, DiagAux> diag_aux;
+    // stats
+    pangulu_hip_stats_t stats;
+    std::vector<EventPair> pending_events;
+    std::vector<hipEvent_t> event_pool;
+    std::mutex mutex;
+};
+
+Backend B;
+
+void ensure_ready()
+{
+    if (B.ready)
+        return;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+    {
+        fprintf(stderr, "[PanguLU-AMD ERROR] no HIP device available (%s); the GPU_HIP platform has no CPU fallback\n",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        exit(EXIT_FAILURE);
+    }
+    HIP_CHECK(hipSetDevice(B.device));
+    HIP_CHECK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+    B.ring.seg_bytes = (size_t)8 << 20;
+    HIP_CHECK(hipHostMalloc((void **)&B.ring.h, B.ring.seg_bytes * Ring::NSEG, hipHostMallocDefault));
+    HIP_CHECK(hipMalloc((void **)&B.ring.d, B.ring.seg_bytes * Ring::NSEG));
+    for (int i = 0; i < Ring::NSEG; i++)
+    {
+        HIP_CHECK(hipEventCreateWithFlags(&B.ring.ev[i], hipEventDisableTiming));
+        B.ring.used[i] = false;
+    }
+    HIP_CHECK(hipMalloc((void **)&B.d_flops, sizeof(unsigned long long) * 8));
+    HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(unsigned long long) * 8));
+    memset(&B.stats, 0, sizeof(B.stats));
+    B.ready = true;
+}
+
+// a staging segment: host pointer to fill, device pointer the kernels will read after commit()
+struct Segment
+{
+    char *h, *d;
+    size_t cap, used;
+    int index;
+    template <typename T>
+    T *alloc(size_t count, T **dev)
+    {
+        size_t off = (used + 15) & ~(size_t)15;
+        if (off + sizeof(T) * count > cap)
+            return nullptr;
+        used = off + sizeof(T) * count;
+        *dev = reinterpret_cast<T *>(d + off);
+        return reinterpret_cast<T *>(h + off);
+    }
+};
+
+Segment acquire_segment()
+{
+    Ring &r = B.ring;
+    int i = r.cur;
+    r.cur = (r.cur + 1) % Ring::NSEG;
+    if (r.used[i])
+        HIP_CHECK(hipEventSynchronize(r.ev[i])); // the H2D copy that last read this pinned segment is done
+    Segment s;
+    s.h = r.h + (size_t)i * r.seg_bytes;
+    s.d = r.d + (size_t)i * r.seg_bytes;
+    s.cap = r.seg_bytes;
+    s.used = 0;
+    s.index = i;
+    return s;
+}
+
+void commit_segment(Segment &s)
+{
+    if (s.used)
+        HIP_CHECK(hipMemcpyAsync(s.d, s.h, s.used, hipMemcpyHostToDevice, B.stream));
+    HIP_CHECK(hipEventRecord(B.ring.ev[s.index], B.stream));
+    B.ring.used[s.index] = true;
+}
+
+hipEvent_t take_event()
+{
+    if (!B.event_pool.empty())
+    {
+        hipEvent_t e = B.event_pool.back();
+        B.event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+
+struct LaunchTimer
+{
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit LaunchTimer(int c) : cls(c)
+    {
+        if (B.opt_profile)
+        {
+            a = take_event();
+            b = take_event();
+            HIP_CHECK(hipEventRecord(a, B.stream));
+        }
+    }
+    ~LaunchTimer()
+    {
+        if (B.opt_profile)
+        {
+            HIP_CHECK(hipEventRecord(b, B.stream));
+            B.pending_events.push_back(EventPair{a, b, cls});
+        }
+    }
+};
+
+void harvest_events()
+{
+    for (auto &p : B.pending_events)
+    {
+        HIP_CHECK(hipEventSynchronize(p.b));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        B.stats.elapsed_ms[p.cls] += ms;
+        B.event_pool.push_back(p.a);
+        B.event_pool.push_back(p.b);
+    }
+    B.pending_events.clear();
+}
+
+inline u32 host_nnz(const slot_t *s, int nb) { return s->columnpointer[nb]; }
+
+// both halves of a diagonal block are one destination: name it by its lower half
+inline slot_t *canon_dst(slot_t *s)
+{
+    if (s->brow_pos == s->bcol_pos && s->is_upper && s->related_block)
+        return s->related_block;
+    return s;
+}
+
+inline void diag_halves(slot_t *any, slot_t **upper, slot_t **lower)
+{
+    if (any->is_upper)
+    {
+        *upper = any;
+        *lower = any->related_block;
+    }
+    else
+    {
+        *upper = any->related_block;
+        *lower = any;
+    }
+    if (!*upper || !*lower)
+    {
+        fprintf(stderr, "[PanguLU-AMD ERROR] diagonal block (%u,%u) is missing its other half\n", any->brow_pos, any->bcol_pos);
+        exit(EXIT_FAILURE);
+    }
+}
+
+// column view of the upper half of a diagonal block (needed when it is an SSSSM destination: the update runs
+// column by column, the half is stored by rows)
+const DiagAux &get_diag_aux(slot_t *upper, int nb)
+{
+    auto it = B.diag_aux.find((const void *)upper->d_value);
+    u32 nnz = host_nnz(upper, nb);
+    if (it != B.diag_aux.end() && it->second.nnz == nnz && it->second.brow == upper->brow_pos)
+        return it->second;
+    DiagAux aux;
+    aux.nnz = nnz;
+    aux.brow = upper->brow_pos;
+    const u32 *rp = upper->columnpointer; // CSR row pointer (host naming, see pangulu_platform.h)
+    const u16 *ci = upper->rowindex;
+    std::vector<u32> cp(nb + 1, 0), vi(nnz);
+    std::vector<u16> ri(nnz);
+    for (u32 p = 0; p < nnz; p++)
+        cp[ci[p] + 1]++;
+    for (int c = 0; c < nb; c++)
+        cp[c + 1] += cp[c];
+    std::vector<u32> cur(cp.begin(), cp.end() - 1);
+    for (int r = 0; r < nb; r++)
+        for (u32 p = rp[r]; p < rp[r + 1]; p++)
+        {
+            u32 o = cur[ci[p]]++;
+            ri[o] = (u16)r;
+            vi[o] = p;
+        }
+    size_t bytes_cp = sizeof(u32) * (nb + 1), bytes_vi = sizeof(u32) * nnz, bytes_ri = sizeof(u16) * nnz;
+    char *d = nullptr;
+    size_t off_vi = (bytes_cp + 15) & ~(size_t)15, off_ri = (off_vi + bytes_vi + 15) & ~(size_t)15;
+    HIP_CHECK(hipMalloc((void **)&d, off_ri + bytes_ri + 16));
+    HIP_CHECK(hipMemcpy(d, cp.data(), bytes_cp, hipMemcpyHostToDevice));
+    if (nnz)
+    {
+        HIP_CHECK(hipMemcpy(d + off_vi, vi.data(), bytes_vi, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d + off_ri, ri.data(), bytes_ri, hipMemcpyHostToDevice));
+    }
+    aux.d_cp = (u32 *)d;
+    aux.d_vi = (u32 *)(d + off_vi);
+    aux.d_ri = (u16 *)(d + off_ri);
+    if (it != B.diag_aux.end())
+    {
+        HIP_CHECK(hipFree(it->second.d_cp));
+        it->second = aux;
+        return it->second;
+    }
+    return B.diag_aux.emplace((const void *)upper->d_value, aux).first->second;
+}
+
+void mirror_to_host(slot_t *s, int nb)
+{
+    size_t bytes = sizeof(val_t) * (size_t)host_nnz(s, nb);
+    if (bytes)
+        HIP_CHECK(hipMemcpyAsync(s->value, s->d_value, bytes, hipMemcpyDeviceToHost, B.stream));
+}
+
+const double SV = (double)sizeof(val_t);
+
+// ---- SSSSM -----------------------------------------------------------------------------------------------------
+void launch_ssssm(int nb, task_t **list, size_t n)
+{
+    if (n == 0)
+        return;
+    const bool dense_ok =
+#if defined(CALCULATE_TYPE_R64)
+        (nb % 128 == 0);
+#else
+        false;
+#endif
+    const u32 full = (u32)nb * (u32)nb;
+    size_t i = 0;
+    while (i < n)
+    {
+        Segment seg = acquire_segment();
+        // worst case per task: one group + one task descriptor; fill until the segment is full
+        size_t max_tasks = seg.cap / (sizeof(SsssmGroupD) + sizeof(SsssmTaskD) + 32) / 2;
+        size_t take = std::min(n - i, max_tasks);
+        SsssmTaskD *d_tasks_s, *d_tasks_d;
+        SsssmGroupD *d_groups_s, *d_groups_d;
+        SsssmTaskD *tasks_s = seg.alloc<SsssmTaskD>(take, &d_tasks_s);
+        SsssmTaskD *tasks_d = seg.alloc<SsssmTaskD>(take, &d_tasks_d);
+        SsssmGroupD *groups_s = seg.alloc<SsssmGroupD>(take, &d_groups_s);
+        SsssmGroupD *groups_d = seg.alloc<SsssmGroupD>(take, &d_groups_d);
+        if (!tasks_s || !tasks_d || !groups_s || !groups_d)
+        {
+            fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
+            exit(EXIT_FAILURE);
+        }
+        size_t ns = 0, nd = 0, gs = 0, gd = 0;
+        double bytes_s = 0, bytes_d = 0;
+        size_t end = i + take;
+        while (i < end)
+        {
+            slot_t *dst = canon_dst(list[i]->opdst);
+            size_t j = i;
+            while (j < end && canon_dst(list[j]->opdst) == dst)
+                j++;
+            const bool diag = dst->brow_pos == dst->bcol_pos;
+            SsssmGroupD G;
+            memset(&G, 0, sizeof(G));
+            u32 nnz_c;
+            if (diag)
+            {
+                slot_t *up, *lo;
+                diag_halves(dst, &up, &lo);
+                const DiagAux &aux = get_diag_aux(up, nb);
+                G.c = BlkView{lo->d_columnpointer, lo->d_rowindex, lo->d_value};
+                G.ucp = aux.d_cp;
+                G.uri = aux.d_ri;
+                G.uvi = aux.d_vi;
+                G.uval = up->d_value;
+                nnz_c = host_nnz(lo, nb) + host_nnz(up, nb);
+            }
+            else
+            {
+                G.c = BlkView{dst->d_columnpointer, dst->d_rowindex, dst->d_value};
+                nnz_c = host_nnz(dst, nb);
+            }
+            const bool dst_full = !diag && nnz_c == full;
+            size_t s0 = ns, d0 = nd;
+            for (size_t t = i; t < j; t++)
+            {
+                slot_t *a = list[t]->op1, *b = list[t]->op2;
+                SsssmTaskD T;
+                T.a = BlkView{a->d_columnpointer, a->d_rowindex, a->d_value};
+                T.b = BlkView{b->d_columnpointer, b->d_rowindex, b->d_value};
+                u32 na = host_nnz(a, nb), nbz = host_nnz(b, nb);
+                double by = (SV + 2) * ((double)na + nbz) + (2 * SV + 2) * (double)nnz_c + 12.0 * (nb + 1);
+                if (dense_ok && dst_full && na == full && nbz == full)
+                {
+                    tasks_d[nd++] = T;
+                    bytes_d += by;
+                }
+                else
+                {
+                    tasks_s[ns++] = T;
+                    bytes_s += by;
+                }
+            }
+            if (ns > s0)
+            {
+                G.task_begin = (u32)s0;
+                G.task_end = (u32)ns;
+                groups_s[gs++] = G;
+            }
+            if (nd > d0)
+            {
+                G.task_begin = (u32)d0;
+                G.task_end = (u32)nd;
+                groups_d[gd++] = G;
+            }
+            i = j;
+        }
+        commit_segment(seg);
+        if (gs)
+        {
+            LaunchTimer lt(4);
+            int colblocks = (nb + SSSSM_WAVES - 1) / SSSSM_WAVES;
+            size_t lds = sizeof(val_t) * (size_t)nb * SSSSM_WAVES;
+            hipLaunchKernelGGL(ssssm_sparse_kernel, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, B.stream,
+                               d_groups_s, d_tasks_s, nb, B.d_flops + 4);
+            B.stats.launches[4]++;
+            B.stats.tasks[4] += ns;
+            B.stats.alg_bytes[4] += bytes_s;
+        }
+#if defined(CALCULATE_TYPE_R64)
+        if (gd)
+        {
+            LaunchTimer lt(5);
+            int tiles = nb / 128;
+            hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, B.stream, d_groups_d,
+                               d_tasks_d, nb);
+            B.stats.launches[5]++;
+            B.stats.tasks[5] += nd;
+            B.stats.alg_bytes[5] += bytes_d;
+            B.stats.flops[5] += 2.0 * (double)nb * nb * nb * (double)nd;
+        }
+#endif
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+// ---- TSTRF / GESSM -----------------------------------------------------------------------------------------------
+void launch_trsm(int nb, task_t **list, size_t n)
+{
+    size_t i = 0;
+    while (i < n)
+    {
+        Segment seg = acquire_segment();
+        size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + 16));
+        TrsmTaskD *d_tasks;
+        TrsmTaskD *tasks = seg.alloc<TrsmTaskD>(take, &d_tasks);
+        double by_t = 0, by_g = 0;
+        size_t nt = 0, ng = 0;
+        for (size_t k = 0; k < take; k++)
+        {
+            task_t *t = list[i + k];
+            slot_t *dst = t->opdst, *diag = t->op1;
+            slot_t *up, *lo;
+            diag_halves(diag, &up, &lo);
+            TrsmTaskD T;
+            memset(&T, 0, sizeof(T));
+            u32 nnz_b = host_nnz(dst, nb);
+            if (t->kernel_id == PANGULU_TASK_TSTRF)
+            {
+                T.vptr = dst->d_rowpointer;
+                T.vidx = dst->d_columnindex;
+                T.vmap = dst->d_idx_of_csc_value_for_csr;
+                T.bval = dst->d_value;
+                T.tptr = up->d_rowpointer;
+                T.tidx = up->d_columnindex;
+                T.tval = up->d_value;
+                T.is_tstrf = 1;
+                by_t += (2 * SV + 6) * (double)nnz_b + 4.0 * (nb + 1) + (SV + 2) * (double)host_nnz(up, nb) + 4.0 * (nb + 1);
+                nt++;
+            }
+            else
+            {
+                T.vptr = dst->d_columnpointer;
+                T.vidx = dst->d_rowindex;
+                T.vmap = nullptr;
+                T.bval = dst->d_value;
+                T.tptr = lo->d_columnpointer;
+                T.tidx = lo->d_rowindex;
+                T.tval = lo->d_value;
+                T.is_tstrf = 0;
+                by_g += (2 * SV + 2) * (double)nnz_b + 4.0 * (nb + 1) + (SV + 2) * (double)host_nnz(lo, nb) + 4.0 * (nb + 1);
+                ng++;
+            }
+            tasks[k] = T;
+        }
+        commit_segment(seg);
+        {
+            LaunchTimer lt(nt >= ng ? 2 : 3);
+            int vblocks = (nb + TRSM_WAVES - 1) / TRSM_WAVES;
+            size_t lds = sizeof(val_t) * (size_t)nb * TRSM_WAVES;
+            hipLaunchKernelGGL(trsm_sparse_kernel, dim3((unsigned)(take * vblocks)), dim3(TRSM_WAVES * 64), lds, B.stream, d_tasks, nb,
+                               B.d_flops + 2, B.d_flops + 3);
+            HIP_CHECK(hipGetLastError());
+        }
+        // one launch serves both kinds; book it under the kind with more tasks, count tasks/bytes exactly
+        B.stats.launches[nt >= ng ? 2 : 3]++;
+        B.stats.tasks[2] += nt;
+        B.stats.tasks[3] += ng;
+        B.stats.alg_bytes[2] += by_t;
+        B.stats.alg_bytes[3] += by_g;
+        if (B.opt_host_mirror)
+            for (size_t k = 0; k < take; k++)
+                mirror_to_host(list[i + k]->opdst, nb);
+        i += take;
+    }
+}
+
+// ---- GETRF -------------------------------------------------------------------------------------------------------
+void launch_getrf(int nb, task_t **list, size_t n)
+{
+    const int max_slots = 256;
+    if (!B.getrf_scratch || B.nb_cfg != nb)
+    {
+        if (B.getrf_scratch)
+        {
+            HIP_CHECK(hipStreamSynchronize(B.stream));
+            HIP_CHECK(hipFree(B.getrf_scratch));
+        }
+        HIP_CHECK(hipMalloc((void **)&B.getrf_scratch, sizeof(val_t) * (size_t)nb * nb * max_slots));
+        B.getrf_scratch_slots = max_slots;
+        B.nb_cfg = nb;
+    }
+    size_t i = 0;
+    while (i < n)
+    {
+        Segment seg = acquire_segment();
+        size_t take = std::min(n - i, (size_t)B.getrf_scratch_slots);
+        GetrfTaskD *d_tasks;
+        GetrfTaskD *tasks = seg.alloc<GetrfTaskD>(take, &d_tasks);
+        double by = 0;
+        for (size_t k = 0; k < take; k++)
+        {
+            slot_t *up, *lo;
+            diag_halves(list[i + k]->opdst, &up, &lo);
+            GetrfTaskD T;
+            T.lcp = lo->d_columnpointer;
+            T.lri = lo->d_rowindex;
+            T.lval = lo->d_value;
+            T.urp = up->d_rowpointer;
+            T.uci = up->d_columnindex;
+            T.uval = up->d_value;
+            T.dense = B.getrf_scratch + (size_t)k * nb * nb;
+            tasks[k] = T;
+            by += (2 * SV + 2) * ((double)host_nnz(lo, nb) + host_nnz(up, nb)) + 8.0 * (nb + 1);
+        }
+        commit_segment(seg);
+        {
+            LaunchTimer lt(1);
+            size_t lds = (sizeof(val_t) * 2 + sizeof(u16) * 2) * (size_t)nb;
+            hipLaunchKernelGGL(getrf_kernel, dim3((unsigned)take), dim3(GETRF_THREADS), lds, B.stream, d_tasks, nb, B.d_flops + 1);
+            HIP_CHECK(hipGetLastError());
+        }
+        B.stats.launches[1]++;
+        B.stats.tasks[1] += take;
+        B.stats.alg_bytes[1] += by;
+        if (B.opt_host_mirror)
+            for (size_t k = 0; k < take; k++)
+            {
+                slot_t *up, *lo;
+                diag_halves(list[i + k]->opdst, &up, &lo);
+                mirror_to_host(up, nb);
+                mirror_to_host(lo, nb);
+            }
+        i += take;
+    }
+}
+
+void check_lds_budget(int nb)
+{
+    size_t need = sizeof(val_t) * (size_t)nb * SSSSM_WAVES;
+    if (need > 160 * 1024 || nb > 8192)
+    {
+        fprintf(stderr, "[PanguLU-AMD ERROR] nb = %d needs %zu bytes of LDS per workgroup; reduce init_options.nb\n", nb, need);
+        exit(EXIT_FAILURE);
+    }
+}
+
+// one dependency-free run of tasks: one launch per kernel class
+void process_run(int nb, task_t *tasks, size_t n, std::vector<task_t *> &getrf, std::vector<task_t *> &trsm, std::vector<task_t *> &ssssm)
+{
+    getrf.clear();
+    trsm.clear();
+    ssssm.clear();
+    for (size_t i = 0; i < n; i++)
+    {
+        switch (tasks[i].kernel_id)
+        {
+        case PANGULU_TASK_GETRF:
+            getrf.push_back(&tasks[i]);
+            break;
+        case PANGULU_TASK_TSTRF:
+        case PANGULU_TASK_GESSM:
+            trsm.push_back(&tasks[i]);
+            break;
+        case PANGULU_TASK_SSSSM:
+            ssssm.push_back(&tasks[i]);
+            break;
+        default:
+            fprintf(stderr, "[PanguLU-AMD ERROR] unknown kernel id %d\n", (int)tasks[i].kernel_id);
+            exit(EXIT_FAILURE);
+        }
+    }
+    if (!B.opt_assume_independent && ssssm.size() > 1)
+    {
+        // updates of one destination must be adjacent (they share one LDS accumulator pass)
+        std::stable_sort(ssssm.begin(), ssssm.end(), [](const task_t *x, const task_t *y)
+                         {
+                             return canon_dst(x->opdst) < canon_dst(y->opdst); });
+    }
+    launch_ssssm(nb, ssssm.data(), ssssm.size());
+    launch_getrf(nb, getrf.data(), getrf.size());
+    launch_trsm(nb, trsm.data(), trsm.size());
+}
+
+} // namespace
+
+// =================================================================================================================
+// C-ABI
+// =================================================================================================================
+extern "C"
+{
+
+    void pangulu_platform_0201001_malloc(void **platform_address, size_t size)
+    {
+        ensure_ready();
+        HIP_CHECK(hipMalloc(platform_address, size ? size : 16));
+    }
+
+    void pangulu_platform_0201001_malloc_pinned(void **platform_address, size_t size)
+    {
+        ensure_ready();
+        HIP_CHECK(hipHostMalloc(platform_address, size ? size : 16, hipHostMallocDefault));
+    }
+
+    void pangulu_platform_0201001_synchronize(void)
+    {
+        ensure_ready();
+        HIP_CHECK(hipStreamSynchronize(B.stream));
+    }
+
+    void pangulu_platform_0201001_memset(void *s, int c, size_t n)
+    {
+        ensure_ready();
+        HIP_CHECK(hipMemsetAsync(s, c, n, B.stream));
+        HIP_CHECK(hipStreamSynchronize(B.stream));
+    }
+
+    void pangulu_platform_0201001_create_stream(void **stream)
+    {
+        ensure_ready();
+        HIP_CHECK(hipStreamCreateWithFlags((hipStream_t *)stream, hipStreamNonBlocking));
+    }
+
+    static hipMemcpyKind kind_of(unsigned int kind)
+    {
+        switch (kind)
+        {
+        case 0:
+            return hipMemcpyHostToDevice;
+        case 1:
+            return hipMemcpyDeviceToHost;
+        case 2:
+            return hipMemcpyDeviceToDevice;
+        default:
+            fprintf(stderr, "[PanguLU-AMD ERROR] invalid memcpy kind %u\n", kind);
+            exit(EXIT_FAILURE);
+        }
+    }
+
+    void pangulu_platform_0201001_memcpy(void *dst, const void *src, size_t count, unsigned int kind)
+    {
+        ensure_ready();
+        // ordered after everything queued on the back-end stream, complete on return
+        HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), B.stream));
+        HIP_CHECK(hipStreamSynchronize(B.stream));
+    }
+
+    void pangulu_platform_0201001_memcpy_async(void *dst, const void *src, size_t count, unsigned int kind, void *stream)
+    {
+        ensure_ready();
+        // stream == NULL is what the reference host passes from its receive thread
+        // (src/pangulu_communication.c:1850,1880): use the back-end stream so later kernels are ordered behind it
+        hipStream_t s = stream ? (hipStream_t)stream : B.stream;
+        HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), s));
+        if (!stream)
+            HIP_CHECK(hipStreamSynchronize(s)); // the source is pageable host memory the caller may reuse at once
+    }
+
+    void pangulu_platform_0201001_free(void *devptr)
+    {
+        if (!devptr)
+            return;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, devptr) == hipSuccess && attr.type == hipMemoryTypeHost)
+        {
+            HIP_CHECK(hipHostFree(devptr));
+            return;
+        }
+        HIP_CHECK(hipFree(devptr));
+    }
+
+    void pangulu_platform_0201001_get_device_num(int *device_num)
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess)
+            n = 0;
+        *device_num = n;
+    }
+
+    void pangulu_platform_0201001_set_default_device(int device_num)
+    {
+        B.device = device_num;
+        HIP_CHECK(hipSetDevice(device_num));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device_num));
+        pangulu_gpu_shared_mem_size = (int)prop.sharedMemPerBlock;
+        ensure_ready();
+    }
+
+    void pangulu_platform_0201001_get_device_name(char *name, int device_num)
+    {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device_num));
+        strcpy(name, prop.name);
+    }
+
+    void pangulu_platform_0201001_get_device_memory_usage(size_t *used_byte)
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        *used_byte = total_b - free_b;
+    }
+
+    void pangulu_platform_0201001_hybrid_batched(pangulu_inblock_idx nb, pangulu_uint64_t ntask, pangulu_task_t *tasks)
+    {
+        ensure_ready();
+        if (ntask == 0)
+            return;
+        std::lock_guard<std::mutex> g(B.mutex);
+        HIP_CHECK(hipSetDevice(B.device));
+        check_lds_budget(nb);
+        static thread_local std::vector<task_t *> l_getrf, l_trsm, l_ssssm;
+        if (B.opt_assume_independent)
+        {
+            process_run(nb, tasks, (size_t)ntask, l_getrf, l_trsm, l_ssssm);
+            return;
+        }
+        // The reference executes the array serially (...0201000.cu:875-898).  Keep that meaning: cut the array
+        // wherever a task touches a block an earlier task of the current run writes, and batch inside each run.
+        std::unordered_map<const slot_t *, int> written; // block -> kernel class of its writer in this run
+        auto canon = [](const slot_t *s) -> const slot_t *
+        {
+            if (s && s->brow_pos == s->bcol_pos && s->is_upper && s->related_block)
+                return s->related_block;
+            return s;
+        };
+        size_t run_begin = 0;
+        for (size_t i = 0; i < (size_t)ntask; i++)
+        {
+            const task_t &t = tasks[i];
+            const slot_t *d = canon(t.opdst), *a = canon(t.op1), *b = canon(t.op2);
+            bool hazard = false;
+            auto wd = written.find(d);
+            if (wd != written.end() && !(t.kernel_id == PANGULU_TASK_SSSSM && wd->second == PANGULU_TASK_SSSSM))
+                hazard = true;
+            if (a && written.count(a))
+                hazard = true;
+            if (b && written.count(b))
+                hazard = true;
+            if (hazard)
+            {
+                process_run(nb, tasks + run_begin, i - run_begin, l_getrf, l_trsm, l_ssssm);
+                run_begin = i;
+                written.clear();
+            }
+            written[d] = t.kernel_id;
+        }
+        process_run(nb, tasks + run_begin, (size_t)ntask - run_begin, l_getrf, l_trsm, l_ssssm);
+    }
+
+    void pangulu_platform_0201001_ssssm_batched(pangulu_inblock_idx nb, pangulu_uint64_t ntask, pangulu_task_t *tasks)
+    {
+        // as the reference's dispatcher does (src/pangulu_kernel_interface.c:302), kernel ids in the array decide
+        pangulu_platform_0201001_hybrid_batched(nb, ntask, tasks);
+    }
+
+    static void single_task(pangulu_inblock_idx nb, int kernel, slot_t *dst, slot_t *op1, slot_t *op2)
+    {
+        task_t t;
+        memset(&t, 0, sizeof(t));
+        t.kernel_id = (pangulu_int16_t)kernel;
+        t.row = dst->brow_pos;
+        t.col = dst->bcol_pos;
+        t.opdst = dst;
+        t.op1 = op1;
+        t.op2 = op2;
+        pangulu_platform_0201001_hybrid_batched(nb, 1, &t);
+    }
+
+    void pangulu_platform_0201001_getrf(pangulu_inblock_idx nb, pangulu_storage_slot_t *opdst, int tid)
+    {
+        (void)tid;
+        single_task(nb, PANGULU_TASK_GETRF, opdst, nullptr, nullptr);
+    }
+    void pangulu_platform_0201001_tstrf(pangulu_inblock_idx nb, pangulu_storage_slot_t *opdst, pangulu_storage_slot_t *opdiag, int tid)
+    {
+        (void)tid;
+        single_task(nb, PANGULU_TASK_TSTRF, opdst, opdiag, nullptr);
+    }
+    void pangulu_platform_0201001_gessm(pangulu_inblock_idx nb, pangulu_storage_slot_t *opdst, pangulu_storage_slot_t *opdiag, int tid)
+    {
+        (void)tid;
+        single_task(nb, PANGULU_TASK_GESSM, opdst, opdiag, nullptr);
+    }
+    void pangulu_platform_0201001_ssssm(pangulu_inblock_idx nb, pangulu_storage_slot_t *opdst, pangulu_storage_slot_t *op1,
+                                        pangulu_storage_slot_t *op2, int tid)
+    {
+        (void)tid;
+        single_task(nb, PANGULU_TASK_SSSSM, opdst, op1, op2);
+    }
+
+    void pangulu_platform_0201001_spmv(pangulu_inblock_idx nb, pangulu_storage_slot_t *a, calculate_type *x, calculate_type *y)
+    {
+        ensure_ready();
+        hipLaunchKernelGGL(spmv_kernel, dim3(1), dim3(256), 0, B.stream, (int)nb, a->d_columnpointer, a->d_rowindex, a->d_value, x, y);
+        HIP_CHECK(hipGetLastError());
+    }
+
+    void pangulu_platform_0201001_vecadd(pangulu_int64_t length, calculate_type *bval, calculate_type *xval)
+    {
+        ensure_ready();
+        if (length <= 0)
+            return;
+        hipLaunchKernelGGL(vecadd_kernel, dim3((unsigned)((length + 255) / 256)), dim3(256), 0, B.stream, (long long)length, bval, xval);
+        HIP_CHECK(hipGetLastError());
+    }
+
+    void pangulu_platform_0201001_sptrsv(pangulu_inblock_idx nb, pangulu_storage_slot_t *s, calculate_type *xval, pangulu_int64_t uplo)
+    {
+        ensure_ready();
+        size_t lds = sizeof(val_t) * (size_t)nb;
+        if (uplo == PANGULU_LOWER)
+            hipLaunchKernelGGL(sptrsv_kernel, dim3(1), dim3(256), lds, B.stream, (int)nb, s->d_columnpointer, s->d_rowindex, s->d_value, xval, 0);
+        else
+            hipLaunchKernelGGL(sptrsv_kernel, dim3(1), dim3(256), lds, B.stream, (int)nb, s->d_rowpointer, s->d_columnindex, s->d_value, xval, 1);
+        HIP_CHECK(hipGetLastError());
+    }
+
+    void pangulu_platform_0201001_prepare_diag(pangulu_inblock_idx nb, pangulu_storage_slot_t *diag)
+    {
+        ensure_ready();
+        std::lock_guard<std::mutex> g(B.mutex);
+        slot_t *up, *lo;
+        diag_halves(diag, &up, &lo);
+        (void)get_diag_aux(up, nb);
+    }
+
+    int pangulu_platform_0201001_set_option(int option, long long value)
+    {
+        switch (option)
+        {
+        case PANGULU_HIP_OPT_HOST_MIRROR:
+            B.opt_host_mirror = value;
+            return 0;
+        case PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE:
+            B.opt_dense_permille = value;
+            return 0;
+        case PANGULU_HIP_OPT_PROFILE:
+            B.opt_profile = value;
+            return 0;
+        case PANGULU_HIP_OPT_ASSUME_INDEPENDENT:
+            B.opt_assume_independent = value;
+            return 0;
+        default:
+            return 1;
+        }
+    }
+
+    void *pangulu_platform_0201001_get_stream(void)
+    {
+        ensure_ready();
+        return (void *)B.stream;
+    }
+
+    void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset)
+    {
+        ensure_ready();
+        std::lock_guard<std::mutex> g(B.mutex);
+        HIP_CHECK(hipStreamSynchronize(B.stream));
+        harvest_events();
+        unsigned long long f[8];
+        HIP_CHECK(hipMemcpy(f, B.d_flops, sizeof(f), hipMemcpyDeviceToHost));
+        for (int c = 1; c <= 4; c++)
+            B.stats.flops[c] = (double)f[c];
+        if (out)
+            *out = B.stats;
+        if (reset)
+        {
+            memset(&B.stats, 0, sizeof(B.stats));
+            HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(f)));
+        }
+    }
+}

@@ -1,0 +1,184 @@
+"""Python mirror of the solver API: same call sequence and argument meaning as include/pangulu.h.
+
+    h = pangulu_init(n, nnz, colptr, rowidx, value, nb=256)     # reorder + symbolic + block records + upload
+    pangulu_gstrf(h)                                            # numeric LU on the GPU (the hot path)
+    x = pangulu_gstrs(h, b)                                     # triangular solves
+    pangulu_finalize(h)
+
+(reference: src/pangulu.c:11-345, driver examples/example.c:282-300).  This is a binding, not an
+implementation: every call goes through the C-ABI of libpangulu_amd_<type>.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class Handle:
+    """Opaque solver handle (the reference's ``void *pangulu_handle``) plus the arrays that must outlive it."""
+
+    def __init__(self, lib, vtype):
+        self.lib = lib
+        self.vtype = vtype
+        self.dtype = _lib.VALUE_TYPES[vtype][0]
+        self.ptr = ctypes.c_void_p(None)
+        self.n = 0
+        self._keep = []
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.ptr)
+
+    def info(self):
+        out = _lib.Info()
+        self.lib.pangulu_amd_get_info(self.ref, ctypes.byref(out))
+        return out.as_dict()
+
+
+def _as(arr, dtype):
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    return a
+
+
+def pangulu_init(n, nnz, csc_colptr, csc_rowidx, csc_value, nb=256, nthread=1, vtype="r64",
+                 ordering=None, coords=None, user_perm=None, recv_buffer_level=0.5, eager_host_mirror=False):
+    """CSC input with 64-bit column pointers and 32-bit row indices, as the reference (src/pangulu_common.h:67-70).
+
+    ordering: None/"nd" (built-in nested dissection, geometric when ``coords`` is given), "identity" (what the
+    reference does when built without METIS/MC64) or "user" with ``user_perm`` (perm[new] = old).
+    On ranks other than 0 the matrix arguments may be None (rank 0 broadcasts them, as examples/example.c does).
+    """
+    lib = _lib.load(vtype)
+    h = Handle(lib, vtype)
+    dtype, sizeof_value, is_complex = _lib.VALUE_TYPES[vtype]
+    if ordering in (None, "nd"):
+        lib.pangulu_amd_set_ordering(_lib.ORDER_ND)
+    elif ordering == "identity":
+        lib.pangulu_amd_set_ordering(_lib.ORDER_IDENTITY)
+    elif ordering == "user":
+        p = _as(user_perm, np.uint32)
+        lib.pangulu_amd_set_user_perm(p.ctypes.data_as(ctypes.c_void_p), len(p))
+    else:
+        raise ValueError("unknown ordering %r" % (ordering,))
+    if coords is not None:
+        c = _as(coords, np.float64)
+        lib.pangulu_amd_set_coordinates(c.ctypes.data_as(ctypes.c_void_p), c.shape[0], c.shape[1])
+    lib.pangulu_amd_set_eager_host_mirror(1 if eager_host_mirror else 0)
+    opt = _lib.InitOptions()
+    opt.nthread = nthread
+    opt.nb = nb
+    opt.gpu_kernel_warp_per_block = 4
+    opt.gpu_data_move_warp_per_block = 4
+    opt.sizeof_value = sizeof_value
+    opt.is_complex_matrix = is_complex
+    opt.mpi_recv_buffer_level = recv_buffer_level
+    if csc_colptr is not None:
+        cp = _as(csc_colptr, np.uint64)
+        ri = _as(csc_rowidx, np.uint32)
+        va = _as(csc_value, dtype)
+        h._keep = [cp, ri, va]
+        args = (cp.ctypes.data_as(ctypes.c_void_p), ri.ctypes.data_as(ctypes.c_void_p), va.ctypes.data_as(ctypes.c_void_p))
+    else:
+        args = (None, None, None)
+    lib.pangulu_init(n, nnz, args[0], args[1], args[2], ctypes.byref(opt), h.ref)
+    h.n = int(h.info()["n"])
+    return h
+
+
+def pangulu_gstrf(h):
+    opt = _lib.GstrfOptions()
+    h.lib.pangulu_gstrf(ctypes.byref(opt), h.ref)
+
+
+def pangulu_gstrs(h, rhs):
+    """Solves A x = rhs with the factors; returns x (rank 0; other ranks get their input back)."""
+    opt = _lib.GstrsOptions()
+    x = np.array(rhs, dtype=h.dtype, copy=True) if rhs is not None else np.zeros(h.n, dtype=h.dtype)
+    h.lib.pangulu_gstrs(x.ctypes.data_as(ctypes.c_void_p), ctypes.byref(opt), h.ref)
+    return x
+
+
+def pangulu_gssv(h, rhs):
+    pangulu_gstrf(h)
+    return pangulu_gstrs(h, rhs)
+
+
+def pangulu_finalize(h):
+    if h.ptr:
+        h.lib.pangulu_finalize(h.ref)
+    h.ptr = ctypes.c_void_p(None)
+
+
+# ---- introspection used by tests and bench.py ------------------------------------------------------------------
+
+def owned_blocks(h):
+    """Yields (brow, bcol, is_upper, colptr, rowidx, values) for every block record this rank owns.
+
+    For is_upper == 1 diagonal halves colptr/rowidx are the CSR row pointer / column index."""
+    nb = int(h.info()["nb"])
+    cnt = h.lib.pangulu_amd_owned_block_count(h.ref)
+    for i in range(cnt):
+        brow, bcol = ctypes.c_uint32(), ctypes.c_uint32()
+        up, nnz = ctypes.c_int(), ctypes.c_ulonglong()
+        cp, ri, va = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        rc = h.lib.pangulu_amd_owned_block(h.ref, i, ctypes.byref(brow), ctypes.byref(bcol), ctypes.byref(up), ctypes.byref(nnz),
+                                           ctypes.byref(cp), ctypes.byref(ri), ctypes.byref(va))
+        assert rc == 0
+        k = int(nnz.value)
+        colptr = np.ctypeslib.as_array(ctypes.cast(cp, ctypes.POINTER(ctypes.c_uint32)), shape=(nb + 1,)).copy()
+        if k:
+            rowidx = np.ctypeslib.as_array(ctypes.cast(ri, ctypes.POINTER(ctypes.c_uint16)), shape=(k,)).copy()
+            raw = np.ctypeslib.as_array(ctypes.cast(va, ctypes.POINTER(ctypes.c_uint8)), shape=(k * np.dtype(h.dtype).itemsize,))
+            values = raw.view(h.dtype).copy()
+        else:
+            rowidx = np.zeros(0, np.uint16)
+            values = np.zeros(0, h.dtype)
+        yield int(brow.value), int(bcol.value), int(up.value), colptr, rowidx, values
+
+
+def permutation(h):
+    p = h.lib.pangulu_amd_get_perm(h.ref)
+    return np.ctypeslib.as_array(p, shape=(h.n,)).copy()
+
+
+def factors_as_scipy(h):
+    """Assemble L (unit lower) and U from this rank's blocks as scipy CSC matrices in the PERMUTED ordering."""
+    import scipy.sparse as sp
+
+    info = h.info()
+    nb, n = int(info["nb"]), int(info["n"])
+    npad = int(info["block_length"]) * nb
+    rows_l, cols_l, vals_l, rows_u, cols_u, vals_u = [], [], [], [], [], []
+    for brow, bcol, up, cp, ri, va in owned_blocks(h):
+        major = np.repeat(np.arange(nb, dtype=np.int64), np.diff(cp.astype(np.int64)))
+        minor = ri.astype(np.int64)
+        if brow == bcol and up:
+            r, c = major + brow * nb, minor + bcol * nb  # CSR
+            rows_u.append(r), cols_u.append(c), vals_u.append(va)
+        elif brow < bcol:
+            r, c = minor + brow * nb, major + bcol * nb
+            rows_u.append(r), cols_u.append(c), vals_u.append(va)
+        else:
+            r, c = minor + brow * nb, major + bcol * nb
+            rows_l.append(r), cols_l.append(c), vals_l.append(va)
+
+    def build(rows, cols, vals):
+        if not rows:
+            return sp.csc_matrix((npad, npad), dtype=h.dtype)
+        return sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(npad, npad))
+
+    L = build(rows_l, cols_l, vals_l)[:n, :n] + sp.identity(n, dtype=h.dtype, format="csc")
+    U = build(rows_u, cols_u, vals_u)[:n, :n]
+    return L.tocsc(), U.tocsc()
+
+
+def hip_stats(h_or_lib, reset=False):
+    lib = h_or_lib.lib if isinstance(h_or_lib, Handle) else h_or_lib
+    st = _lib.HipStats()
+    lib.pangulu_platform_0201001_get_stats(ctypes.byref(st), 1 if reset else 0)
+    out = {}
+    for k, name in _lib.KERNEL_CLASSES.items():
+        out[name] = dict(launches=int(st.launches[k]), tasks=int(st.tasks[k]), alg_bytes=float(st.alg_bytes[k]),
+                         flops=float(st.flops[k]), elapsed_ms=float(st.elapsed_ms[k]))
+    return out
