@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- numeric factorisation GFLOP/s (pangulu_gstrf, R64) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete pangulu_gstrf of the workload matrix.  Between steps the block records are restored from a
+device-side snapshot (pangulu_amd_reset_numeric, un-timed), so every timed step starts with its inputs resident in
+HBM; each step is bracketed by a barrier + device synchronise on both sides and the slowest rank's time counts.
+value = F / t with F = sum_k (c_k + 2 c_k^2) the reference's structural flop count (src/pangulu_kernel_interface.c:4-176,
+computed once from the symbolic pattern outside the timed region).
+
+Workload (BASELINE.json configs[1]): "SuiteSparse ldoor (n=952K, nnz=42M) R64, nb=256".  ldoor is not in the image and
+there is no network, so unless --mtx points at a MatrixMarket file the run uses the deterministic stand-in
+pangulu_amd.matrices.shell(398, 398): a two-layer structural shell with 3 unknowns per node, n = 950 424,
+~50 M entries, diagonally dominant -- the same class (thin-walled structure, ~45-55 entries per row) and size.
+Ordering: built-in geometric nested dissection (stated in the JSON line; F depends on it).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (v_mfma_f64_16x16x4: 64 cycles per 2048 flop per SIMD)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="shell", choices=["shell", "fem27", "poisson", "kkt"])
+    ap.add_argument("--size", type=int, nargs="*", default=None, help="generator size arguments (shell: nx ny)")
+    ap.add_argument("--mtx", default=None, help="MatrixMarket file to factorise instead of the synthetic stand-in")
+    ap.add_argument("--nb", type=int, default=256)
+    ap.add_argument("--ordering", default="nd", choices=["nd", "identity"])
+    ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, nargs=2, default=[110, 110], help="shell nx ny of the CPU-baseline sample")
+    ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "host"), choices=["host", "rccl"])
+    return ap.parse_args()
+
+
+def make_matrix(args, M):
+    if args.mtx:
+        n, cp, ri, va, co = M.read_mtx(args.mtx)
+        return (n, cp, ri, va, co), "mtx:%s" % os.path.basename(args.mtx)
+    size = args.size
+    if args.workload == "shell":
+        nx, ny = (size + [None, None])[:2] if size else (398, 398)
+        ny = ny or nx
+        return M.shell(nx, ny), "ldoor-class stand-in: shell(%d,%d) 2 layers x 3 dofs" % (nx, ny)
+    if args.workload == "fem27":
+        s = size or [64]
+        return M.fem27(*s), "Serena-class stand-in: fem27(%s)" % ",".join(map(str, s))
+    if args.workload == "poisson":
+        s = size or [64]
+        return M.poisson3d(*s), "poisson3d(%s)" % ",".join(map(str, s))
+    s = size or [40]
+    return M.kkt(s[0]), "nlpkkt-class stand-in: kkt(%d)" % s[0]
+
+
+def grid(world):
+    """p x q process grid, p the largest divisor of the rank count not above its square root (src/pangulu.c:83-90)."""
+    p = int(np.sqrt(world))
+    while world % p:
+        p -= 1
+    return p, world // p
+
+
+def find_openblas():
+    """The CPU baseline's SSSSM uses OpenBLAS dgemm like the reference (…0100000.c:317-327) when scipy's bundled
+    library is present; otherwise the oracle's own triple loop."""
+    try:
+        import scipy
+
+        d = os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs")
+        for f in sorted(os.listdir(d)):
+            if "openblas" in f and f.endswith(".so") and "64_" not in f:
+                return os.path.join(d, f)
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(args, pa, M, lib):
+    """Oracle (CPU restatement of the reference's CPU platform) timed on one host core on a bounded sample of the
+    same workload class.  Reported beside the GPU number; not a target."""
+    from tests.helpers import oracle_library, select_platform
+
+    blas = find_openblas()
+    if blas:
+        os.environ["PANGULU_ORACLE_BLAS"] = blas
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    nx, ny = args.cpu_sample
+    n, cp, ri, va, co = M.shell(nx, ny)
+    select_platform(lib, oracle_library("r64"))
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=args.nb, ordering=args.ordering, coords=co, nthread=max(1, os.cpu_count() or 1))
+    t0 = time.time()
+    pa.pangulu_gstrf(h)
+    dt = time.time() - t0
+    info = h.info()
+    pa.pangulu_finalize(h)
+    select_platform(lib, "hip")
+    return {
+        "value": info["flop"] / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+        "sample": "shell(%d,%d) n=%d F=%.3e nb=%d, 1 rank x 1 compute thread, SSSSM GEMM: %s, %.1f s" % (
+            nx, ny, n, info["flop"], args.nb, "OpenBLAS (scipy bundle)" if blas else "oracle triple loop", dt),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus and "RANK" in os.environ:
+        args.gpus = world
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one process per GPU)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["LOCAL_RANK"] = str(local_rank)
+
+    import torch  # device selection + the synchronise the contract asks for; not on the compute path
+
+    import pangulu_amd as pa
+    from pangulu_amd import _lib
+    from pangulu_amd import matrices as M
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the numeric factorisation has no CPU fallback")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    lib = _lib.load("r64")
+    nthreads = args.host_threads or max(1, (os.cpu_count() or 1) // max(1, world))
+    os.environ["PANGULU_AMD_HOST_THREADS"] = str(nthreads)
+
+    if world > 1:
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        base_port = int(os.environ.get("MASTER_PORT", "29500")) + 23
+        transport = _lib.TRANSPORT_RCCL if args.transport == "rccl" else _lib.TRANSPORT_HOST
+        rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port, transport, None)
+        assert rc == 0
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, pa, M, lib)
+
+    if rank == 0:
+        mat, workload = make_matrix(args, M)
+        n, cp, ri, va, coords = mat
+    else:
+        n, cp, ri, va, coords, workload = 0, None, None, None, None, ""
+    t0 = time.time()
+    h = pa.pangulu_init(n, len(va) if va is not None else 0, cp, ri, va, nb=args.nb, ordering=args.ordering,
+                        coords=coords if args.ordering == "nd" else None, nthread=nthreads)
+    t_init = time.time() - t0
+    assert lib.pangulu_amd_snapshot(h.ref) == 0
+    info0 = h.info()
+    flop = float(info0["flop"])
+
+    def one_step():
+        lib.pangulu_amd_comm_barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        pa.pangulu_gstrf(h)            # ends with a stream synchronise + barrier inside the library
+        torch.cuda.synchronize()
+        lib.pangulu_amd_comm_barrier()
+        return time.perf_counter() - t
+
+    for _ in range(args.warmup):
+        one_step()
+        lib.pangulu_amd_reset_numeric(h.ref)
+    pa.hip_stats(lib, reset=True)
+    times = []
+    for s in range(args.steps):
+        times.append(one_step())
+        if s + 1 < args.steps or not args.no_profile_pass:
+            lib.pangulu_amd_reset_numeric(h.ref)
+    # max over ranks of the summed step time
+    tsum = np.array([sum(times)], dtype=np.float64)
+    if world > 1:
+        lib.pangulu_amd_comm_allreduce_max_f64(tsum.ctypes.data_as(ctypes.c_void_p), 1)
+    ms_per_step = float(tsum[0]) / max(1, args.steps) * 1e3
+    info = h.info()
+    stats_timed = pa.hip_stats(lib, reset=True)
+
+    # one extra, un-timed factorisation with per-launch hipEvents to attribute time to kernels
+    roofline = None
+    kernels = {}
+    if not args.no_profile_pass:
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_PROFILE, 1)
+        one_step()
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_PROFILE, 0)
+        st = pa.hip_stats(lib, reset=True)
+        for name, v in st.items():
+            if v["launches"]:
+                kernels[name] = {
+                    "launches": v["launches"], "tasks": v["tasks"], "ms": round(v["elapsed_ms"], 3),
+                    "avg_launch_us": round(1e3 * v["elapsed_ms"] / v["launches"], 2),
+                    "alg_GB": round(v["alg_bytes"] / 1e9, 4), "GFLOP": round(v["flops"] / 1e9, 4),
+                }
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["ms"])
+            v = st[dom]
+            sec = v["elapsed_ms"] / 1e3
+            if dom == "ssssm_dense_mfma":
+                ach = v["flops"] / sec / 1e12
+                roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / FP64_PEAK_TFLOPS, "traffic": None}
+            else:
+                ach = v["alg_bytes"] / sec / 1e9
+                roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roofline["avg_launch_us"] = kernels[dom]["avg_launch_us"]
+            roofline["share_of_kernel_time"] = kernels[dom]["ms"] / sum(k["ms"] for k in kernels.values())
+
+    # end-to-end check of the last factorisation: ||Ax-b||/||b|| with b = A*1 (examples/example.c:252-264,304-364)
+    residual = None
+    if rank == 0:
+        b = M.rhs_of_ones(n, cp, ri, va)
+    else:
+        b = None
+    x = pa.pangulu_gstrs(h, b)
+    if rank == 0:
+        residual = M.relative_residual(n, cp, ri, va, x, b)
+    pa.pangulu_finalize(h)
+    if world > 1:
+        lib.pangulu_amd_comm_finalize()
+
+    if rank == 0:
+        value = flop / (ms_per_step / 1e3) / 1e9
+        line = {
+            "metric": "numeric factorisation GFLOP/s (pangulu_gstrf, R64)",
+            "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic" if not args.mtx else "file",
+            "config": {
+                "workload": workload, "n": int(info["n"]), "nnz": int(info["nnz"]), "nb": int(info["nb"]),
+                "ordering": "built-in nested dissection (geometric)" if args.ordering == "nd" else "identity",
+                "symbolic_nnz": int(info["symbolic_nnz"]), "flop": int(info["flop"]),
+                "parallelism": "2D block-cyclic %dx%d" % grid(world),
+                "transport": args.transport if world > 1 else "none",
+                "blocks": int(info["nblocks_nondiag"]),
+                "tasks": {"getrf": int(info["ntask_getrf"]), "tstrf": int(info["ntask_tstrf"]), "gessm": int(info["ntask_gessm"]),
+                          "ssssm": int(info["ntask_ssssm"])},
+            },
+            "residual": residual,
+            "init_s": round(t_init, 2),
+            "host_sched_s_last_step": round(info["time_numeric_host_sched"], 4),
+            "batches_per_step": int(info["batches"]),
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,7 @@ extern "C"
                               const void *nccl_unique_id);
     int pangulu_amd_rccl_unique_id(void *out128);
     void pangulu_amd_comm_barrier(void);
+    void pangulu_amd_comm_allreduce_max_f64(double *values, int count);
     void pangulu_amd_comm_finalize(void);
     int pangulu_amd_comm_rank(void);
     int pangulu_amd_comm_size(void);
@@ -36,6 +37,8 @@ extern "C"
      * pangulu_platform_<7-digit id>_<name> (the tests pass oracle/_build/libpangulu_oracle_*.so with id
      * 0x0100000 to run the scheduler on the CPU restatement).  Returns 0 on success. */
     int pangulu_amd_use_platform_library(const char *so_path, unsigned int platform_id);
+    /* back to the built-in HIP platform (tests compare both in one process) */
+    void pangulu_amd_use_builtin_platform(void);
     unsigned int pangulu_amd_active_platform(void);
 
     /* ---- analysis options (set before pangulu_init) -------------------------------------------------- */
@@ -75,6 +78,14 @@ extern "C"
     void pangulu_amd_get_info(void **pangulu_handle, pangulu_amd_info_t *out);
     /* evaluate T* = sum_t max(bytes_t / BW, flop_t / P) over this rank's task list (structure only) */
     void pangulu_amd_model_roofline(void **pangulu_handle, double hbm_gbytes_per_s, double fp_tflops);
+
+    /* ---- repeated factorisations (bench.py) ---------------------------------------------------------- */
+    /* gstrf overwrites the matrix with its factors.  snapshot() keeps a pristine device-side copy of this rank's
+     * block records (call it after pangulu_init, before the first gstrf); reset_numeric() restores the records
+     * from it with one device-to-device copy and re-arms the dependency counters, so the next pangulu_gstrf
+     * factorises the same matrix again with its inputs already resident in HBM.  Both return 0 on success. */
+    int pangulu_amd_snapshot(void **pangulu_handle);
+    int pangulu_amd_reset_numeric(void **pangulu_handle);
 
     /* ---- factor access (tests) ------------------------------------------------------------------------ */
     /* Block records this rank owns, in storage order.  Pointers are host pointers into the record and stay

@@ -392,9 +392,68 @@ static void ssssm_scratch_reserve(int nb)
     S.tpanel = (val_t *)malloc(sizeof(val_t) * (size_t)nb * nb);
 }
 
+#if defined(PG_ORACLE_FMA) && !defined(PANGULU_COMPLEX)
+/* FMA build only: the same update in the operation order of the GPU's sparse kernel -- every destination entry
+ * takes its terms one by one, in ascending k, each as one fused multiply-add -- so that a whole factorisation on
+ * the sparse path can be compared bit for bit.  (The plain build below keeps the reference's gather/GEMM/scatter
+ * order; tests/test_oracle_* checks that the two agree to rounding.) */
+static void ssssm_in_place_fused(pangulu_inblock_idx nb, slot_t *opdst, slot_t *op1, slot_t *op2)
+{
+    ssssm_scratch_reserve(nb);
+    val_t *acc = S.tpanel; /* dense destination column */
+    slot_t *U = NULL, *L = opdst;
+    if (opdst->brow_pos == opdst->bcol_pos)
+    {
+        split_diag(opdst, &U, &L);
+    }
+    /* by-column positions of the upper (CSR) half of a diagonal destination */
+    pangulu_int32_t *ucnt = S.kmap;
+    for (int j = 0; j < nb; j++)
+    {
+        pangulu_int32_t b0 = ptr_at(op2->columnpointer, j), b1 = op2->columnpointer[j + 1];
+        if (b0 == b1)
+            continue;
+        for (pangulu_int32_t p = ptr_at(L->columnpointer, j); p < (pangulu_int32_t)L->columnpointer[j + 1]; p++)
+            acc[L->rowindex[p]] = L->value[p];
+        if (U)
+        {
+            for (int r = 0; r <= j; r++)
+            {
+                ucnt[r] = -1;
+                for (pangulu_int32_t p = U->columnpointer[r]; p < (pangulu_int32_t)U->columnpointer[r + 1]; p++)
+                    if (U->rowindex[p] == j)
+                    {
+                        ucnt[r] = p;
+                        acc[r] = U->value[p];
+                    }
+            }
+        }
+        for (pangulu_int32_t q = b0; q < b1; q++)
+        {
+            int k = op2->rowindex[q];
+            val_t b = op2->value[q];
+            for (pangulu_int32_t p = ptr_at(op1->columnpointer, k); p < (pangulu_int32_t)op1->columnpointer[k + 1]; p++)
+                SUBMUL(acc[op1->rowindex[p]], op1->value[p], b);
+        }
+        for (pangulu_int32_t p = ptr_at(L->columnpointer, j); p < (pangulu_int32_t)L->columnpointer[j + 1]; p++)
+            L->value[p] = acc[L->rowindex[p]];
+        if (U)
+        {
+            for (int r = 0; r <= j; r++)
+                if (ucnt[r] >= 0)
+                    U->value[ucnt[r]] = acc[r];
+        }
+    }
+}
+#endif
+
 void pangulu_platform_0100000_ssssm(pangulu_inblock_idx nb, slot_t *opdst, slot_t *op1, slot_t *op2, int tid)
 {
     (void)tid;
+#if defined(PG_ORACLE_FMA) && !defined(PANGULU_COMPLEX)
+    ssssm_in_place_fused(nb, opdst, op1, op2);
+    return;
+#endif
     ssssm_scratch_reserve(nb);
     int m = 0, n = 0, k = 0;
     for (int i = 0; i < nb; i++)

@@ -128,12 +128,15 @@ def load(vtype="r64"):
     lib.pangulu_amd_comm_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, vp]
     lib.pangulu_amd_comm_init.restype = ctypes.c_int
     lib.pangulu_amd_comm_barrier.restype = None
+    lib.pangulu_amd_comm_allreduce_max_f64.argtypes = [vp, ctypes.c_int]
+    lib.pangulu_amd_comm_allreduce_max_f64.restype = None
     lib.pangulu_amd_comm_finalize.restype = None
     lib.pangulu_amd_comm_rank.restype = ctypes.c_int
     lib.pangulu_amd_comm_size.restype = ctypes.c_int
     lib.pangulu_amd_use_platform_library.argtypes = [ctypes.c_char_p, ctypes.c_uint]
     lib.pangulu_amd_use_platform_library.restype = ctypes.c_int
     lib.pangulu_amd_active_platform.restype = ctypes.c_uint
+    lib.pangulu_amd_use_builtin_platform.restype = None
     lib.pangulu_amd_set_ordering.argtypes = [ctypes.c_int]
     lib.pangulu_amd_set_ordering.restype = None
     lib.pangulu_amd_set_user_perm.argtypes = [vp, ctypes.c_uint32]
@@ -153,6 +156,10 @@ def load(vtype="r64"):
         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong), vpp, vpp, vpp,
     ]
     lib.pangulu_amd_owned_block.restype = ctypes.c_int
+    lib.pangulu_amd_snapshot.argtypes = [vpp]
+    lib.pangulu_amd_snapshot.restype = ctypes.c_int
+    lib.pangulu_amd_reset_numeric.argtypes = [vpp]
+    lib.pangulu_amd_reset_numeric.restype = ctypes.c_int
     lib.pangulu_amd_get_perm.argtypes = [vpp]
     lib.pangulu_amd_get_perm.restype = ctypes.POINTER(ctypes.c_uint32)
     lib.pangulu_amd_apply_lu.argtypes = [vpp, vp, vp]

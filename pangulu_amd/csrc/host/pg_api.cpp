@@ -39,7 +39,7 @@ static Platform g_platform;
 static bool g_platform_ready = false;
 static bool g_platform_builtin = true;
 
-static void bind_builtin_hip(Platform &p)
+void bind_builtin_hip(Platform &p)
 {
     p = Platform();
     p.id = PANGULU_PLATFORM_GPU_HIP;
@@ -152,6 +152,13 @@ extern "C"
         return 0;
     }
 
+    void pangulu_amd_use_builtin_platform(void)
+    {
+        bind_builtin_hip(g_platform);
+        g_platform_ready = true;
+        g_platform_builtin = true;
+    }
+
     unsigned int pangulu_amd_active_platform(void) { return active_platform().id; }
 
     int pangulu_amd_comm_init(int rank, int size, const char *addr, int base_port, int transport, const void *nccl_unique_id)
@@ -166,7 +173,9 @@ extern "C"
         return 0;
     }
     void pangulu_amd_comm_barrier(void) { world()->barrier(); }
+    void pangulu_amd_comm_allreduce_max_f64(double *values, int count) { world()->allreduce_max_f64(values, count); }
     void pangulu_amd_comm_finalize(void) { set_world(nullptr); }
+    int pangulu_amd_rccl_unique_id(void *out128) { return rccl_make_unique_id(out128); }
     int pangulu_amd_comm_rank(void) { return world()->rank; }
     int pangulu_amd_comm_size(void) { return world()->size; }
 
@@ -475,6 +484,48 @@ extern "C"
             y[i] = (calculate_type)r[i];
         return 0;
 #endif
+    }
+
+    int pangulu_amd_snapshot(void **pangulu_handle)
+    {
+        Solver *S = (Solver *)*pangulu_handle;
+        Platform &plat = active_platform();
+        if (S->factored)
+            return 1;
+        if (!S->arena_snapshot)
+        {
+            if (plat.host_memory)
+                S->arena_snapshot = (char *)malloc(S->storage.arena_bytes);
+            else
+                plat.malloc_((void **)&S->arena_snapshot, S->storage.arena_bytes);
+        }
+        plat.memcpy_(S->arena_snapshot, S->storage.darena, S->storage.arena_bytes, 2);
+        plat.synchronize();
+        return 0;
+    }
+
+    int pangulu_amd_reset_numeric(void **pangulu_handle)
+    {
+        Solver *S = (Solver *)*pangulu_handle;
+        Platform &plat = active_platform();
+        if (!S->arena_snapshot)
+            return 1;
+        plat.synchronize();
+        plat.memcpy_(S->storage.darena, S->arena_snapshot, S->storage.arena_bytes, 2);
+        plat.synchronize();
+        S->remain = S->remain0;
+        S->remain_diag = S->remain_diag0;
+        S->rank_remain_task = S->rank_remain_task0;
+        S->rank_remain_recv = S->rank_remain_recv0;
+        for (auto &s : S->storage.owned)
+            s.data_status = PANGULU_DATA_PREPARING;
+        for (auto &q : S->pending)
+            q.clear();
+        S->pending_dirty.clear();
+        S->pending_total = 0;
+        S->factored = false;
+        S->host_values_current = plat.host_memory;
+        return 0;
     }
 
     void pangulu_amd_model_roofline(void **pangulu_handle, double hbm_gbytes_per_s, double fp_tflops)

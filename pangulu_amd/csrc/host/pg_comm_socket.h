@@ -1,0 +1,403 @@
+// pg_comm_socket.h -- TCP control plane + host-staged block transport (see pg_comm.cpp for the design notes).
+#pragma once
+
+#include <arpa/inet.h>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <poll.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include "pg_host.h"
+
+namespace pg
+{
+
+enum : u32
+{
+    FRAME_BYTES = 1,
+    FRAME_BLOCK = 2
+};
+struct Frame
+{
+    u32 type;
+    u32 tag;
+    u64 bytes;
+};
+enum : int
+{
+    TAG_BARRIER = 0x7ffffff0,
+    TAG_BCAST = 0x7ffffff1,
+    TAG_REDUCE = 0x7ffffff2
+};
+
+inline void write_all(int fd, const void *buf, size_t n)
+{
+    const char *p = (const char *)buf;
+    while (n)
+    {
+        ssize_t w = ::send(fd, p, n, MSG_NOSIGNAL);
+        if (w < 0)
+        {
+            if (errno == EINTR)
+                continue;
+            fatal("socket send failed: %s", strerror(errno));
+        }
+        p += w;
+        n -= (size_t)w;
+    }
+}
+
+inline void read_all(int fd, void *buf, size_t n)
+{
+    char *p = (char *)buf;
+    while (n)
+    {
+        ssize_t r = ::recv(fd, p, n, 0);
+        if (r < 0)
+        {
+            if (errno == EINTR)
+                continue;
+            fatal("socket recv failed: %s", strerror(errno));
+        }
+        if (r == 0)
+            fatal("peer closed the connection");
+        p += r;
+        n -= (size_t)r;
+    }
+}
+
+struct SocketComm : Comm
+{
+    std::vector<int> fd;                  // per peer
+    std::vector<std::mutex> wmutex;       // per peer write lock
+    std::map<std::pair<int, int>, std::deque<std::vector<char>>> mailbox; // (src, tag) -> messages
+    // sender thread
+    struct SendReq
+    {
+        int dst;
+        Frame f;
+        BlockHeader h;
+        const char *payload;
+        size_t payload_bytes;
+    };
+    std::deque<SendReq> sendq;
+    std::mutex qmutex;
+    std::condition_variable qcv, qdrained;
+    bool stop = false;
+    size_t inflight = 0;
+    std::thread sender;
+
+    SocketComm(int rank_, int size_, const char *addr, int base_port) : wmutex((size_t)size_)
+    {
+        rank = rank_;
+        size = size_;
+        fd.assign((size_t)size, -1);
+        int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+        int one = 1;
+        setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        sockaddr_in sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sin_family = AF_INET;
+        sa.sin_port = htons((uint16_t)(base_port + rank));
+        inet_pton(AF_INET, addr, &sa.sin_addr);
+        if (::bind(ls, (sockaddr *)&sa, sizeof(sa)) != 0)
+            fatal("rank %d: bind to %s:%d failed: %s", rank, addr, base_port + rank, strerror(errno));
+        ::listen(ls, size);
+        // connect to every lower rank, accept from every higher rank
+        for (int peer = 0; peer < rank; peer++)
+        {
+            int s = -1;
+            for (int attempt = 0;; attempt++)
+            {
+                s = ::socket(AF_INET, SOCK_STREAM, 0);
+                sockaddr_in pa = sa;
+                pa.sin_port = htons((uint16_t)(base_port + peer));
+                if (::connect(s, (sockaddr *)&pa, sizeof(pa)) == 0)
+                    break;
+                ::close(s);
+                if (attempt > 6000)
+                    fatal("rank %d: cannot reach rank %d at %s:%d", rank, peer, addr, base_port + peer);
+                usleep(10000);
+            }
+            setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            int me = rank;
+            write_all(s, &me, sizeof(me));
+            fd[(size_t)peer] = s;
+        }
+        for (int k = rank + 1; k < size; k++)
+        {
+            int s = ::accept(ls, nullptr, nullptr);
+            if (s < 0)
+                fatal("accept failed: %s", strerror(errno));
+            setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            int who = -1;
+            read_all(s, &who, sizeof(who));
+            fd[(size_t)who] = s;
+        }
+        ::close(ls);
+        sender = std::thread([this]()
+                             { sender_loop(); });
+    }
+
+    ~SocketComm() override
+    {
+        {
+            std::lock_guard<std::mutex> g(qmutex);
+            stop = true;
+        }
+        qcv.notify_all();
+        if (sender.joinable())
+            sender.join();
+        for (int s : fd)
+            if (s >= 0)
+                ::close(s);
+    }
+
+    void sender_loop()
+    {
+        for (;;)
+        {
+            SendReq r;
+            {
+                std::unique_lock<std::mutex> lk(qmutex);
+                qcv.wait(lk, [&]()
+                         { return stop || !sendq.empty(); });
+                if (sendq.empty())
+                    return;
+                r = sendq.front();
+                sendq.pop_front();
+            }
+            {
+                std::lock_guard<std::mutex> g(wmutex[(size_t)r.dst]);
+                write_all(fd[(size_t)r.dst], &r.f, sizeof(Frame));
+                write_all(fd[(size_t)r.dst], &r.h, sizeof(BlockHeader));
+                if (r.payload_bytes)
+                    write_all(fd[(size_t)r.dst], r.payload, r.payload_bytes);
+            }
+            {
+                std::lock_guard<std::mutex> g(qmutex);
+                inflight--;
+            }
+            qdrained.notify_all();
+        }
+    }
+
+    void send_bytes(int dst, int tag, const void *buf, size_t bytes) override
+    {
+        Frame f{FRAME_BYTES, (u32)tag, bytes};
+        std::lock_guard<std::mutex> g(wmutex[(size_t)dst]);
+        write_all(fd[(size_t)dst], &f, sizeof(f));
+        if (bytes)
+            write_all(fd[(size_t)dst], buf, bytes);
+    }
+
+    // read one frame from `src`; BYTES go to the mailbox, a BLOCK frame leaves its header in `bh`
+    bool read_frame(int src, BlockHeader *bh)
+    {
+        Frame f;
+        read_all(fd[(size_t)src], &f, sizeof(f));
+        if (f.type == FRAME_BYTES)
+        {
+            std::vector<char> m(f.bytes);
+            if (f.bytes)
+                read_all(fd[(size_t)src], m.data(), f.bytes);
+            mailbox[{src, (int)f.tag}].push_back(std::move(m));
+            return false;
+        }
+        if (f.type != FRAME_BLOCK)
+            fatal("corrupt frame from rank %d", src);
+        if (!bh)
+            fatal("rank %d: block record from rank %d outside the numeric phase", rank, src);
+        read_all(fd[(size_t)src], bh, sizeof(BlockHeader));
+        return true;
+    }
+
+    void recv_bytes(int src, int tag, void *buf, size_t bytes) override
+    {
+        for (;;)
+        {
+            auto it = mailbox.find({src, tag});
+            if (it != mailbox.end() && !it->second.empty())
+            {
+                std::vector<char> &m = it->second.front();
+                if (m.size() != bytes)
+                    fatal("message size mismatch from rank %d tag %d: got %zu want %zu", src, tag, m.size(), bytes);
+                if (bytes)
+                    memcpy(buf, m.data(), bytes);
+                it->second.pop_front();
+                return;
+            }
+            read_frame(src, nullptr);
+        }
+    }
+
+    void barrier() override
+    {
+        if (size == 1)
+            return;
+        char c = 0;
+        if (rank == 0)
+        {
+            for (int r = 1; r < size; r++)
+                recv_bytes(r, TAG_BARRIER, &c, 1);
+            for (int r = 1; r < size; r++)
+                send_bytes(r, TAG_BARRIER, &c, 1);
+        }
+        else
+        {
+            send_bytes(0, TAG_BARRIER, &c, 1);
+            recv_bytes(0, TAG_BARRIER, &c, 1);
+        }
+    }
+
+    void bcast(void *buf, size_t bytes, int root) override
+    {
+        if (size == 1)
+            return;
+        // chunked so that arbitrarily large arrays (the input matrix) pass
+        const size_t chunk = (size_t)1 << 26;
+        for (size_t off = 0; off < bytes || (bytes == 0 && off == 0); off += chunk)
+        {
+            size_t len = bytes ? std::min(chunk, bytes - off) : 0;
+            if (rank == root)
+            {
+                for (int r = 0; r < size; r++)
+                    if (r != root)
+                        send_bytes(r, TAG_BCAST, (char *)buf + off, len);
+            }
+            else
+            {
+                recv_bytes(root, TAG_BCAST, (char *)buf + off, len);
+            }
+            if (bytes == 0)
+                break;
+        }
+    }
+
+    void allreduce_sum_i64(i64 *v, int count) override
+    {
+        if (size == 1)
+            return;
+        std::vector<i64> tmp((size_t)count);
+        if (rank == 0)
+        {
+            for (int r = 1; r < size; r++)
+            {
+                recv_bytes(r, TAG_REDUCE, tmp.data(), sizeof(i64) * (size_t)count);
+                for (int i = 0; i < count; i++)
+                    v[i] += tmp[(size_t)i];
+            }
+        }
+        else
+        {
+            send_bytes(0, TAG_REDUCE, v, sizeof(i64) * (size_t)count);
+        }
+        bcast(v, sizeof(i64) * (size_t)count, 0);
+    }
+
+    void allreduce_max_f64(double *v, int count) override
+    {
+        if (size == 1)
+            return;
+        std::vector<double> tmp((size_t)count);
+        if (rank == 0)
+        {
+            for (int r = 1; r < size; r++)
+            {
+                recv_bytes(r, TAG_REDUCE, tmp.data(), sizeof(double) * (size_t)count);
+                for (int i = 0; i < count; i++)
+                    v[i] = std::max(v[i], tmp[(size_t)i]);
+            }
+        }
+        else
+        {
+            send_bytes(0, TAG_REDUCE, v, sizeof(double) * (size_t)count);
+        }
+        bcast(v, sizeof(double) * (size_t)count, 0);
+    }
+
+    void isend_block(slot_t *s, const BlockHeader &h, int dst) override
+    {
+        Platform &plat = active_platform();
+        size_t bytes = h.bytes_lo;
+        if (!plat.host_memory)
+        {
+            // host-staged: bring the finished values back (the pattern part of the host record is already right)
+            plat.memcpy_(s->value, s->d_value, sizeof(val_t) * h.nnz, 1);
+        }
+        // the wire record is the host record with a fresh header (src/pangulu_communication.c:1929-1942)
+        BlockHeader *rec = (BlockHeader *)((char *)s->value - 32);
+        *rec = h;
+        SendReq r;
+        r.dst = dst;
+        r.f = Frame{FRAME_BLOCK, 0, bytes};
+        r.h = h;
+        r.payload = (const char *)s->value; // header travels in r.h, the rest of the record follows
+        r.payload_bytes = bytes - 32;
+        {
+            std::lock_guard<std::mutex> g(qmutex);
+            sendq.push_back(r);
+            inflight++;
+        }
+        qcv.notify_one();
+        sent_bytes += bytes;
+    }
+
+    int probe_cursor = 0;
+    bool probe_block(BlockHeader &h, int &src) override
+    {
+        std::vector<pollfd> pf;
+        std::vector<int> who;
+        for (int k = 0; k < size; k++)
+        {
+            int r = (probe_cursor + k) % size;
+            if (r == rank)
+                continue;
+            pf.push_back(pollfd{fd[(size_t)r], POLLIN, 0});
+            who.push_back(r);
+        }
+        int n = ::poll(pf.data(), pf.size(), 0);
+        if (n <= 0)
+            return false;
+        for (size_t i = 0; i < pf.size(); i++)
+        {
+            if (pf[i].revents & (POLLIN | POLLHUP))
+            {
+                probe_cursor = (who[i] + 1) % size;
+                if (read_frame(who[i], &h))
+                {
+                    src = who[i];
+                    return true;
+                }
+                return false; // a control message was filed; come back
+            }
+        }
+        return false;
+    }
+
+    void recv_block(slot_t *s, const BlockHeader &h, int src) override
+    {
+        size_t bytes = h.bytes_lo;
+        BlockHeader *rec = (BlockHeader *)((char *)s->value - 32);
+        *rec = h;
+        read_all(fd[(size_t)src], (char *)s->value, bytes - 32);
+        Platform &plat = active_platform();
+        if (!plat.host_memory)
+            plat.memcpy_((char *)s->d_value - 32, (char *)s->value - 32, bytes, 0);
+        recv_bytes_total += bytes;
+    }
+
+    void flush_sends() override
+    {
+        std::unique_lock<std::mutex> lk(qmutex);
+        qdrained.wait(lk, [&]()
+                      { return inflight == 0; });
+    }
+};
+
+
+} // namespace pg

@@ -208,6 +208,8 @@ public:
 Comm *world();             // never null: a 1-rank loopback by default
 void set_world(Comm *c);   // takes ownership
 Comm *make_socket_comm(int rank, int size, const char *addr, int base_port, int transport, const void *nccl_id);
+int rccl_make_unique_id(void *out128); // 0 on success; librccl.so is loaded lazily
+Comm *make_rccl_comm(int rank, int size, const char *addr, int base_port, const void *nccl_id);
 
 // ---------------------------------------------------------------------------------------------------------
 // the solver instance behind the opaque handle
@@ -257,6 +259,7 @@ struct Solver
     std::vector<u32> pending_dirty;        // owned slot indices with non-empty queues, in first-touch order
     u64 pending_total = 0;
     bool factored = false, host_values_current = true;
+    char *arena_snapshot = nullptr;        // pristine copy of the owned records (device side), see pangulu_amd_snapshot
     // statistics
     pangulu_amd_info_t info;
     TaskModel model;

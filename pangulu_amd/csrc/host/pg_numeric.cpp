@@ -552,7 +552,11 @@ struct Sched
             if (batch.empty())
             {
                 if (!idle_flush())
+                {
+                    if (!multi)
+                        fatal("scheduler stalled with %lld panel tasks left and nothing runnable", (long long)S.rank_remain_task);
                     usleep(20);
+                }
                 continue;
             }
             S.rank_remain_task -= (i64)batch.size();
@@ -596,6 +600,13 @@ struct Sched
         if (b == ~0ull)
             fatal("received block (%u,%u) that is not in the block pattern", h.brow, h.bcol);
         S.slot_of[b] = s;
+        if (S.remain[b] == 0)
+        {
+            // forwarded by the owner's rule, but none of my updates pairs it with an existing partner block
+            S.slot_of[b] = nullptr;
+            S.storage.recycle(s);
+            return;
+        }
         if (h.brow > h.bcol)
             release_after_L(s, h.brow, h.bcol, false);
         else
@@ -646,7 +657,10 @@ void numeric_factorize(Solver &S)
     Comm *comm = world();
     Platform &plat = active_platform();
     if (plat.set_option)
+    {
         plat.set_option(PANGULU_HIP_OPT_HOST_MIRROR, S.eager_host_mirror ? 1 : 0);
+        plat.set_option(PANGULU_HIP_OPT_ASSUME_INDEPENDENT, 1); // batches of this scheduler are dependency-free
+    }
     S.heap.clear();
     S.pending_total = 0;
     S.pending_dirty.clear();

@@ -460,6 +460,26 @@ void preprocess(Solver &S, const CscMatrix &A)
     }
     // + 1 for the panel operation of every owned block; remote diagonals count my TSTRF/GESSM consumers
     i64 my_tasks = 0, my_getrf = 0, my_tstrf = 0, my_gessm = 0, my_recv = 0;
+    // What will be SENT to me follows the owners' forwarding rule (pg_numeric.cpp release_after_L/U, reference
+    // src/pangulu_numeric.c:452-517,535-600): a finished L(br,k) goes to every rank owning a block of block row
+    // br right of column k (or diagonal (br,br)); a finished U(k,bc) to every rank owning a block of block
+    // column bc below row k (or diagonal (bc,bc)) -- whether or not that rank ends up with an update that uses
+    // it (the partner operand may be structurally absent).  The receive count must follow the same rule.
+    std::vector<i64> last_owned_col(nbk, -1), last_owned_row(nbk, -1);
+    for (u32 bc = 0; bc < nbk; bc++)
+        for (u64 t = P.colptr[bc]; t < P.colptr[bc + 1]; t++)
+            if (S.owner(P.rowidx[t], bc) == me)
+            {
+                u32 br = P.rowidx[t];
+                last_owned_col[br] = std::max<i64>(last_owned_col[br], bc);
+                last_owned_row[bc] = std::max<i64>(last_owned_row[bc], br);
+            }
+    for (u32 k = 0; k < nbk; k++)
+        if (S.owner(k, k) == me)
+        {
+            last_owned_col[k] = std::max<i64>(last_owned_col[k], k);
+            last_owned_row[k] = std::max<i64>(last_owned_row[k], k);
+        }
     for (u32 bc = 0; bc < nbk; bc++)
     {
         for (u64 t = P.colptr[bc]; t < P.colptr[bc + 1]; t++)
@@ -477,9 +497,11 @@ void preprocess(Solver &S, const CscMatrix &A)
                 if (S.owner(level, level) != me)
                     S.remain_diag[level]++;
             }
-            else if (S.remain[t] > 0)
+            else
             {
-                my_recv++;
+                bool sent_to_me = (br > bc) ? (last_owned_col[br] > (i64)bc) : (last_owned_row[bc] > (i64)br);
+                if (sent_to_me)
+                    my_recv++;
             }
         }
     }
@@ -544,8 +566,14 @@ void preprocess(Solver &S, const CscMatrix &A)
         };
         for (u32 bc = 0; bc < nbk; bc++)
             for (u64 t = P.colptr[bc]; t < P.colptr[bc + 1]; t++)
-                if (S.owner(P.rowidx[t], bc) != me && S.remain[t] > 0)
+            {
+                u32 br = P.rowidx[t];
+                if (S.owner(br, bc) == me)
+                    continue;
+                bool sent_to_me = (br > bc) ? (last_owned_col[br] > (i64)bc) : (last_owned_row[bc] > (i64)br);
+                if (sent_to_me)
                     need_cnt[classify(P.nnz[t])]++;
+            }
         for (u32 k = 0; k < nbk; k++)
             if (S.owner(k, k) != me && S.remain_diag[k] > 0)
                 need_cnt[classify(P.diag_upper_nnz[k])] += 2;
@@ -623,6 +651,13 @@ void download_factors(Solver &S)
 Solver::~Solver()
 {
     Platform &plat = active_platform();
+    if (arena_snapshot)
+    {
+        if (plat.host_memory)
+            free(arena_snapshot);
+        else
+            plat.free_(arena_snapshot);
+    }
     if (storage.harena)
     {
         if (!plat.host_memory && storage.darena)

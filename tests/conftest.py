@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """The shared objects are build products (git-ignored); build them once if this checkout has none."""
+    from pangulu_amd import _lib
+
+    need = [_lib.library_path("r64"), os.path.join(ROOT, "oracle", "_build", "libpangulu_oracle_r64.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    yield

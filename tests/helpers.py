@@ -1,0 +1,74 @@
+"""Shared test plumbing: factorise a matrix on a chosen platform through the public C-ABI and return the factors.
+
+`platform` is "hip" (the product path) or the path of an oracle shared object (CPU restatement of the reference's
+CPU platform; test infrastructure only -- see oracle/pangulu_oracle.c).
+"""
+import os
+
+import numpy as np
+
+import pangulu_amd as pa
+from pangulu_amd import _lib
+from pangulu_amd import matrices as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_library(vtype="r64", fma=False):
+    return os.path.join(ROOT, "oracle", "_build", "libpangulu_oracle_%s%s.so" % (vtype, "_fma" if fma else ""))
+
+
+def select_platform(lib, platform):
+    if platform == "hip":
+        lib.pangulu_amd_use_builtin_platform()
+    else:
+        rc = lib.pangulu_amd_use_platform_library(platform.encode(), _lib.PLATFORM_CPU_NAIVE)
+        assert rc == 0, "cannot load %s" % platform
+
+
+def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_factors=True, user_perm=None, nthread=4):
+    """Runs pangulu_init + gstrf (+ gstrs with b = A*1) and returns info, factors (scipy CSC, permuted ordering),
+    the permutation, x and ||Ax-b||/||b||."""
+    n, cp, ri, va, coords = mat
+    lib = _lib.load(vtype)
+    select_platform(lib, platform)
+    if platform == "hip":
+        pa.hip_stats(lib, reset=True)
+    if ordering is None:
+        ordering = "nd"
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering,
+                        coords=coords if ordering == "nd" else None, user_perm=user_perm, nthread=nthread)
+    out = {"info": h.info()}
+    pa.pangulu_gstrf(h)
+    out["info"] = h.info()
+    if platform == "hip":
+        out["hip_stats"] = pa.hip_stats(lib)
+    out["perm"] = pa.permutation(h)
+    if keep_factors:
+        out["L"], out["U"] = pa.factors_as_scipy(h)
+    if solve:
+        b = M.rhs_of_ones(n, cp, ri, va)
+        x = pa.pangulu_gstrs(h, b)
+        out["x"] = x
+        out["residual"] = M.relative_residual(n, cp, ri, va, x, b)
+    pa.pangulu_finalize(h)
+    return out
+
+
+def lu_check(mat, res):
+    """The reference's factor check (src/pangulu_numeric.c:1082-1341): ||L(U 1) - A' 1|| / ||A' 1|| in the permuted ordering."""
+    n, cp, ri, va, _ = mat
+    A = M.to_scipy(n, cp, ri, va).tocsr()
+    p = res["perm"].astype(np.int64)
+    Ap = A[p][:, p]
+    ones = np.ones(n, dtype=va.dtype)
+    lhs = res["L"] @ (res["U"] @ ones)
+    rhs = Ap @ ones
+    return float(np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs))
+
+
+def max_rel_diff(a, b):
+    """max |a-b| / max |b| over two sparse matrices with the same shape."""
+    d = abs(a - b)
+    scale = abs(b).max()
+    return float(d.max() / scale) if scale else float(d.max())

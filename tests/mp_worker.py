@@ -1,0 +1,66 @@
+"""One rank of a multi-process CPU run (launched by tests/test_multirank.py).
+
+Rendezvous and result gathering use torch.distributed with the gloo backend; the solver's own process group
+(pangulu_amd_comm_init: TCP control plane + host-staged block records) is what is under test.  The numeric kernels
+are the oracle's CPU platform -- this checks the distributed scheduler, not the GPU.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import pangulu_amd as pa  # noqa: E402
+from pangulu_amd import _lib  # noqa: E402
+from pangulu_amd import matrices as M  # noqa: E402
+from tests.helpers import oracle_library  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    spec, nb, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    vtype = sys.argv[4] if len(sys.argv) > 4 else "r64"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _lib.load(vtype)
+    assert lib.pangulu_amd_use_platform_library(oracle_library(vtype).encode(), _lib.PLATFORM_CPU_NAIVE) == 0
+    base_port = int(os.environ["MASTER_PORT"]) + 40
+    assert lib.pangulu_amd_comm_init(rank, world, b"127.0.0.1", base_port, _lib.TRANSPORT_HOST, None) == 0
+    dtype = _lib.VALUE_TYPES[vtype][0]
+    gen = {"fem27_6": lambda: M.fem27(6, dtype=dtype), "poisson8": lambda: M.poisson3d(8, dtype=dtype),
+           "shell_8x7": lambda: M.shell(8, 7, dtype=dtype), "trefethen": lambda: M.trefethen(dtype=dtype),
+           "random200": lambda: M.random_pattern(200, 0.03, 5, dtype=dtype)}[spec]
+    n, cp, ri, va, co = gen()
+    ordering = "identity" if spec == "trefethen" else "nd"
+    if rank == 0:
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=co if ordering == "nd" else None)
+    else:
+        h = pa.pangulu_init(0, 0, None, None, None, nb=nb, vtype=vtype, ordering=ordering)  # rank 0 broadcasts the matrix
+    pa.pangulu_gstrf(h)
+    info = h.info()
+    L, U = pa.factors_as_scipy(h)  # this rank's blocks only
+    b = M.rhs_of_ones(n, cp, ri, va) if rank == 0 else None
+    x = pa.pangulu_gstrs(h, b)
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((L, U, info), parts, dst=0)
+    if rank == 0:
+        Ls = sum(p[0] for p in parts)
+        Us = sum(p[1] for p in parts)
+        import scipy.sparse as sp
+
+        Ls = Ls - (world - 1) * sp.identity(n, format="csc", dtype=dtype)  # every rank added the unit diagonal
+        res = M.relative_residual(n, cp, ri, va, x, b)
+        np.savez(out_path, L_data=Ls.tocsc().data, L_ind=Ls.tocsc().indices, L_ptr=Ls.tocsc().indptr,
+                 U_data=Us.tocsc().data, U_ind=Us.tocsc().indices, U_ptr=Us.tocsc().indptr, residual=res,
+                 flop=parts[0][2]["flop"], sent=[p[2]["sent_bytes"] for p in parts], recv=[p[2]["recv_bytes"] for p in parts],
+                 recv_blocks=[p[2]["recv_blocks"] for p in parts], tasks=[p[2]["ntask_ssssm"] for p in parts])
+    pa.pangulu_finalize(h)
+    lib.pangulu_amd_comm_finalize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

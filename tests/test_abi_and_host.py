@@ -1,0 +1,168 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/*.h declares, struct layouts match the
+reference ABI, and the host logic (ordering, symbolic, block records, scheduler) behaves on the oracle platform."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import pangulu_amd as pa
+from pangulu_amd import _lib
+from pangulu_amd import matrices as M
+
+from .helpers import ROOT, factorize, oracle_library
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pangulu_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("vtype", ["r64", "r32", "cr64", "cr32"])
+def test_library_exports_every_declared_symbol(vtype):
+    lib = ctypes.CDLL(_lib.library_path(vtype))
+    names = declared_functions("pangulu_platform.h") + declared_functions("pangulu.h") + declared_functions("pangulu_amd_ext.h")
+    assert len([n for n in names if n.startswith("pangulu_platform_0201001_")]) >= 21
+    for n in names:
+        if n in ("pangulu_amd_rccl_unique_id",):  # declared for the RCCL transport, resolved lazily
+            continue
+        assert hasattr(lib, n), "%s is declared in include/ but not exported by %s" % (n, _lib.library_path(vtype))
+    for op in _lib.PLATFORM_SYMBOLS:
+        assert hasattr(lib, "pangulu_platform_0201001_" + op)
+
+
+@pytest.mark.parametrize("vtype", ["r64", "r32", "cr64", "cr32"])
+def test_oracle_exports_the_cpu_platform(vtype):
+    lib = ctypes.CDLL(oracle_library(vtype))
+    for op in _lib.PLATFORM_SYMBOLS:
+        assert hasattr(lib, "pangulu_platform_0100000_" + op)
+    lib.pangulu_oracle_sizeof_value.restype = ctypes.c_int
+    assert lib.pangulu_oracle_sizeof_value() == _lib.VALUE_TYPES[vtype][1]
+
+
+def test_struct_abi_matches_reference_layout(tmp_path):
+    """sizeof/offsetof of the two descriptor structs as a C compiler sees them (reference: 144 and 48 bytes)."""
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "pangulu_platform.h"\n'
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(pangulu_storage_slot_t), offsetof(pangulu_storage_slot_t,value),"
+        "offsetof(pangulu_storage_slot_t,related_block), offsetof(pangulu_storage_slot_t,d_value), sizeof(pangulu_task_t),"
+        "offsetof(pangulu_task_t,compare_flag), offsetof(pangulu_task_t,op2));return 0;}\n")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert list(map(int, out)) == [144, 24, 64, 112, 48, 16, 40]
+
+
+def test_product_path_fails_loudly_without_a_gpu():
+    """No CPU fallback: with the built-in HIP platform and no device, pangulu_init must abort with a message."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import pangulu_amd as pa\nfrom pangulu_amd import matrices as M\n"
+        "n,cp,ri,va,co = M.trefethen()\n"
+        "pa.pangulu_init(n, len(va), cp, ri, va, nb=10, ordering='identity')\nprint('UNEXPECTED')\n" % ROOT
+    )
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert "UNEXPECTED" not in out.stdout
+    assert "no HIP device" in out.stderr or "HIP" in out.stderr
+
+
+def test_init_rejects_mismatched_value_type():
+    code = (
+        "import sys, ctypes; sys.path.insert(0, %r)\n"
+        "from pangulu_amd import _lib\nlib=_lib.load('r64')\n"
+        "opt=_lib.InitOptions(); opt.nb=8; opt.sizeof_value=4; opt.is_complex_matrix=0\n"
+        "h=ctypes.c_void_p()\n"
+        "lib.pangulu_init(1,1,None,None,None,ctypes.byref(opt),ctypes.byref(h))\nprint('UNEXPECTED')\n" % ROOT
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 1 and "sizeof_value" in out.stdout and "UNEXPECTED" not in out.stdout
+
+
+@pytest.mark.parametrize("gen,coords", [(lambda: M.poisson3d(9, 7, 5), True), (lambda: M.poisson3d(9, 7, 5), False),
+                                        (lambda: M.shell(10, 9), True), (lambda: M.random_pattern(300, 0.01, 1), False)])
+def test_nested_dissection_is_a_permutation_and_reduces_fill(gen, coords):
+    n, cp, ri, va, co = gen()
+    mat = (n, cp, ri, va, co if coords else None)
+    nd = factorize(mat, 32, oracle_library("r64"), ordering="nd", solve=True, keep_factors=False)
+    ident = factorize(mat, 32, oracle_library("r64"), ordering="identity", solve=False, keep_factors=False)
+    assert sorted(nd["perm"].tolist()) == list(range(n))
+    assert nd["residual"] < 1e-13
+    if n > 250:
+        assert nd["info"]["flop"] < 1.5 * ident["info"]["flop"]
+
+
+def test_user_permutation_is_honoured():
+    mat = M.poisson3d(5)
+    n = mat[0]
+    perm = np.random.default_rng(0).permutation(n).astype(np.uint32)
+    r = factorize(mat, 16, oracle_library("r64"), ordering="user", user_perm=perm)
+    assert (r["perm"] == perm).all() and r["residual"] < 1e-13
+
+
+def test_block_records_follow_the_reference_layout():
+    """Patterns of the exported records: sorted CSC inside blocks, mirrored diagonal halves with the diagonal entry
+    first in every upper row, values = A on its pattern and 0 on fill before gstrf."""
+    mat = M.fem27(5)
+    n, cp, ri, va, co = mat
+    lib = _lib.load("r64")
+    lib.pangulu_amd_use_platform_library(oracle_library("r64").encode(), _lib.PLATFORM_CPU_NAIVE)
+    nb = 32
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, coords=co)
+    perm = pa.permutation(h).astype(np.int64)
+    Ap = M.to_scipy(n, cp, ri, va).tocsr()[perm][:, perm].toarray()
+    nbk = (n + nb - 1) // nb
+    npad = nbk * nb
+    dense = np.zeros((npad, npad))
+    lower_cols, upper_rows = {}, {}
+    for brow, bcol, up, colptr, rowidx, vals in pa.owned_blocks(h):
+        assert colptr[0] == 0 and (np.diff(colptr.astype(np.int64)) >= 0).all()
+        for c in range(nb):
+            seg = rowidx[colptr[c]:colptr[c + 1]].astype(np.int64)
+            assert (np.diff(seg) > 0).all()
+            if brow == bcol and up:
+                if len(seg):
+                    assert seg[0] == c  # diagonal first
+                upper_rows[(brow, c)] = seg[1:].tolist()
+                dense[brow * nb + c, bcol * nb + seg] = vals[colptr[c]:colptr[c + 1]]
+            else:
+                if brow == bcol:
+                    assert (seg > c).all()
+                    lower_cols[(brow, c)] = seg.tolist()
+                dense[brow * nb + seg, bcol * nb + c] = vals[colptr[c]:colptr[c + 1]]
+    assert lower_cols == upper_rows  # mirrored halves
+    assert np.array_equal(dense[:n, :n], Ap)
+    pa.pangulu_finalize(h)
+
+
+def test_gstrf_twice_after_reset_gives_identical_factors():
+    mat = M.fem27(5)
+    n, cp, ri, va, co = mat
+    lib = _lib.load("r64")
+    lib.pangulu_amd_use_platform_library(oracle_library("r64").encode(), _lib.PLATFORM_CPU_NAIVE)
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=32, coords=co)
+    assert lib.pangulu_amd_snapshot(h.ref) == 0
+    pa.pangulu_gstrf(h)
+    L1, U1 = pa.factors_as_scipy(h)
+    assert lib.pangulu_amd_reset_numeric(h.ref) == 0
+    pa.pangulu_gstrf(h)
+    L2, U2 = pa.factors_as_scipy(h)
+    assert abs(L1 - L2).max() == 0 and abs(U1 - U2).max() == 0
+    pa.pangulu_finalize(h)
+
+
+def test_matrix_generators_are_diagonally_dominant():
+    for gen in (lambda: M.shell(7, 6), lambda: M.fem27(4), lambda: M.poisson3d(5), lambda: M.kkt(3), lambda: M.random_pattern(60, 0.1, 2)):
+        n, cp, ri, va, _ = gen()
+        A = M.to_scipy(n, cp, ri, va).tocsr()
+        d = np.abs(A.diagonal())
+        off = np.asarray(abs(A).sum(axis=1)).ravel() - d
+        assert (d > off - 1e-12).all() or (d >= 0.99 * off).all()
+        assert sp.issparse(A)

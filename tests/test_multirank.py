@@ -1,0 +1,72 @@
+"""N > 1 on CPU: 2D block-cyclic ownership, point-to-point block exchange, slot recycling, distributed SpTRSV.
+
+Ranks are separate processes (rendezvous through torch.distributed / gloo on 127.0.0.1); kernels are the oracle's.
+The sum of all ranks' factor blocks must equal the single-rank factors to rounding (the reference itself differs
+between 1 and N ranks in the last bits), and ||Ax-b||/||b|| must stay at rounding level."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from pangulu_amd import matrices as M
+
+from .helpers import ROOT, factorize, max_rel_diff, oracle_library
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(world, spec, nb, out_path, vtype="r64"):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), spec, str(nb), out_path, vtype],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r])
+
+
+GENS = {"fem27_6": lambda: M.fem27(6), "poisson8": lambda: M.poisson3d(8), "shell_8x7": lambda: M.shell(8, 7),
+        "trefethen": lambda: M.trefethen(), "random200": lambda: M.random_pattern(200, 0.03, 5)}
+
+
+@pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (2, "trefethen", 4), (4, "poisson8", 32), (4, "trefethen", 4),
+                                           (3, "shell_8x7", 24), (2, "random200", 16)])
+def test_multirank_matches_single_rank(tmp_path, world, spec, nb):
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out)
+    z = np.load(out)
+    mat = GENS[spec]()
+    n = mat[0]
+    ordering = "identity" if spec == "trefethen" else "nd"
+    ref = factorize(mat, nb, oracle_library("r64"), ordering=ordering)
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
+    assert int(z["flop"]) == ref["info"]["flop"]
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
+    assert float(z["residual"]) < 1e-13
+    # every rank took part and the bytes sent equal the bytes received
+    assert sum(z["sent"]) == sum(z["recv"]) and sum(z["recv"]) > 0
+    assert sum(z["tasks"]) == ref["info"]["ntask_ssssm"]
+    if spec == "trefethen":
+        assert float(z["residual"]) < 4e-16  # the reference printed 1.4e-16 at 2 and 4 ranks, nb=4
