@@ -112,7 +112,7 @@ def load(vtype="r64"):
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C pangulu_amd/csrc TYPE=%s`); there is no fallback implementation" % (path, vtype.upper())
         )
-    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
     vp, vpp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)
     lib.pangulu_init.argtypes = [ctypes.c_uint32, ctypes.c_uint64, vp, vp, vp, ctypes.POINTER(InitOptions), vpp]
     lib.pangulu_init.restype = None

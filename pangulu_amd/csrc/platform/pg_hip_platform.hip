@@ -986,8 +986,17 @@ void launch_trsm(int nb, task_t **list, size_t n)
         {
             task_t *t = list[i + k];
             slot_t *dst = t->opdst, *diag = t->op1;
-            slot_t *up, *lo;
-            diag_halves(diag, &up, &lo);
+            // opdiag may be either half (…0100000.c:143-145,184-186); only the half the solve reads has to exist
+            // (a rank that received a remote diagonal for its TSTRFs only may never get the L half)
+            const bool want_upper = t->kernel_id == PANGULU_TASK_TSTRF;
+            slot_t *half = ((diag->is_upper != 0) == want_upper) ? diag : diag->related_block;
+            if (!half)
+            {
+                fprintf(stderr, "[PanguLU-AMD ERROR] %s on block (%u,%u): the %s half of diagonal %u is not available\n",
+                        want_upper ? "TSTRF" : "GESSM", dst->brow_pos, dst->bcol_pos, want_upper ? "upper" : "lower", diag->brow_pos);
+                exit(EXIT_FAILURE);
+            }
+            slot_t *up = half, *lo = half;
             TrsmTaskD T;
             memset(&T, 0, sizeof(T));
             u32 nnz_b = host_nnz(dst, nb);

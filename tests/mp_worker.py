@@ -23,9 +23,13 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     spec, nb, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     vtype = sys.argv[4] if len(sys.argv) > 4 else "r64"
+    platform = sys.argv[5] if len(sys.argv) > 5 else "oracle"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = _lib.load(vtype)
-    assert lib.pangulu_amd_use_platform_library(oracle_library(vtype).encode(), _lib.PLATFORM_CPU_NAIVE) == 0
+    if platform == "oracle":
+        assert lib.pangulu_amd_use_platform_library(oracle_library(vtype).encode(), _lib.PLATFORM_CPU_NAIVE) == 0
+    else:
+        lib.pangulu_amd_use_builtin_platform()  # every rank on the one GPU of the test box (LOCAL_RANK % device count)
     base_port = int(os.environ["MASTER_PORT"]) + 40
     assert lib.pangulu_amd_comm_init(rank, world, b"127.0.0.1", base_port, _lib.TRANSPORT_HOST, None) == 0
     dtype = _lib.VALUE_TYPES[vtype][0]
