@@ -59,6 +59,7 @@ extern "C"
     typedef struct pangulu_amd_info_t
     {
         unsigned long long n, nnz, nb, block_length;
+        unsigned long long n_padded;          /* n plus the padding rows of a block-aligned ordering (== n otherwise)  */
         unsigned long long symbolic_nnz;      /* nnz(L+U) incl. diagonal once, as src/pangulu_symbolic.c:242          */
         long long flop;                       /* structural flop count F = sum_k (c_k + 2 c_k^2), SURVEY.md §8a a9     */
         unsigned long long nblocks_nondiag;   /* non-empty off-diagonal blocks, whole matrix                          */
@@ -95,7 +96,7 @@ extern "C"
     int pangulu_amd_owned_block(void **pangulu_handle, long long idx, sparse_index_t *brow, sparse_index_t *bcol,
                                 int *is_upper, unsigned long long *nnz, const pangulu_inblock_ptr **colptr,
                                 const pangulu_inblock_idx **rowidx, const calculate_type **value);
-    /* the symmetric permutation used: perm[new] = old (length n) */
+    /* the symmetric permutation used: perm[new] = old, length info.n_padded; entries >= n are padding rows */
     const sparse_index_t *pangulu_amd_get_perm(void **pangulu_handle);
     /* y = L*(U*x) with the (downloaded) factors of a single-rank run, in the permuted ordering; used for the
      * reference's factor check ||L(U.1) - A.1|| / ||A.1|| (src/pangulu_numeric.c:1082-1341) */

@@ -212,6 +212,9 @@ extern "C"
      *     dependent phases.  The native scheduler sets it. */
 #define PANGULU_HIP_OPT_PROFILE 3
 #define PANGULU_HIP_OPT_ASSUME_INDEPENDENT 4
+    /*   PANGULU_HIP_OPT_GETRF_STRICT_ORDER (default 0): 1 selects the pattern-driven GETRF kernel for every block
+     *     (the only one for value types other than R64); 0 lets R64 blocks use the LDS-blocked MFMA kernel. */
+#define PANGULU_HIP_OPT_GETRF_STRICT_ORDER 5
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an

@@ -51,6 +51,7 @@ class Info(ctypes.Structure):
         ("nnz", ctypes.c_ulonglong),
         ("nb", ctypes.c_ulonglong),
         ("block_length", ctypes.c_ulonglong),
+        ("n_padded", ctypes.c_ulonglong),
         ("symbolic_nnz", ctypes.c_ulonglong),
         ("flop", ctypes.c_longlong),
         ("nblocks_nondiag", ctypes.c_ulonglong),
@@ -184,6 +185,7 @@ HIP_OPT_HOST_MIRROR = 1
 HIP_OPT_DENSE_THRESHOLD_PERMILLE = 2
 HIP_OPT_PROFILE = 3
 HIP_OPT_ASSUME_INDEPENDENT = 4
+HIP_OPT_GETRF_STRICT_ORDER = 5
 
 ORDER_IDENTITY, ORDER_ND, ORDER_USER = 0, 1, 2
 TRANSPORT_HOST, TRANSPORT_RCCL = 0, 1

@@ -84,30 +84,41 @@ void build_graph(const CscMatrix &A, Graph &G)
     }
 }
 
-// Nested dissection with vertex separators taken from a bisection's boundary.  Regions are kept as ranges of
-// the output permutation: a region [lo, hi) of `perm` is split in place into [left | right | separator].
+// Nested dissection with vertex separators taken from a bisection's boundary.  A region is split into
+// [left | right | separator]; the separator is ordered last so that its fill stays at the end of the region.
+//
+// Block alignment (the MI355X-first part): the solver tiles the matrix in regular nb x nb blocks, and a block that
+// straddles two sibling subtrees chains them together -- the block-level task graph of an unaligned dissection is
+// nearly one long chain of diagonal blocks, which starves a GPU.  With `align` > 0 the start of the right child of
+// every large split is moved up to the next multiple of `align` by inserting padding positions (kNoVertex in the
+// output; the caller turns them into isolated identity rows).  Large regions then start on block boundaries by
+// induction, sibling subtrees share no block, and their panels can be batched into the same launches.
+const u32 kNoVertex = 0xFFFFFFFFu;
+
 struct Dissector
 {
     const Graph &G;
     const double *xyz;
     int dim;
     u32 leaf;
-    std::vector<u32> &perm;      // perm[new] = old, being built in place
-    std::vector<u32> region;     // region id of every vertex (which stack entry currently owns it)
+    u32 align, align_min; // pad to `align` when both children have at least `align_min` vertices
+    std::vector<u32> out;        // ordering being built: out[new] = old, or kNoVertex for padding
+    std::vector<u32> region;     // region id of every vertex (which live region currently owns it)
     std::vector<u32> level;      // BFS scratch
-    std::vector<u32> queue;
-    u32 next_region = 1;
+    std::vector<u32> queue, seen, side;
+    u32 next_region = 1, stamp = 0;
 
-    Dissector(const Graph &g, const double *c, int d, u32 leaf_size, std::vector<u32> &out)
-        : G(g), xyz(c), dim(d), leaf(leaf_size), perm(out), region(g.n, 0), level(g.n, 0)
+    Dissector(const Graph &g, const double *c, int d, u32 leaf_size, u32 align_, u32 align_min_)
+        : G(g), xyz(c), dim(d), leaf(leaf_size), align(align_), align_min(align_min_), region(g.n, 0), level(g.n, 0), seen(g.n, 0), side(g.n, 0)
     {
         queue.reserve(g.n);
+        out.reserve(g.n + g.n / 8);
     }
 
     // BFS inside region `rid` from `start`; fills queue (visit order) and level[]; returns number of levels
-    u32 bfs(u32 start, u32 rid, u32 stamp_base, std::vector<u32> &seen, u32 stamp)
+    u32 bfs(u32 start, u32 rid)
     {
-        (void)stamp_base;
+        stamp++;
         queue.clear();
         queue.push_back(start);
         seen[start] = stamp;
@@ -132,214 +143,187 @@ struct Dissector
         return maxl + 1;
     }
 
-    void run()
+    void emit(const std::vector<u32> &vs) { out.insert(out.end(), vs.begin(), vs.end()); }
+
+    void relabel(const std::vector<u32> &vs, u32 rid)
     {
-        u32 n = G.n;
-        std::iota(perm.begin(), perm.end(), 0u);
-        struct Range
+        for (u32 v : vs)
+            region[v] = rid;
+    }
+
+    // orders the vertices of `vs` (all labelled `rid`) behind what is already in `out`
+    void order(std::vector<u32> &vs, u32 rid)
+    {
+        const u32 m = (u32)vs.size();
+        if (m <= leaf)
         {
-            u32 lo, hi, rid;
-        };
-        std::vector<Range> stack;
-        stack.push_back({0, n, 0});
-        std::vector<u32> seen(n, 0);
-        u32 stamp = 0;
-        std::vector<u32> side(n, 0); // 0 left, 1 right, 2 separator
-        std::vector<u32> tmp;
-        while (!stack.empty())
-        {
-            Range r = stack.back();
-            stack.pop_back();
-            u32 m = r.hi - r.lo;
-            if (m <= leaf)
-            {
-                continue; // keep the order the parent's split left them in
-            }
-            u32 *vs = perm.data() + r.lo;
-            bool split_done = false;
-            if (xyz && dim > 0)
-            {
-                // geometric: cut the widest axis at the median coordinate
-                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-                for (u32 t = 0; t < m; t++)
-                    for (int d = 0; d < dim; d++)
-                    {
-                        double c = xyz[(size_t)vs[t] * dim + d];
-                        lo[d] = std::min(lo[d], c);
-                        hi[d] = std::max(hi[d], c);
-                    }
-                int ax = 0;
-                for (int d = 1; d < dim; d++)
-                    if (hi[d] - lo[d] > hi[ax] - lo[ax])
-                        ax = d;
-                if (hi[ax] > lo[ax])
-                {
-                    tmp.assign(vs, vs + m);
-                    std::nth_element(tmp.begin(), tmp.begin() + m / 2, tmp.end(), [&](u32 a, u32 b)
-                                     { return xyz[(size_t)a * dim + ax] < xyz[(size_t)b * dim + ax]; });
-                    double cut = xyz[(size_t)tmp[m / 2] * dim + ax];
-                    if (cut <= lo[ax])
-                    {
-                        cut = std::nextafter(lo[ax], hi[ax]); // many ties at the low end: cut just above them
-                    }
-                    for (u32 t = 0; t < m; t++)
-                        side[vs[t]] = xyz[(size_t)vs[t] * dim + ax] < cut ? 0 : 1;
-                    split_done = true;
-                }
-            }
-            if (!split_done)
-            {
-                // graph: level structure from a pseudo-peripheral vertex of the first component; everything the
-                // BFS does not reach (other components) joins the smaller side
-                u32 start = vs[0];
-                stamp++;
-                u32 nl = bfs(start, r.rid, 0, seen, stamp);
-                for (int it = 0; it < 2; it++)
-                {
-                    u32 far = queue.back();
-                    stamp++;
-                    u32 nl2 = bfs(far, r.rid, 0, seen, stamp);
-                    if (nl2 <= nl)
-                    {
-                        nl = nl2;
-                        break;
-                    }
-                    nl = nl2;
-                }
-                u32 reached = (u32)queue.size();
-                if (reached < m)
-                {
-                    // disconnected region: component found vs the rest, no separator needed
-                    for (u32 t = 0; t < m; t++)
-                        side[vs[t]] = 1;
-                    for (u32 v : queue)
-                        side[v] = 0;
-                    u32 nleft = 0;
-                    tmp.resize(m);
-                    u32 a = 0, b = reached;
-                    for (u32 t = 0; t < m; t++)
-                    {
-                        if (side[vs[t]] == 0)
-                            tmp[a++] = vs[t];
-                        else
-                            tmp[b++] = vs[t];
-                    }
-                    nleft = a;
-                    std::copy(tmp.begin(), tmp.end(), vs);
-                    u32 rl = next_region++, rr = next_region++;
-                    for (u32 t = 0; t < nleft; t++)
-                        region[vs[t]] = rl;
-                    for (u32 t = nleft; t < m; t++)
-                        region[vs[t]] = rr;
-                    stack.push_back({r.lo, r.lo + nleft, rl});
-                    stack.push_back({r.lo + nleft, r.hi, rr});
-                    continue;
-                }
-                if (nl < 3)
-                {
-                    continue; // clique-like: nothing to gain
-                }
-                // choose the level where the cumulative count crosses half
-                std::vector<u32> lcount(nl, 0);
-                for (u32 v : queue)
-                    lcount[level[v]]++;
-                u32 acc = 0, cutl = 1;
-                for (u32 l = 0; l < nl; l++)
-                {
-                    acc += lcount[l];
-                    if (acc * 2 >= m)
-                    {
-                        cutl = l;
-                        break;
-                    }
-                }
-                cutl = std::min(std::max(cutl, 1u), nl - 2);
-                for (u32 v : queue)
-                    side[v] = level[v] < cutl ? 0 : 1;
-            }
-            // vertex separator = boundary of the left side or of the right side, whichever is smaller
-            u32 bl = 0, br = 0;
-            for (u32 t = 0; t < m; t++)
-            {
-                u32 v = vs[t];
-                bool touches = false;
-                for (u64 p = G.ptr[v]; p < G.ptr[v + 1] && !touches; p++)
-                {
-                    u32 w = G.adj[p];
-                    touches = (region[w] == r.rid) && ((side[w] & 1u) != (side[v] & 1u));
-                }
-                if (touches)
-                {
-                    if (side[v] == 0)
-                    {
-                        bl++;
-                        side[v] = 4; // left boundary (bit0 = 0)
-                    }
-                    else
-                    {
-                        br++;
-                        side[v] = 5; // right boundary (bit0 = 1)
-                    }
-                }
-            }
-            u32 sepmark = (bl <= br) ? 4u : 5u;
-            u32 nleft = 0, nright = 0, nsep = 0;
-            for (u32 t = 0; t < m; t++)
-            {
-                u32 s = side[vs[t]];
-                if (s == sepmark)
-                    nsep++;
-                else if ((s & 1u) == 0)
-                    nleft++;
-                else
-                    nright++;
-            }
-            if (nsep == 0 || nleft == 0 || nright == 0)
-            {
-                // no proper 3-way split (e.g. the boundary swallowed a side): leave as a leaf
-                for (u32 t = 0; t < m; t++)
-                    side[vs[t]] = 0;
-                continue;
-            }
-            tmp.resize(m);
-            u32 a = 0, b = nleft, c = nleft + nright;
-            for (u32 t = 0; t < m; t++)
-            {
-                u32 v = vs[t], s = side[v];
-                if (s == sepmark)
-                    tmp[c++] = v;
-                else if ((s & 1u) == 0)
-                    tmp[a++] = v;
-                else
-                    tmp[b++] = v;
-            }
-            std::copy(tmp.begin(), tmp.end(), vs);
-            u32 rl = next_region++, rr = next_region++, rs = next_region++;
-            for (u32 t = 0; t < nleft; t++)
-                region[vs[t]] = rl;
-            for (u32 t = nleft; t < nleft + nright; t++)
-                region[vs[t]] = rr;
-            for (u32 t = nleft + nright; t < m; t++)
-                region[vs[t]] = rs; // separators are final: never split again
-            stack.push_back({r.lo, r.lo + nleft, rl});
-            stack.push_back({r.lo + nleft, r.lo + nleft + nright, rr});
+            emit(vs);
+            return;
         }
+        bool have_sides = false;
+        if (xyz && dim > 0)
+        {
+            // geometric: cut the widest axis at the median coordinate
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (u32 v : vs)
+                for (int d = 0; d < dim; d++)
+                {
+                    double c = xyz[(size_t)v * dim + d];
+                    lo[d] = std::min(lo[d], c);
+                    hi[d] = std::max(hi[d], c);
+                }
+            int ax = 0;
+            for (int d = 1; d < dim; d++)
+                if (hi[d] - lo[d] > hi[ax] - lo[ax])
+                    ax = d;
+            if (hi[ax] > lo[ax])
+            {
+                std::vector<u32> tmp(vs);
+                std::nth_element(tmp.begin(), tmp.begin() + m / 2, tmp.end(), [&](u32 a, u32 b)
+                                 { return xyz[(size_t)a * dim + ax] < xyz[(size_t)b * dim + ax]; });
+                double cut = xyz[(size_t)tmp[m / 2] * dim + ax];
+                if (cut <= lo[ax])
+                    cut = std::nextafter(lo[ax], hi[ax]); // many ties at the low end: cut just above them
+                for (u32 v : vs)
+                    side[v] = xyz[(size_t)v * dim + ax] < cut ? 0 : 1;
+                have_sides = true;
+            }
+        }
+        if (!have_sides)
+        {
+            // graph: level structure rooted at a pseudo-peripheral vertex
+            u32 nl = bfs(vs[0], rid);
+            for (int it = 0; it < 2; it++)
+            {
+                u32 nl2 = bfs(queue.back(), rid);
+                bool better = nl2 > nl;
+                nl = nl2;
+                if (!better)
+                    break;
+            }
+            if ((u32)queue.size() < m)
+            {
+                // disconnected region: the component just found and the rest are independent, no separator
+                std::vector<u32> comp(queue), rest;
+                rest.reserve(m - comp.size());
+                u32 rc = next_region++, rr = next_region++;
+                relabel(comp, rc);
+                for (u32 v : vs)
+                    if (region[v] == rid)
+                        rest.push_back(v);
+                relabel(rest, rr);
+                std::vector<u32>().swap(vs);
+                order(comp, rc);
+                maybe_align(comp.size(), rest.size());
+                order(rest, rr);
+                return;
+            }
+            if (nl < 3)
+            {
+                emit(vs); // clique-like: nothing to gain
+                return;
+            }
+            std::vector<u32> lcount(nl, 0);
+            for (u32 v : queue)
+                lcount[level[v]]++;
+            u32 acc = 0, cutl = 1;
+            for (u32 l = 0; l < nl; l++)
+            {
+                acc += lcount[l];
+                if (acc * 2 >= m)
+                {
+                    cutl = l;
+                    break;
+                }
+            }
+            cutl = std::min(std::max(cutl, 1u), nl - 2);
+            for (u32 v : vs)
+                side[v] = level[v] < cutl ? 0 : 1;
+        }
+        // vertex separator = boundary of the left side or of the right side, whichever is smaller
+        u32 bl = 0, br = 0;
+        for (u32 v : vs)
+        {
+            bool touches = false;
+            for (u64 p = G.ptr[v]; p < G.ptr[v + 1] && !touches; p++)
+            {
+                u32 w = G.adj[p];
+                touches = (region[w] == rid) && ((side[w] & 1u) != (side[v] & 1u));
+            }
+            if (touches)
+            {
+                if ((side[v] & 1u) == 0)
+                {
+                    bl++;
+                    side[v] = 4; // left boundary (bit 0 clear)
+                }
+                else
+                {
+                    br++;
+                    side[v] = 5; // right boundary (bit 0 set)
+                }
+            }
+        }
+        const u32 sepmark = (bl <= br) ? 4u : 5u;
+        std::vector<u32> L, R, S;
+        for (u32 v : vs)
+        {
+            u32 s = side[v];
+            if (s == sepmark)
+                S.push_back(v);
+            else if ((s & 1u) == 0)
+                L.push_back(v);
+            else
+                R.push_back(v);
+        }
+        if (S.empty() || L.empty() || R.empty())
+        {
+            emit(vs); // no proper 3-way split (e.g. the boundary swallowed a side)
+            return;
+        }
+        std::vector<u32>().swap(vs);
+        u32 rl = next_region++, rr = next_region++, rs = next_region++;
+        relabel(L, rl);
+        relabel(R, rr);
+        relabel(S, rs); // separators are final
+        size_t nl_ = L.size(), nr_ = R.size();
+        order(L, rl);
+        maybe_align(nl_, nr_);
+        order(R, rr);
+        emit(S);
+    }
+
+    void maybe_align(size_t left, size_t right)
+    {
+        if (align == 0 || left < align_min || right < align_min)
+            return;
+        while (out.size() % align)
+            out.push_back(kNoVertex);
     }
 };
 
 } // namespace
 
-void order_nested_dissection(const CscMatrix &A, const double *coords, int dim, std::vector<u32> &perm)
+void order_nested_dissection(const CscMatrix &A, const double *coords, int dim, u32 align, std::vector<u32> &perm)
 {
     Graph G;
     build_graph(A, G);
-    perm.resize(A.n);
     const char *leaf_env = getenv("PANGULU_AMD_ND_LEAF");
     u32 leaf = leaf_env ? (u32)atoi(leaf_env) : 96u;
     if (leaf < 4)
         leaf = 4;
-    Dissector D(G, coords, dim, leaf, perm);
-    D.run();
+    const char *amin_env = getenv("PANGULU_AMD_ND_ALIGN_MIN_BLOCKS");
+    u32 align_min = align * (amin_env ? (u32)atoi(amin_env) : 8u);
+    Dissector D(G, coords, dim, leaf, align, align_min);
+    std::vector<u32> all(A.n);
+    std::iota(all.begin(), all.end(), 0u);
+    D.order(all, 0);
+    // padding positions become fresh vertex ids n, n+1, ... (isolated identity rows added by the caller)
+    perm = std::move(D.out);
+    u32 next = A.n;
+    for (u32 &v : perm)
+        if (v == kNoVertex)
+            v = next++;
 }
 
 void permute_symmetric(const CscMatrix &A, const std::vector<u32> &perm, CscMatrix &B)

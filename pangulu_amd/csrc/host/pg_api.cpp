@@ -288,12 +288,10 @@ extern "C"
         comm->bcast(A.colptr.data(), sizeof(u64) * A.colptr.size(), 0);
         comm->bcast(A.rowidx.data(), sizeof(u32) * A.rowidx.size(), 0);
         comm->bcast(A.value.data(), sizeof(val_t) * A.value.size(), 0);
-        S->n = A.n;
-        S->nbk = (A.n + S->nb - 1) / S->nb;
+        S->n_user = A.n;
         S->info.n = A.n;
         S->info.nnz = A.nnz();
         S->info.nb = S->nb;
-        S->info.block_length = S->nbk;
 
         Options &opt = pending_options();
         S->eager_host_mirror = opt.eager_host_mirror;
@@ -309,19 +307,48 @@ extern "C"
             else if (opt.ordering == PANGULU_AMD_ORDER_ND)
             {
                 const double *xyz = (opt.coord_dim > 0 && opt.coords.size() == (size_t)A.n * opt.coord_dim) ? opt.coords.data() : nullptr;
-                order_nested_dissection(A, xyz, opt.coord_dim, S->perm);
+                const char *al = getenv("PANGULU_AMD_ND_ALIGN");
+                u32 align = (al && atoi(al) == 0) ? 0u : S->nb; // subtrees start on block boundaries (pg_analysis.cpp)
+                order_nested_dissection(A, xyz, opt.coord_dim, align, S->perm);
             }
             else
             {
                 order_identity(A.n, S->perm);
             }
         }
-        S->perm.resize(A.n);
-        comm->bcast(S->perm.data(), sizeof(u32) * A.n, 0);
+        // an aligned dissection is longer than the matrix: positions whose "old" index is >= n_user are padding,
+        // realised as isolated rows/columns with a unit diagonal (x = b = 1 there, no coupling, no flops)
+        u64 np = S->perm.size();
+        comm->bcast(&np, sizeof(np), 0);
+        S->perm.resize(np);
+        comm->bcast(S->perm.data(), sizeof(u32) * np, 0);
         opt.coords.clear();
         opt.coord_dim = 0;
-        S->iperm.resize(A.n);
-        for (u32 i = 0; i < A.n; i++)
+        S->n = (u32)np;
+        S->nbk = (S->n + S->nb - 1) / S->nb;
+        S->info.n_padded = S->n;
+        S->info.block_length = S->nbk;
+        if (S->n > A.n)
+        {
+            u32 extra = S->n - A.n;
+            u64 base = A.nnz();
+            A.colptr.resize((size_t)S->n + 1);
+            A.rowidx.resize(base + extra);
+            A.value.resize(base + extra);
+            for (u32 d = 0; d < extra; d++)
+            {
+                A.rowidx[base + d] = A.n + d;
+#ifdef PANGULU_COMPLEX
+                A.value[base + d] = val_t{1, 0};
+#else
+                A.value[base + d] = 1;
+#endif
+                A.colptr[(size_t)A.n + d + 1] = base + d + 1;
+            }
+            A.n = S->n;
+        }
+        S->iperm.resize(S->n);
+        for (u32 i = 0; i < S->n; i++)
             S->iperm[S->perm[i]] = i;
         permute_symmetric(A, S->perm, S->Aperm);
         A = CscMatrix();
@@ -371,7 +398,12 @@ extern "C"
         if (comm->rank == 0)
         {
             for (u32 i = 0; i < S->n; i++)
-                b[i] = rhs[S->perm[i]];
+            {
+                if (S->perm[i] < S->n_user)
+                    b[i] = rhs[S->perm[i]];
+                else
+                    memset(&b[i], 0, sizeof(val_t)); // padding row: 1 * x = 0
+            }
         }
         comm->bcast(b.data(), sizeof(val_t) * S->n, 0);
         comm->barrier();
@@ -381,7 +413,8 @@ extern "C"
         if (comm->rank == 0)
         {
             for (u32 i = 0; i < S->n; i++)
-                rhs[S->perm[i]] = b[i];
+                if (S->perm[i] < S->n_user)
+                    rhs[S->perm[i]] = b[i];
         }
     }
 

@@ -86,7 +86,9 @@ struct CscMatrix
 
 // perm[new] = old
 void order_identity(u32 n, std::vector<u32> &perm);
-void order_nested_dissection(const CscMatrix &A, const double *coords, int dim, std::vector<u32> &perm);
+// `align` > 0: pad so that large subtrees start on multiples of `align`; perm may then be longer than A.n, entries >= A.n
+// are padding positions (isolated identity rows)
+void order_nested_dissection(const CscMatrix &A, const double *coords, int dim, u32 align, std::vector<u32> &perm);
 // B = P A P^T with sorted columns
 void permute_symmetric(const CscMatrix &A, const std::vector<u32> &perm, CscMatrix &B);
 
@@ -234,7 +236,8 @@ struct TaskModel // SURVEY.md §8d algorithmic bytes / flops of the rank's tasks
 struct Solver
 {
     // configuration
-    u32 n = 0, nb = 0, nbk = 0;
+    u32 n = 0, nb = 0, nbk = 0; // n includes the padding rows of an aligned ordering
+    u32 n_user = 0;             // order of the matrix the user passed
     int rank = 0, nproc = 1, p = 1, q = 1;
     float recv_buffer_level = 0.5f;
     bool eager_host_mirror = false;

@@ -491,6 +491,258 @@ __global__ __launch_bounds__(GETRF_THREADS) void getrf_kernel(const GetrfTaskD *
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// GETRF, blocked (R64, nb a multiple of 16 up to 256).  The kernel above pays two L2 round trips per pivot
+// (~1.5 us x nb): it is latency-bound whatever the fill.  This one keeps the active 16-column panel and the matching
+// 16-row strip of U in LDS, eliminates inside them (LDS latency only), and applies the panel's rank-16 update to the
+// trailing block on the f64 matrix cores straight from those LDS images:
+//   for each panel j0:  P = D[j0:, j0:j0+16] (LDS, column-major)   S = D[j0:j0+16, j0+16:] (LDS, row-major)
+//       16 pivots: scale L(:,k); rank-1 update of the rest of P and of S          (wavefront per column / row)
+//       write P and S back;  D[j0+16:, j0+16:] -= P_lower * S                      (v_mfma_f64_16x16x4_f64)
+// The dense image is zero outside the pattern; structural zeros make exact no-ops, so the factors equal the sparse
+// algorithm's on the pattern.  Every entry still receives its updates in ascending pivot order.
+// The trailing product is formed transposed (A operand = -S^T, B operand = P^T) so that each accumulator register
+// maps to 16 consecutive rows of one column of D: loads and stores of the trailing block are 128-byte segments.
+// -----------------------------------------------------------------------------------------------------------------
+#if defined(CALCULATE_TYPE_R64)
+#define GETRF_PANEL 16
+#define GETRF_BLOCKED_THREADS 1024
+#define GETRF_BLOCKED_ROWS 256 // one row thread per row: nb <= 256
+
+// index i with ptr[i] <= p < ptr[i+1] (ptr ascending, ptr[0] = 0, p < ptr[n])
+__device__ inline int owner_of(const u32 *ptr, int n, u32 p)
+{
+    int lo = 0, hi = n; // invariant: ptr[lo] <= p < ptr[hi]
+    while (hi - lo > 1)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+#define GETRF_STAMP(slot)                                                  \
+    if (dbg && tid == 0 && blockIdx.x == 0)                                \
+    {                                                                      \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+        dbg[slot] += now_ - stamp_;                                        \
+        stamp_ = now_;                                                     \
+    }
+
+__global__ __launch_bounds__(GETRF_BLOCKED_THREADS) void getrf_blocked_f64_kernel(const GetrfTaskD *__restrict__ tasks, int nb,
+                                                                                  unsigned long long *flop_counter,
+                                                                                  unsigned long long *dbg)
+{
+    unsigned long long stamp_ = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int ldp = nb + 2; // leading dimensions padded by one 16-byte slot: MFMA operand reads stay conflict-free
+    double *P = reinterpret_cast<double *>(smem_raw); // P[c * ldp + r]: column c (0..15) of the panel, row r (absolute)
+    double *S = P + GETRF_PANEL * ldp;                // S[k * ldp + c]: row k (0..15) of the strip, column c (absolute)
+    double *Rb = S + GETRF_PANEL * ldp;               // Rb[kk * 16 + c]: pivot row kk of the panel, published per step
+    u32 *sLcp = reinterpret_cast<u32 *>(Rb + GETRF_PANEL * GETRF_PANEL); // column pointer of the lower half (nb + 1 entries)
+    u32 *sUrp = sLcp + nb + 1;                                           // row pointer of the upper half
+    const GetrfTaskD T = tasks[blockIdx.x];
+    double *__restrict__ D = T.dense;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwaves = GETRF_BLOCKED_THREADS / 64;
+
+    // dense image: zero, then scatter both halves
+    for (int i = tid; i < nb * nb / 2; i += GETRF_BLOCKED_THREADS)
+        reinterpret_cast<double2 *>(D)[i] = make_double2(0.0, 0.0);
+    for (int i = tid; i <= nb; i += GETRF_BLOCKED_THREADS)
+    {
+        sLcp[i] = T.lcp[i];
+        sUrp[i] = T.urp[i];
+    }
+    __syncthreads();
+    // scatter / gather run flat over the nonzeros (coalesced, many loads in flight); the owning column (row) of a
+    // position comes from a binary search in the LDS copy of the pointer array
+    const u32 nnzL = sLcp[nb], nnzU = sUrp[nb];
+    unsigned long long ops = 0;
+    for (u32 p = tid; p < nnzL; p += GETRF_BLOCKED_THREADS)
+        D[(size_t)owner_of(sLcp, nb, p) * nb + T.lri[p]] = T.lval[p];
+    for (u32 p = tid; p < nnzU; p += GETRF_BLOCKED_THREADS)
+        D[(size_t)T.uci[p] * nb + owner_of(sUrp, nb, p)] = T.uval[p];
+    for (int c = tid; c < nb; c += GETRF_BLOCKED_THREADS)
+    {
+        // structural flop count of the sparse algorithm (what the reference counts, src/pangulu_kernel_interface.c:4-82)
+        const u32 nl = sLcp[c + 1] - sLcp[c], nu = sUrp[c + 1] - sUrp[c];
+        if (nu > 0)
+            ops += (unsigned long long)nl * (1ull + 2ull * (nu - 1));
+    }
+    __syncthreads();
+    GETRF_STAMP(0)
+
+    for (int j0 = 0; j0 < nb; j0 += GETRF_PANEL)
+    {
+        const int jt = j0 + GETRF_PANEL; // first trailing row/column
+        // ---- panel: thread t < nb - j0 owns row j0 + t of the 16 panel columns in registers ---------------------
+        // Per pivot the owner of the pivot row publishes it through LDS (one barrier), every row below scales its
+        // own L entry and updates its own 15 registers: no LDS traffic besides the 16-value broadcast.
+        const int myrow = j0 + tid;
+        const bool row_thread = tid < GETRF_BLOCKED_ROWS && myrow < nb;
+        double x[GETRF_PANEL];
+        if (row_thread)
+        {
+#pragma unroll
+            for (int c = 0; c < GETRF_PANEL; c++)
+                x[c] = D[(size_t)(j0 + c) * nb + myrow];
+        }
+        GETRF_STAMP(1)
+#pragma unroll
+        for (int kk = 0; kk < GETRF_PANEL; kk++)
+        {
+            if (tid == kk)
+            {
+#pragma unroll
+                for (int c = 0; c < GETRF_PANEL; c++)
+                    Rb[kk * GETRF_PANEL + c] = x[c];
+            }
+            __syncthreads();
+            const int k = j0 + kk;
+            if (sLcp[k] != sLcp[k + 1] && row_thread && myrow > k && x[kk] != 0.0)
+            {
+                const double l = x[kk] / clamp_pivot(Rb[kk * GETRF_PANEL + kk]);
+                x[kk] = l;
+#pragma unroll
+                for (int c = 0; c < GETRF_PANEL; c++)
+                    if (c > kk)
+                        x[c] = x[c] - l * Rb[kk * GETRF_PANEL + c];
+            }
+        }
+        GETRF_STAMP(2)
+        if (row_thread)
+        {
+#pragma unroll
+            for (int c = 0; c < GETRF_PANEL; c++)
+            {
+                D[(size_t)(j0 + c) * nb + myrow] = x[c];
+                P[c * ldp + myrow] = x[c];
+            }
+        }
+        __syncthreads();
+        GETRF_STAMP(3)
+        // ---- strip: thread t < nb - jt owns column jt + t of the 16 strip rows; forward substitution with the unit
+        // lower 16 x 16 tile L11 read (broadcast) from the panel image ------------------------------------------------
+        if (tid < nb - jt)
+        {
+            const int c = jt + tid;
+            double s[GETRF_PANEL];
+            const double2 *src = reinterpret_cast<const double2 *>(D + (size_t)c * nb + j0);
+#pragma unroll
+            for (int q = 0; q < GETRF_PANEL / 2; q++)
+            {
+                const double2 v = src[q];
+                s[2 * q] = v.x;
+                s[2 * q + 1] = v.y;
+            }
+#pragma unroll
+            for (int kk = 0; kk < GETRF_PANEL; kk++)
+            {
+                if (s[kk] != 0.0)
+                {
+#pragma unroll
+                    for (int rr = 0; rr < GETRF_PANEL; rr++)
+                        if (rr > kk)
+                            s[rr] = s[rr] - P[kk * ldp + j0 + rr] * s[kk];
+                }
+            }
+            double2 *dst = reinterpret_cast<double2 *>(D + (size_t)c * nb + j0);
+#pragma unroll
+            for (int q = 0; q < GETRF_PANEL / 2; q++)
+                dst[q] = make_double2(s[2 * q], s[2 * q + 1]);
+#pragma unroll
+            for (int kk = 0; kk < GETRF_PANEL; kk++)
+                S[kk * ldp + c] = s[kk];
+        }
+        __syncthreads();
+        GETRF_STAMP(4)
+        // ---- trailing update on the matrix cores ---------------------------------------------------------------
+        const int mt = (nb - jt) / 16; // trailing tiles per dimension
+        const int l15 = lane & 15, l4 = lane >> 4;
+        // a wavefront takes 32 x 32 macro tiles (2 x 2 MFMA tiles sharing their operands): 16 accumulator loads in
+        // flight per pass instead of 4, half the LDS operand reads per flop
+        const int mm = (mt + 1) / 2;
+        for (int mtile = wave; mtile < mm * mm; mtile += nwaves)
+        {
+            const int ri = (mtile % mm) * 2, ci = (mtile / mm) * 2;
+            const int r0 = jt + ri * 16, c0 = jt + ci * 16;
+            const bool hr = ri + 1 < mt, hc = ci + 1 < mt; // second row / column of tiles exists
+            const int r1 = hr ? r0 + 16 : r0, c1 = hc ? c0 + 16 : c0;
+            // operands: A[i = l15][k = l4] = -U(k, c+i);  B[k = l4][j = l15] = L(r+j, k)
+            double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                a0[q] = -S[(q * 4 + l4) * ldp + c0 + l15];
+                a1[q] = -S[(q * 4 + l4) * ldp + c1 + l15];
+                b0[q] = P[(q * 4 + l4) * ldp + r0 + l15];
+                b1[q] = P[(q * 4 + l4) * ldp + r1 + l15];
+            }
+            const bool za0 = !__any((a0[0] != 0.0) | (a0[1] != 0.0) | (a0[2] != 0.0) | (a0[3] != 0.0));
+            const bool za1 = !hc || !__any((a1[0] != 0.0) | (a1[1] != 0.0) | (a1[2] != 0.0) | (a1[3] != 0.0));
+            const bool zb0 = !__any((b0[0] != 0.0) | (b0[1] != 0.0) | (b0[2] != 0.0) | (b0[3] != 0.0));
+            const bool zb1 = !hr || !__any((b1[0] != 0.0) | (b1[1] != 0.0) | (b1[2] != 0.0) | (b1[3] != 0.0));
+            // tile (x, y) = rows r_x, columns c_y; skipped when its L rows or U columns are all zero (uniform)
+            const bool d00 = !(zb0 || za0), d10 = !(zb1 || za0), d01 = !(zb0 || za1), d11 = !(zb1 || za1);
+            v4f64 t00 = {0.0, 0.0, 0.0, 0.0}, t10 = t00, t01 = t00, t11 = t00;
+            // accumulator register g of lane l is D(r + l15, c + l4 + 4g)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                if (d00)
+                    t00[g] = D[(size_t)(c0 + l4 + 4 * g) * nb + r0 + l15];
+                if (d10)
+                    t10[g] = D[(size_t)(c0 + l4 + 4 * g) * nb + r1 + l15];
+                if (d01)
+                    t01[g] = D[(size_t)(c1 + l4 + 4 * g) * nb + r0 + l15];
+                if (d11)
+                    t11[g] = D[(size_t)(c1 + l4 + 4 * g) * nb + r1 + l15];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                if (d00)
+                    t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], t00, 0, 0, 0);
+                if (d10)
+                    t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b1[q], t10, 0, 0, 0);
+                if (d01)
+                    t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b0[q], t01, 0, 0, 0);
+                if (d11)
+                    t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], t11, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                if (d00)
+                    D[(size_t)(c0 + l4 + 4 * g) * nb + r0 + l15] = t00[g];
+                if (d10)
+                    D[(size_t)(c0 + l4 + 4 * g) * nb + r1 + l15] = t10[g];
+                if (d01)
+                    D[(size_t)(c1 + l4 + 4 * g) * nb + r0 + l15] = t01[g];
+                if (d11)
+                    D[(size_t)(c1 + l4 + 4 * g) * nb + r1 + l15] = t11[g];
+            }
+        }
+        __syncthreads();
+        GETRF_STAMP(5)
+    }
+
+    for (u32 p = tid; p < nnzL; p += GETRF_BLOCKED_THREADS)
+        T.lval[p] = D[(size_t)owner_of(sLcp, nb, p) * nb + T.lri[p]];
+    for (u32 p = tid; p < nnzU; p += GETRF_BLOCKED_THREADS)
+        T.uval[p] = D[(size_t)T.uci[p] * nb + owner_of(sUrp, nb, p)];
+    __syncthreads();
+    GETRF_STAMP(6)
+    ops = wave_sum(ops);
+    if (lane == 0 && ops)
+        atomicAdd(flop_counter, ops);
+}
+#endif
+
+// -----------------------------------------------------------------------------------------------------------------
 // solve-side kernels (device pointers x, y), semantics of ...0100000.c:435-506
 // -----------------------------------------------------------------------------------------------------------------
 __global__ void spmv_kernel(int nb, const u32 *cp, const u16 *ri, const val_t *val, const val_t *x, val_t *y)
@@ -624,6 +876,7 @@ struct Backend
     long long opt_dense_permille = 1000;
     long long opt_profile = 0;
     long long opt_assume_independent = 0;
+    long long opt_getrf_strict = 0;
     // resources
     Ring ring;
     unsigned long long *d_flops = nullptr; // [6]
@@ -661,8 +914,8 @@ void ensure_ready()
         HIP_CHECK(hipEventCreateWithFlags(&B.ring.ev[i], hipEventDisableTiming));
         B.ring.used[i] = false;
     }
-    HIP_CHECK(hipMalloc((void **)&B.d_flops, sizeof(unsigned long long) * 8));
-    HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(unsigned long long) * 8));
+    HIP_CHECK(hipMalloc((void **)&B.d_flops, sizeof(unsigned long long) * 16)); // [0..7] flop counters, [8..15] debug stamps
+    HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(unsigned long long) * 16));
     memset(&B.stats, 0, sizeof(B.stats));
     B.ready = true;
 }
@@ -1091,8 +1344,28 @@ void launch_getrf(int nb, task_t **list, size_t n)
         commit_segment(seg);
         {
             LaunchTimer lt(1);
-            size_t lds = (sizeof(val_t) * 2 + sizeof(u16) * 2) * (size_t)nb;
-            hipLaunchKernelGGL(getrf_kernel, dim3((unsigned)take), dim3(GETRF_THREADS), lds, B.stream, d_tasks, nb, B.d_flops + 1);
+            bool blocked = false;
+#if defined(CALCULATE_TYPE_R64)
+            blocked = !B.opt_getrf_strict && (nb % 16 == 0) && nb <= GETRF_BLOCKED_ROWS;
+            if (blocked)
+            {
+                size_t lds = sizeof(double) * (2 * GETRF_PANEL * (size_t)(nb + 2) + GETRF_PANEL * GETRF_PANEL) + sizeof(u32) * 2 * (size_t)(nb + 1);
+                static size_t lds_allowed = 0;
+                if (lds > lds_allowed)
+                {
+                    HIP_CHECK(hipFuncSetAttribute((const void *)getrf_blocked_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    lds_allowed = lds;
+                }
+                static const bool debug_stamps = getenv("PANGULU_HIP_DEBUG_GETRF") != nullptr;
+                hipLaunchKernelGGL(getrf_blocked_f64_kernel, dim3((unsigned)take), dim3(GETRF_BLOCKED_THREADS), lds, B.stream, d_tasks, nb,
+                                   B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
+            }
+#endif
+            if (!blocked)
+            {
+                size_t lds = (sizeof(val_t) * 2 + sizeof(u16) * 2) * (size_t)nb;
+                hipLaunchKernelGGL(getrf_kernel, dim3((unsigned)take), dim3(GETRF_THREADS), lds, B.stream, d_tasks, nb, B.d_flops + 1);
+            }
             HIP_CHECK(hipGetLastError());
         }
         B.stats.launches[1]++;
@@ -1416,6 +1689,9 @@ extern "C"
         case PANGULU_HIP_OPT_ASSUME_INDEPENDENT:
             B.opt_assume_independent = value;
             return 0;
+        case PANGULU_HIP_OPT_GETRF_STRICT_ORDER:
+            B.opt_getrf_strict = value;
+            return 0;
         default:
             return 1;
         }
@@ -1433,8 +1709,11 @@ extern "C"
         std::lock_guard<std::mutex> g(B.mutex);
         HIP_CHECK(hipStreamSynchronize(B.stream));
         harvest_events();
-        unsigned long long f[8];
+        unsigned long long f[16];
         HIP_CHECK(hipMemcpy(f, B.d_flops, sizeof(f), hipMemcpyDeviceToHost));
+        if (getenv("PANGULU_HIP_DEBUG_GETRF"))
+            fprintf(stderr, "[getrf stamps, block 0, 100 MHz ticks] scatter %llu | panel-load %llu | pivots %llu | panel-store %llu | strip %llu | gemm %llu | gather %llu\n",
+                    f[8], f[9], f[10], f[11], f[12], f[13], f[14]);
         for (int c = 1; c <= 4; c++)
             B.stats.flops[c] = (double)f[c];
         if (out)

@@ -139,15 +139,16 @@ def owned_blocks(h):
 
 def permutation(h):
     p = h.lib.pangulu_amd_get_perm(h.ref)
-    return np.ctypeslib.as_array(p, shape=(h.n,)).copy()
+    return np.ctypeslib.as_array(p, shape=(int(h.info()["n_padded"]),)).copy()
 
 
 def factors_as_scipy(h):
-    """Assemble L (unit lower) and U from this rank's blocks as scipy CSC matrices in the PERMUTED ordering."""
+    """Assemble L (unit lower) and U from this rank's blocks as scipy CSC matrices in the PERMUTED ordering
+    (order n_padded: a block-aligned dissection adds isolated unit rows, see pangulu_amd_ext.h)."""
     import scipy.sparse as sp
 
     info = h.info()
-    nb, n = int(info["nb"]), int(info["n"])
+    nb, n = int(info["nb"]), int(info["n_padded"])
     npad = int(info["block_length"]) * nb
     rows_l, cols_l, vals_l, rows_u, cols_u, vals_u = [], [], [], [], [], []
     for brow, bcol, up, cp, ri, va in owned_blocks(h):

@@ -26,7 +26,8 @@ def select_platform(lib, platform):
         assert rc == 0, "cannot load %s" % platform
 
 
-def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_factors=True, user_perm=None, nthread=4):
+def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_factors=True, user_perm=None, nthread=4,
+              hip_options=None):
     """Runs pangulu_init + gstrf (+ gstrs with b = A*1) and returns info, factors (scipy CSC, permuted ordering),
     the permutation, x and ||Ax-b||/||b||."""
     n, cp, ri, va, coords = mat
@@ -34,6 +35,9 @@ def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_fa
     select_platform(lib, platform)
     if platform == "hip":
         pa.hip_stats(lib, reset=True)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_GETRF_STRICT_ORDER, 0)
+        for opt, val in (hip_options or {}).items():
+            assert lib.pangulu_platform_0201001_set_option(opt, val) == 0
     if ordering is None:
         ordering = "nd"
     h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering,
@@ -57,14 +61,24 @@ def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_fa
 
 def lu_check(mat, res):
     """The reference's factor check (src/pangulu_numeric.c:1082-1341): ||L(U 1) - A' 1|| / ||A' 1|| in the permuted ordering."""
-    n, cp, ri, va, _ = mat
-    A = M.to_scipy(n, cp, ri, va).tocsr()
-    p = res["perm"].astype(np.int64)
-    Ap = A[p][:, p]
-    ones = np.ones(n, dtype=va.dtype)
+    Ap = permuted_matrix(mat, res["perm"])
+    ones = np.ones(Ap.shape[0], dtype=mat[3].dtype)
     lhs = res["L"] @ (res["U"] @ ones)
     rhs = Ap @ ones
     return float(np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs))
+
+
+def permuted_matrix(mat, perm):
+    """P [A 0; 0 I] P^T for the (possibly padded) permutation the solver used."""
+    import scipy.sparse as sp
+
+    n, cp, ri, va, _ = mat
+    A = M.to_scipy(n, cp, ri, va)
+    npad = len(perm)
+    if npad > n:
+        A = sp.block_diag([A, sp.identity(npad - n, dtype=va.dtype)], format="csr")
+    p = perm.astype(np.int64)
+    return A.tocsr()[p][:, p]
 
 
 def max_rel_diff(a, b):

@@ -54,7 +54,7 @@ def main():
         Us = sum(p[1] for p in parts)
         import scipy.sparse as sp
 
-        Ls = Ls - (world - 1) * sp.identity(n, format="csc", dtype=dtype)  # every rank added the unit diagonal
+        Ls = Ls - (world - 1) * sp.identity(Ls.shape[0], format="csc", dtype=dtype)  # every rank added the unit diagonal
         res = M.relative_residual(n, cp, ri, va, x, b)
         np.savez(out_path, L_data=Ls.tocsc().data, L_ind=Ls.tocsc().indices, L_ptr=Ls.tocsc().indptr,
                  U_data=Us.tocsc().data, U_ind=Us.tocsc().indices, U_ptr=Us.tocsc().indptr, residual=res,

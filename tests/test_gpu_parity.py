@@ -85,8 +85,12 @@ def test_sparse_path_is_bit_exact_against_fma_oracle(name, gen, nb, ordering):
     # multiply-add.  The FMA build of the oracle restates exactly that order (oracle/pangulu_oracle.c,
     # PG_ORACLE_FMA), the scheduler is deterministic on one rank, so the whole factorisation must agree bit for
     # bit as long as no block is full enough for the MFMA kernel (nb is not a multiple of 128 here).
+    from pangulu_amd import _lib
+
     mat = gen()
-    gpu = factorize(mat, nb, "hip", ordering=ordering)
+    # strict-order GETRF: the LDS-blocked MFMA variant also applies updates in ascending pivot order, but sums four
+    # pivots per matrix-core instruction, whose internal rounding is not specified
+    gpu = factorize(mat, nb, "hip", ordering=ordering, hip_options={_lib.HIP_OPT_GETRF_STRICT_ORDER: 1})
     ref = factorize(mat, nb, oracle_library("r64", fma=True), ordering=ordering)
     assert gpu["hip_stats"]["ssssm_dense_mfma"]["tasks"] == 0
     for f in ("L", "U"):

@@ -96,9 +96,9 @@ def test_factors_reproduce_the_matrix(name, gen, nb, ordering, vtype, dtype, tol
     """Independent ground truth: L*U must equal the permuted matrix (no pivoting, diagonally dominant input)."""
     mat = gen(dtype)
     r = factorize(mat, nb, oracle_library(vtype), vtype=vtype, ordering=ordering)
-    n, cp, ri, va, _ = mat
-    p = r["perm"].astype(np.int64)
-    Ap = M.to_scipy(n, cp, ri, va).tocsr()[p][:, p]
+    from .helpers import permuted_matrix
+
+    Ap = permuted_matrix(mat, r["perm"])
     err = abs(r["L"] @ r["U"] - Ap).max() / abs(Ap).max()
     assert err < tol, err
     assert r["residual"] < 50 * tol
