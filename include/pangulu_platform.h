@@ -199,9 +199,10 @@ extern "C"
      *   PANGULU_HIP_OPT_HOST_MIRROR (default 1): after GETRF/TSTRF/GESSM copy the block's values back into
      *     slot->value like …0201000.cu:639-640,680,714 does (the reference host's MPI send and SpTRSV read
      *     host memory).  The native host keeps factors device-resident and sets 0.
-     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 1000): SSSSM triples whose three blocks have at
-     *     least this fill (nnz*1000/nb^2) go to the f64/f32 MFMA dense kernel; 1000 = only completely full
-     *     blocks, the reference's cuBLAS-direct rule (…0201000.cu:827).
+     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 150): blocks with at least this fill
+     *     (nnz*1000/nb^2) are "dense-mode": they get a dense mirror in HBM, updates into them accumulate there,
+     *     and an update whose three blocks are all dense-mode runs on the f64 MFMA kernel.  1000 = only
+     *     completely full blocks (the reference's cuBLAS-direct rule, …0201000.cu:827); 1001 disables dense mode.
      */
 #define PANGULU_HIP_OPT_HOST_MIRROR 1
 #define PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE 2
@@ -215,6 +216,18 @@ extern "C"
     /*   PANGULU_HIP_OPT_GETRF_STRICT_ORDER (default 0): 1 selects the pattern-driven GETRF kernel for every block
      *     (the only one for value types other than R64); 0 lets R64 blocks use the LDS-blocked MFMA kernel. */
 #define PANGULU_HIP_OPT_GETRF_STRICT_ORDER 5
+    /*   PANGULU_HIP_OPT_COUNT_FLOPS (default 1): also count the structural flops of updates that run on the dense
+     *     MFMA kernel (one extra pass over op2's pattern per such task, like the reference's PERF counters
+     *     src/pangulu_kernel_interface.c:161-176); 0 skips that pass (flops[5] then stays 0).
+     *   PANGULU_HIP_OPT_RESET_BLOCK_STATE: forget all dense mirrors' contents (value ignored).  A host that restores
+     *     block values behind the back-end's back (bench.py's reset between repeated factorisations) must call it. */
+#define PANGULU_HIP_OPT_COUNT_FLOPS 6
+#define PANGULU_HIP_OPT_RESET_BLOCK_STATE 7
+    /*   PANGULU_HIP_OPT_SSSSM_GROUP_CHUNK (default 8): updates queued on one destination run as one sequential pass
+     *     per destination column (deterministic, no atomics) while there are at most this many; longer queues are
+     *     cut into chunks of this size that run concurrently and add their partial sums with floating-point
+     *     atomics (results then vary in the last bits from run to run).  0 = never split. */
+#define PANGULU_HIP_OPT_SSSSM_GROUP_CHUNK 8
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an
@@ -236,6 +249,7 @@ extern "C"
         double alg_bytes[6];
         double flops[6];
         double elapsed_ms[6];
+        double mfma_flops_executed; /* 2*nb^3 per task of class 5: what the matrix cores actually did */
     } pangulu_hip_stats_t;
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset);
 

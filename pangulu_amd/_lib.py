@@ -90,6 +90,7 @@ class HipStats(ctypes.Structure):
         ("alg_bytes", ctypes.c_double * 6),
         ("flops", ctypes.c_double * 6),
         ("elapsed_ms", ctypes.c_double * 6),
+        ("mfma_flops_executed", ctypes.c_double),
     ]
 
 
@@ -186,6 +187,9 @@ HIP_OPT_DENSE_THRESHOLD_PERMILLE = 2
 HIP_OPT_PROFILE = 3
 HIP_OPT_ASSUME_INDEPENDENT = 4
 HIP_OPT_GETRF_STRICT_ORDER = 5
+HIP_OPT_COUNT_FLOPS = 6
+HIP_OPT_RESET_BLOCK_STATE = 7
+HIP_OPT_SSSSM_GROUP_CHUNK = 8
 
 ORDER_IDENTITY, ORDER_ND, ORDER_USER = 0, 1, 2
 TRANSPORT_HOST, TRANSPORT_RCCL = 0, 1

@@ -660,6 +660,7 @@ void numeric_factorize(Solver &S)
     {
         plat.set_option(PANGULU_HIP_OPT_HOST_MIRROR, S.eager_host_mirror ? 1 : 0);
         plat.set_option(PANGULU_HIP_OPT_ASSUME_INDEPENDENT, 1); // batches of this scheduler are dependency-free
+        plat.set_option(PANGULU_HIP_OPT_RESET_BLOCK_STATE, 0);  // block values were (re)loaded behind the back-end's back
     }
     S.heap.clear();
     S.pending_total = 0;

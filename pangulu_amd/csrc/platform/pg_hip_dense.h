@@ -1,0 +1,192 @@
+// pg_hip_dense.h -- dense-mode blocks: column-major mirrors in HBM and the f64 matrix-core SSSSM kernel.
+// (included by pg_hip_platform.hip after the descriptor structs; R64 only)
+//
+// North star: "MFMA applied only on blocks whose fill makes the update effectively a dense contraction".  The
+// reference's rule is all-or-nothing (all three blocks completely full -> cuBLAS on the value arrays,
+// ...0201000.cu:827-852; diagonal destination -> densify all three per task, :754-823).  Here a block whose fill
+// reaches the dense threshold gets a persistent dense MIRROR (nb x nb doubles, zero outside its pattern) in a
+// pool sized for 288 GB of HBM:
+//   * updates INTO such a block accumulate in the mirror (MFMA kernel when both operands have mirrors, LDS kernel
+//     with a dense destination column otherwise); its sparse values are refreshed once, right before its panel
+//     operation (or it is handed to GETRF as the dense image directly);
+//   * a finished L/U block used as an operand is densified once and then serves every later update.
+// The sparse record stays the authoritative form of every finished block (exchange, solve, download).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------------------
+// C(nb x nb) -= sum_t A_t * B_t on dense mirrors.  Workgroup = 4 wavefronts = one 128 x 128 tile of C; each
+// wavefront a 64 x 64 sub-tile as 4 x 4 accumulators of v_mfma_f64_16x16x4_f64.  K runs over all tasks of the
+// group in steps of 16: the 128 x 16 slab of A and the 16 x 128 slab of B go through LDS ([k][m] / [k][n], row
+// stride 144 doubles = conflict-free b64 fragment reads), the next slab is prefetched into registers while the
+// current one feeds the matrix cores.  The product is formed transposed (A operand from the B slab, B operand from
+// the A slab) so that accumulator register g of lane l is C(m0 + (l & 15), n0 + (l >> 4) + 4 g): the final
+// read-modify-write of C moves 128-byte segments.
+// ---------------------------------------------------------------------------------------------------------------
+#define DG_TILE 128
+#define DG_K 16
+#define DG_LD 144 // padded slab row (doubles): rows of consecutive k land 32 banks apart
+
+__global__ __launch_bounds__(256) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
+                                                               const SsssmTaskD *__restrict__ tasks, int nb)
+{
+    __shared__ __align__(16) double sA[DG_K * DG_LD];
+    __shared__ __align__(16) double sB[DG_K * DG_LD];
+    const int tiles = nb / DG_TILE;
+    const int g = blockIdx.x / (tiles * tiles);
+    const int tile = blockIdx.x % (tiles * tiles);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int M0 = (tile % tiles) * DG_TILE, N0 = (tile / tiles) * DG_TILE; // workgroup tile origin
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;                   // wavefront sub-tile inside it
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const SsssmGroupD G = groups[g];
+
+    v4f64 acc[4][4]; // [ni][mi]
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+            acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    // staging maps.  A slab (128 rows x 16 k, column-major source): thread -> rows 2*(tid & 63), +1 of k = (tid >> 6) + 4 i.
+    // B slab (16 k x 128 cols): thread -> k pair 2*(tid & 7) of column (tid >> 3) + 32 i: 8 consecutive threads read one
+    // 128-byte run of a column.
+    const int a_m = 2 * (tid & 63), a_k = tid >> 6;
+    const int b_k = 2 * (tid & 7), b_n = tid >> 3;
+    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3; // next slab, in flight while the current one is consumed
+
+    const u32 ntask = G.task_end - G.task_begin;
+    const int steps_per_task = nb / DG_K;
+    const int nsteps = (int)ntask * steps_per_task;
+
+#define DG_LOAD_SLAB(step_)                                                                          \
+    {                                                                                                \
+        const SsssmTaskD &T_ = tasks[G.task_begin + (step_) / steps_per_task];                       \
+        const int k0_ = ((step_) % steps_per_task) * DG_K;                                           \
+        const double *A_ = T_.a.val + (size_t)(k0_ + a_k) * nb + M0 + a_m;                           \
+        const double *B_ = T_.b.val + (size_t)(N0 + b_n) * nb + k0_ + b_k;                           \
+        ra0 = *reinterpret_cast<const double2 *>(A_);                                                \
+        ra1 = *reinterpret_cast<const double2 *>(A_ + (size_t)4 * nb);                               \
+        ra2 = *reinterpret_cast<const double2 *>(A_ + (size_t)8 * nb);                               \
+        ra3 = *reinterpret_cast<const double2 *>(A_ + (size_t)12 * nb);                              \
+        rb0 = *reinterpret_cast<const double2 *>(B_);                                                \
+        rb1 = *reinterpret_cast<const double2 *>(B_ + (size_t)32 * nb);                              \
+        rb2 = *reinterpret_cast<const double2 *>(B_ + (size_t)64 * nb);                              \
+        rb3 = *reinterpret_cast<const double2 *>(B_ + (size_t)96 * nb);                              \
+    }
+
+    if (nsteps > 0)
+        DG_LOAD_SLAB(0)
+    for (int step = 0; step < nsteps; step++)
+    {
+        __syncthreads(); // everyone is done reading the previous slab
+        *reinterpret_cast<double2 *>(&sA[(a_k + 0) * DG_LD + a_m]) = ra0;
+        *reinterpret_cast<double2 *>(&sA[(a_k + 4) * DG_LD + a_m]) = ra1;
+        *reinterpret_cast<double2 *>(&sA[(a_k + 8) * DG_LD + a_m]) = ra2;
+        *reinterpret_cast<double2 *>(&sA[(a_k + 12) * DG_LD + a_m]) = ra3;
+        sB[b_k * DG_LD + b_n] = rb0.x;
+        sB[(b_k + 1) * DG_LD + b_n] = rb0.y;
+        sB[b_k * DG_LD + b_n + 32] = rb1.x;
+        sB[(b_k + 1) * DG_LD + b_n + 32] = rb1.y;
+        sB[b_k * DG_LD + b_n + 64] = rb2.x;
+        sB[(b_k + 1) * DG_LD + b_n + 64] = rb2.y;
+        sB[b_k * DG_LD + b_n + 96] = rb3.x;
+        sB[(b_k + 1) * DG_LD + b_n + 96] = rb3.y;
+        __syncthreads();
+        if (step + 1 < nsteps)
+            DG_LOAD_SLAB(step + 1) // in flight while the matrix cores work
+#pragma unroll
+        for (int kq = 0; kq < DG_K / 4; kq++)
+        {
+            double fa[4], fb[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                fa[mi] = sA[(kq * 4 + l4) * DG_LD + wm + mi * 16 + l15];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+                fb[ni] = sB[(kq * 4 + l4) * DG_LD + wn + ni * 16 + l15];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+#undef DG_LOAD_SLAB
+
+    double *__restrict__ C = G.cdense;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+            {
+                const size_t off = (size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15);
+                if (G.atomic)
+                {
+                    if (acc[ni][mi][r] != 0.0)
+                        atomicAdd(&C[off], -acc[ni][mi][r]);
+                }
+                else
+                    C[off] -= acc[ni][mi][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mirror maintenance.  One workgroup per block.
+// ---------------------------------------------------------------------------------------------------------------
+struct MirrorJobD
+{
+    BlkView lo;     // CSC view (off-diagonal block, or strictly-lower half of a diagonal block)
+    BlkView up;     // upper CSR half of a diagonal block (ptr == nullptr otherwise)
+    double *dense;  // nb x nb column-major
+};
+
+__global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restrict__ jobs, int nb)
+{
+    const MirrorJobD J = jobs[blockIdx.x];
+    double2 *d2 = reinterpret_cast<double2 *>(J.dense);
+    for (int i = threadIdx.x; i < nb * nb / 2; i += blockDim.x)
+        d2[i] = make_double2(0.0, 0.0);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int c = wave; c < nb; c += nw)
+    {
+        for (u32 p = ptr0(J.lo.ptr, c) + lane; p < J.lo.ptr[c + 1]; p += 64)
+            J.dense[(size_t)c * nb + J.lo.idx[p]] = J.lo.val[p];
+        if (J.up.ptr)
+            for (u32 p = J.up.ptr[c] + lane; p < J.up.ptr[c + 1]; p += 64) // c is a row of the CSR half here
+                J.dense[(size_t)J.up.idx[p] * nb + c] = J.up.val[p];
+    }
+}
+
+__global__ __launch_bounds__(256) void sparsify_kernel(const MirrorJobD *__restrict__ jobs, int nb)
+{
+    const MirrorJobD J = jobs[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int c = wave; c < nb; c += nw)
+    {
+        for (u32 p = ptr0(J.lo.ptr, c) + lane; p < J.lo.ptr[c + 1]; p += 64)
+            J.lo.val[p] = J.dense[(size_t)c * nb + J.lo.idx[p]];
+        if (J.up.ptr)
+            for (u32 p = J.up.ptr[c] + lane; p < J.up.ptr[c + 1]; p += 64)
+                J.up.val[p] = J.dense[(size_t)J.up.idx[p] * nb + c];
+    }
+}
+
+// structural flops of C -= A*B: 2 * sum over entries (k, j) of B of nnz(A(:, k))  (src/pangulu_kernel_interface.c:161-176)
+__global__ __launch_bounds__(256) void ssssm_flop_count_kernel(const SsssmTaskD *__restrict__ tasks, int nb,
+                                                               unsigned long long *flop_counter)
+{
+    const SsssmTaskD T = tasks[blockIdx.x];
+    const u32 nnzb = T.b.ptr[nb];
+    unsigned long long s = 0;
+    for (u32 p = threadIdx.x; p < nnzb; p += blockDim.x)
+    {
+        const u32 k = T.b.idx[p];
+        s += T.a.ptr[k + 1] - ptr0(T.a.ptr, (int)k);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0 && s)
+        atomicAdd(flop_counter, 2ull * s);
+}

@@ -1,0 +1,202 @@
+// pg_hip_dense_host.h -- host-side bookkeeping of dense-mode blocks (included inside the anonymous namespace of
+// pg_hip_platform.hip, after Backend / Segment / host_nnz / diag_halves).
+#pragma once
+
+#if defined(CALCULATE_TYPE_R64)
+
+struct BlockState
+{
+    double *mirror = nullptr;
+    bool mirror_current = false; // mirror holds the block's current values
+    bool sparse_current = true;  // the sparse record holds the block's current values
+    u32 brow = 0, bcol = 0, nnz = 0;
+};
+
+struct MirrorPool
+{
+    std::vector<char *> chunks;
+    size_t chunk_bytes = 0, cursor = 0, mirror_bytes = 0; // cursor counts mirrors handed out since the last reset
+    size_t limit_mirrors = 0;
+    std::unordered_map<const void *, BlockState> blocks; // key: d_value of the (lower half of the) block
+    std::vector<MirrorJobD> to_densify, to_sparsify;
+};
+MirrorPool MP;
+
+inline bool dense_mode_available(int nb)
+{
+    return (nb % DG_TILE == 0) && B.opt_dense_permille <= 1000;
+}
+
+// is the block behind `s` (a diagonal block counts both halves) filled enough for dense mode?
+inline bool is_dense_mode(slot_t *s, int nb)
+{
+    u64 nnz;
+    if (s->brow_pos == s->bcol_pos)
+    {
+        slot_t *up, *lo;
+        diag_halves(s, &up, &lo);
+        nnz = (u64)host_nnz(lo, nb) + host_nnz(up, nb);
+    }
+    else
+    {
+        nnz = host_nnz(s, nb);
+    }
+    return nnz * 1000ull >= (u64)B.opt_dense_permille * (u64)nb * (u64)nb;
+}
+
+inline const void *block_key(slot_t *s)
+{
+    if (s->brow_pos == s->bcol_pos && s->is_upper && s->related_block)
+        return (const void *)s->related_block->d_value;
+    return (const void *)s->d_value;
+}
+
+BlockState &block_state(slot_t *s, int nb)
+{
+    s = canon_dst(s); // a diagonal block is known by its lower half
+    BlockState &st = MP.blocks[block_key(s)];
+    u32 nnz = host_nnz(s, nb);
+    if (st.brow != s->brow_pos || st.bcol != s->bcol_pos || st.nnz != nnz)
+    {
+        // first sight, or a receive slot that now holds another block: forget everything but the memory
+        double *keep = st.mirror;
+        st = BlockState();
+        st.mirror = keep;
+        st.brow = s->brow_pos;
+        st.bcol = s->bcol_pos;
+        st.nnz = nnz;
+    }
+    return st;
+}
+
+// a mirror for the block, or nullptr when the pool's budget is exhausted (callers then stay on the sparse path)
+double *obtain_mirror(BlockState &st, int nb)
+{
+    if (st.mirror)
+        return st.mirror;
+    size_t mb = sizeof(double) * (size_t)nb * nb;
+    if (MP.mirror_bytes != mb)
+    {
+        // block order changed (or first use): start over
+        for (char *c : MP.chunks)
+            HIP_CHECK(hipFree(c));
+        MP.chunks.clear();
+        for (auto &kv : MP.blocks)
+            kv.second.mirror = nullptr;
+        MP.mirror_bytes = mb;
+        MP.cursor = 0;
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const char *frac_env = getenv("PANGULU_HIP_MIRROR_FRACTION");
+        double frac = frac_env ? atof(frac_env) : 0.6; // of what is free now; the rest stays for records and slots
+        MP.limit_mirrors = (size_t)(frac * (double)free_b / (double)mb);
+        MP.chunk_bytes = mb * 1024; // 512 MiB at nb = 256
+    }
+    if (MP.cursor >= MP.limit_mirrors)
+        return nullptr;
+    size_t per_chunk = MP.chunk_bytes / mb;
+    size_t chunk = MP.cursor / per_chunk, slot = MP.cursor % per_chunk;
+    if (chunk >= MP.chunks.size())
+    {
+        char *c = nullptr;
+        if (hipMalloc((void **)&c, MP.chunk_bytes) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            MP.limit_mirrors = MP.cursor;
+            return nullptr;
+        }
+        MP.chunks.push_back(c);
+    }
+    MP.cursor++;
+    st.mirror = reinterpret_cast<double *>(MP.chunks[chunk] + slot * mb);
+    return st.mirror;
+}
+
+MirrorJobD mirror_job(slot_t *s, double *dense)
+{
+    MirrorJobD J;
+    memset(&J, 0, sizeof(J));
+    if (s->brow_pos == s->bcol_pos)
+    {
+        slot_t *up, *lo;
+        diag_halves(s, &up, &lo);
+        J.lo = BlkView{lo->d_columnpointer, lo->d_rowindex, lo->d_value};
+        J.up = BlkView{up->d_rowpointer, up->d_columnindex, up->d_value};
+    }
+    else
+    {
+        J.lo = BlkView{s->d_columnpointer, s->d_rowindex, s->d_value};
+    }
+    J.dense = dense;
+    return J;
+}
+
+// make sure the block has a mirror holding its current values; queues a densify job if it has to be (re)built.
+// Returns nullptr when no mirror can be had.
+double *current_mirror(slot_t *s, int nb)
+{
+    BlockState &st = block_state(s, nb);
+    double *m = obtain_mirror(st, nb);
+    if (!m)
+        return nullptr;
+    if (!st.mirror_current)
+    {
+        MP.to_densify.push_back(mirror_job(s, m)); // sparse_current holds whenever mirror_current does not
+        st.mirror_current = true;
+    }
+    return m;
+}
+
+// the block's sparse values are about to be read or overwritten: bring them up to date first
+void require_sparse(slot_t *s, int nb)
+{
+    s = canon_dst(s);
+    auto it = MP.blocks.find(block_key(s));
+    if (it == MP.blocks.end())
+        return;
+    BlockState &st = it->second;
+    if (st.brow != s->brow_pos || st.bcol != s->bcol_pos)
+        return;
+    if (!st.sparse_current && st.mirror)
+    {
+        MP.to_sparsify.push_back(mirror_job(s, st.mirror));
+        st.sparse_current = true;
+    }
+}
+
+void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify)
+{
+    size_t i = 0;
+    while (i < jobs.size())
+    {
+        Segment seg = acquire_segment();
+        size_t take = std::min(jobs.size() - i, seg.cap / (sizeof(MirrorJobD) + 16));
+        MirrorJobD *d_jobs;
+        MirrorJobD *h = seg.alloc<MirrorJobD>(take, &d_jobs);
+        memcpy(h, jobs.data() + i, sizeof(MirrorJobD) * take);
+        commit_segment(seg);
+        if (densify)
+            hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take), dim3(256), 0, B.stream, d_jobs, nb);
+        else
+            hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take), dim3(256), 0, B.stream, d_jobs, nb);
+        HIP_CHECK(hipGetLastError());
+        i += take;
+    }
+    jobs.clear();
+}
+
+void reset_block_states()
+{
+    MP.blocks.clear();
+    MP.cursor = 0;
+    MP.to_densify.clear();
+    MP.to_sparsify.clear();
+}
+
+#else // other value types have no dense mode
+
+inline bool dense_mode_available(int) { return false; }
+inline void require_sparse(slot_t *, int) {}
+inline void reset_block_states() {}
+
+#endif

@@ -86,6 +86,20 @@ __host__ __device__ inline val_t v_div(val_t a, val_t b) { return a / b; }
 __host__ __device__ inline real_t v_realpart(val_t a) { return a; }
 #endif
 
+// dst += v with hardware floating-point atomics (skips exact zeros: most of a dense column of a sparse update)
+__device__ inline void v_atomic_add(val_t *dst, val_t v)
+{
+#ifdef PANGULU_COMPLEX
+    if (v.re != 0)
+        atomicAdd(&dst->re, v.re);
+    if (v.im != 0)
+        atomicAdd(&dst->im, v.im);
+#else
+    if (v != 0)
+        atomicAdd(dst, v);
+#endif
+}
+
 // the CPU path's pivot clamp (...0100000.c:79-84): |real part| < 1e-16 -> +1e-16
 __device__ inline val_t clamp_pivot(val_t p)
 {
@@ -119,7 +133,14 @@ struct SsssmGroupD
     const u16 *uri;
     const u32 *uvi;
     val_t *uval;
+    // dense-mode destination: its nb x nb column-major mirror (see pg_hip_dense.h); the sparse views above are unused
+    val_t *cdense;
     u32 task_begin, task_end;
+    // a destination with many queued updates is cut into several groups that run concurrently: each then starts
+    // from zero and ADDS its partial sum to the destination with floating-point atomics (otherwise the longest
+    // queue sets the duration of the whole launch)
+    u32 atomic;
+    u32 pad_;
 };
 
 struct TrsmTaskD
@@ -146,6 +167,8 @@ struct GetrfTaskD
     const u16 *uci;
     val_t *uval;
     val_t *dense; // nb*nb scratch, only touched on the pattern
+    u32 preloaded; // blocked kernel: `dense` already holds the block (a dense-mode mirror): skip zero + scatter
+    u32 pad_;
 };
 
 __device__ inline u32 ptr0(const u32 *p, int i) { return i == 0 ? 0u : p[i]; }
@@ -195,16 +218,27 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
     if (!any)
         return;
 
-    const u32 c0 = ptr0(G.c.ptr, j), c1 = G.c.ptr[j + 1];
-    for (u32 p = c0 + lane; p < c1; p += 64)
-        acc[G.c.idx[p]] = G.c.val[p];
-    u32 u0 = 0, u1 = 0;
-    if (G.ucp)
+    u32 c0 = 0, c1 = 0, u0 = 0, u1 = 0;
+    const bool atomic = G.atomic != 0;
+    if (G.cdense)
     {
-        u0 = G.ucp[j];
-        u1 = G.ucp[j + 1];
-        for (u32 p = u0 + lane; p < u1; p += 64)
-            acc[G.uri[p]] = G.uval[G.uvi[p]];
+        // dense-mode destination: the column is a contiguous run of its mirror
+        for (int r = lane; r < nb; r += 64)
+            acc[r] = atomic ? v_make(0) : G.cdense[(size_t)j * nb + r];
+    }
+    else
+    {
+        c0 = ptr0(G.c.ptr, j);
+        c1 = G.c.ptr[j + 1];
+        for (u32 p = c0 + lane; p < c1; p += 64)
+            acc[G.c.idx[p]] = atomic ? v_make(0) : G.c.val[p];
+        if (G.ucp)
+        {
+            u0 = G.ucp[j];
+            u1 = G.ucp[j + 1];
+            for (u32 p = u0 + lane; p < u1; p += 64)
+                acc[G.uri[p]] = atomic ? v_make(0) : G.uval[G.uvi[p]];
+        }
     }
     wave_lds_fence();
 
@@ -247,12 +281,36 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
         }
     }
 
-    for (u32 p = c0 + lane; p < c1; p += 64)
-        G.c.val[p] = acc[G.c.idx[p]];
-    if (G.ucp)
+    if (atomic)
     {
-        for (u32 p = u0 + lane; p < u1; p += 64)
-            G.uval[G.uvi[p]] = acc[G.uri[p]];
+        if (G.cdense)
+        {
+            for (int r = lane; r < nb; r += 64)
+                v_atomic_add(&G.cdense[(size_t)j * nb + r], acc[r]);
+        }
+        else
+        {
+            for (u32 p = c0 + lane; p < c1; p += 64)
+                v_atomic_add(&G.c.val[p], acc[G.c.idx[p]]);
+            if (G.ucp)
+                for (u32 p = u0 + lane; p < u1; p += 64)
+                    v_atomic_add(&G.uval[G.uvi[p]], acc[G.uri[p]]);
+        }
+    }
+    else if (G.cdense)
+    {
+        for (int r = lane; r < nb; r += 64)
+            G.cdense[(size_t)j * nb + r] = acc[r];
+    }
+    else
+    {
+        for (u32 p = c0 + lane; p < c1; p += 64)
+            G.c.val[p] = acc[G.c.idx[p]];
+        if (G.ucp)
+        {
+            for (u32 p = u0 + lane; p < u1; p += 64)
+                G.uval[G.uvi[p]] = acc[G.uri[p]];
+        }
     }
     fmas = wave_sum(fmas);
     if (lane == 0 && fmas)
@@ -260,68 +318,11 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// SSSSM, dense (R64): C(nb x nb) -= sum_t A_t * B_t on the f64 matrix cores.  Workgroup = 4 wavefronts = one
-// 128 x 128 tile of C, each wavefront a 64 x 64 sub-tile held as 4 x 4 accumulators of v_mfma_f64_16x16x4_f64
-// (A frag: lane l holds A[row l&15][k = l>>4]; B frag: B[k = l>>4][col l&15]; D: col = l&15, row = (l>>4) + 4*reg).
+// SSSSM, dense (R64) and the dense-mode mirrors: pg_hip_dense.h
 // -----------------------------------------------------------------------------------------------------------------
 #if defined(CALCULATE_TYPE_R64)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
-                                                               const SsssmTaskD *__restrict__ tasks, int nb)
-{
-    const int tiles = nb / 128;
-    const int g = blockIdx.x / (tiles * tiles);
-    const int tile = blockIdx.x % (tiles * tiles);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m0 = (tile % tiles) * 128 + (wave & 1) * 64;
-    const int n0 = (tile / tiles) * 128 + (wave >> 1) * 64;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const SsssmGroupD G = groups[g];
-
-    v4f64 acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++)
-            acc[mi][ni] = (v4f64){0.0, 0.0, 0.0, 0.0};
-
-    for (u32 t = G.task_begin; t < G.task_end; t++)
-    {
-        const double *__restrict__ A = tasks[t].a.val;
-        const double *__restrict__ B = tasks[t].b.val;
-        const double *ap = A + (size_t)l4 * nb + m0 + l15;
-        const double *bp = B + (size_t)(n0 + l15) * nb + l4;
-#pragma unroll 2
-        for (int k = 0; k < nb; k += 4)
-        {
-            double a[4], b[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-                a[mi] = ap[(size_t)k * nb + mi * 16];
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-                b[ni] = bp[(size_t)ni * 16 * nb + k];
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-                for (int ni = 0; ni < 4; ni++)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
-    }
-
-    double *__restrict__ C = G.c.val;
-#pragma unroll
-    for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-            {
-                const size_t off = (size_t)(n0 + ni * 16 + l15) * nb + (m0 + mi * 16 + l4 + 4 * r);
-                C[off] -= acc[mi][ni][r];
-            }
-}
+#include "pg_hip_dense.h"
 #endif
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -548,9 +549,12 @@ __global__ __launch_bounds__(GETRF_BLOCKED_THREADS) void getrf_blocked_f64_kerne
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = GETRF_BLOCKED_THREADS / 64;
 
-    // dense image: zero, then scatter both halves
-    for (int i = tid; i < nb * nb / 2; i += GETRF_BLOCKED_THREADS)
-        reinterpret_cast<double2 *>(D)[i] = make_double2(0.0, 0.0);
+    // dense image: zero, then scatter both halves (unless the caller hands over a current dense mirror)
+    if (!T.preloaded)
+    {
+        for (int i = tid; i < nb * nb / 2; i += GETRF_BLOCKED_THREADS)
+            reinterpret_cast<double2 *>(D)[i] = make_double2(0.0, 0.0);
+    }
     for (int i = tid; i <= nb; i += GETRF_BLOCKED_THREADS)
     {
         sLcp[i] = T.lcp[i];
@@ -561,10 +565,13 @@ __global__ __launch_bounds__(GETRF_BLOCKED_THREADS) void getrf_blocked_f64_kerne
     // position comes from a binary search in the LDS copy of the pointer array
     const u32 nnzL = sLcp[nb], nnzU = sUrp[nb];
     unsigned long long ops = 0;
-    for (u32 p = tid; p < nnzL; p += GETRF_BLOCKED_THREADS)
-        D[(size_t)owner_of(sLcp, nb, p) * nb + T.lri[p]] = T.lval[p];
-    for (u32 p = tid; p < nnzU; p += GETRF_BLOCKED_THREADS)
-        D[(size_t)T.uci[p] * nb + owner_of(sUrp, nb, p)] = T.uval[p];
+    if (!T.preloaded)
+    {
+        for (u32 p = tid; p < nnzL; p += GETRF_BLOCKED_THREADS)
+            D[(size_t)owner_of(sLcp, nb, p) * nb + T.lri[p]] = T.lval[p];
+        for (u32 p = tid; p < nnzU; p += GETRF_BLOCKED_THREADS)
+            D[(size_t)T.uci[p] * nb + owner_of(sUrp, nb, p)] = T.uval[p];
+    }
     for (int c = tid; c < nb; c += GETRF_BLOCKED_THREADS)
     {
         // structural flop count of the sparse algorithm (what the reference counts, src/pangulu_kernel_interface.c:4-82)
@@ -873,10 +880,13 @@ struct Backend
     int nb_cfg = 0;
     // options
     long long opt_host_mirror = 1;
-    long long opt_dense_permille = 1000;
+    long long opt_dense_permille = 150;
     long long opt_profile = 0;
     long long opt_assume_independent = 0;
     long long opt_getrf_strict = 0;
+    long long opt_count_flops = 1;
+    long long opt_group_chunk = 8;
+    double mfma_flops_executed = 0;
     // resources
     Ring ring;
     unsigned long long *d_flops = nullptr; // [6]
@@ -1099,23 +1109,22 @@ void mirror_to_host(slot_t *s, int nb)
 
 const double SV = (double)sizeof(val_t);
 
+#include "pg_hip_dense_host.h"
+
 // ---- SSSSM -----------------------------------------------------------------------------------------------------
+// Tasks arrive grouped by destination.  Per group the destination is either dense-mode (updates accumulate in its
+// mirror) or sparse; per task the update runs on the matrix cores when destination and both operands have mirrors,
+// on the LDS-accumulator kernel otherwise.
 void launch_ssssm(int nb, task_t **list, size_t n)
 {
     if (n == 0)
         return;
-    const bool dense_ok =
-#if defined(CALCULATE_TYPE_R64)
-        (nb % 128 == 0);
-#else
-        false;
-#endif
-    const u32 full = (u32)nb * (u32)nb;
+    const bool dense_ok = dense_mode_available(nb);
     size_t i = 0;
     while (i < n)
     {
         Segment seg = acquire_segment();
-        // worst case per task: one group + one task descriptor; fill until the segment is full
+        // worst case per task: one group + one task descriptor in each class; fill until the segment is full
         size_t max_tasks = seg.cap / (sizeof(SsssmGroupD) + sizeof(SsssmTaskD) + 32) / 2;
         size_t take = std::min(n - i, max_tasks);
         SsssmTaskD *d_tasks_s, *d_tasks_d;
@@ -1142,24 +1151,42 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             SsssmGroupD G;
             memset(&G, 0, sizeof(G));
             u32 nnz_c;
+            slot_t *up = nullptr, *lo = dst;
             if (diag)
             {
-                slot_t *up, *lo;
                 diag_halves(dst, &up, &lo);
-                const DiagAux &aux = get_diag_aux(up, nb);
-                G.c = BlkView{lo->d_columnpointer, lo->d_rowindex, lo->d_value};
-                G.ucp = aux.d_cp;
-                G.uri = aux.d_ri;
-                G.uvi = aux.d_vi;
-                G.uval = up->d_value;
                 nnz_c = host_nnz(lo, nb) + host_nnz(up, nb);
             }
             else
             {
-                G.c = BlkView{dst->d_columnpointer, dst->d_rowindex, dst->d_value};
                 nnz_c = host_nnz(dst, nb);
             }
-            const bool dst_full = !diag && nnz_c == full;
+#if defined(CALCULATE_TYPE_R64)
+            double *cm = nullptr;
+            if (dense_ok && is_dense_mode(dst, nb))
+            {
+                cm = current_mirror(dst, nb);
+                if (cm)
+                {
+                    block_state(dst, nb).sparse_current = false; // from now on the mirror is ahead of the record
+                    G.cdense = cm;
+                }
+            }
+            if (!cm)
+                require_sparse(dst, nb); // (a destination that lost its mirror budget mid-way)
+#endif
+            if (!G.cdense)
+            {
+                G.c = BlkView{lo->d_columnpointer, lo->d_rowindex, lo->d_value};
+                if (diag)
+                {
+                    const DiagAux &aux = get_diag_aux(up, nb);
+                    G.ucp = aux.d_cp;
+                    G.uri = aux.d_ri;
+                    G.uvi = aux.d_vi;
+                    G.uval = up->d_value;
+                }
+            }
             size_t s0 = ns, d0 = nd;
             for (size_t t = i; t < j; t++)
             {
@@ -1169,7 +1196,21 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 T.b = BlkView{b->d_columnpointer, b->d_rowindex, b->d_value};
                 u32 na = host_nnz(a, nb), nbz = host_nnz(b, nb);
                 double by = (SV + 2) * ((double)na + nbz) + (2 * SV + 2) * (double)nnz_c + 12.0 * (nb + 1);
-                if (dense_ok && dst_full && na == full && nbz == full)
+                bool on_mfma = false;
+#if defined(CALCULATE_TYPE_R64)
+                if (G.cdense && is_dense_mode(a, nb) && is_dense_mode(b, nb))
+                {
+                    double *am = current_mirror(a, nb);
+                    double *bm = am ? current_mirror(b, nb) : nullptr;
+                    if (am && bm)
+                    {
+                        T.a.val = am; // the pattern pointers stay: the flop counter reads them
+                        T.b.val = bm;
+                        on_mfma = true;
+                    }
+                }
+#endif
+                if (on_mfma)
                 {
                     tasks_d[nd++] = T;
                     bytes_d += by;
@@ -1180,21 +1221,33 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                     bytes_s += by;
                 }
             }
-            if (ns > s0)
+            // cut long queues into chunks that run concurrently and merge with atomics
+            const size_t chunk = (size_t)(B.opt_group_chunk > 0 ? B.opt_group_chunk : 1 << 30);
+            const bool split = (ns - s0) > chunk || (nd - d0) > chunk;
+            for (size_t c = s0; c < ns; c += chunk)
             {
-                G.task_begin = (u32)s0;
-                G.task_end = (u32)ns;
+                G.task_begin = (u32)c;
+                G.task_end = (u32)std::min(ns, c + chunk);
+                G.atomic = split ? 1u : 0u;
                 groups_s[gs++] = G;
             }
-            if (nd > d0)
+            for (size_t c = d0; c < nd; c += chunk)
             {
-                G.task_begin = (u32)d0;
-                G.task_end = (u32)nd;
+                G.task_begin = (u32)c;
+                G.task_end = (u32)std::min(nd, c + chunk);
+                G.atomic = split ? 1u : 0u;
                 groups_d[gd++] = G;
             }
             i = j;
         }
         commit_segment(seg);
+#if defined(CALCULATE_TYPE_R64)
+        // mirrors that have to be (re)built for this launch, and sparse records that must catch up first
+        if (!MP.to_sparsify.empty())
+            flush_mirror_jobs(nb, MP.to_sparsify, false);
+        if (!MP.to_densify.empty())
+            flush_mirror_jobs(nb, MP.to_densify, true);
+#endif
         if (gs)
         {
             LaunchTimer lt(4);
@@ -1209,14 +1262,18 @@ void launch_ssssm(int nb, task_t **list, size_t n)
 #if defined(CALCULATE_TYPE_R64)
         if (gd)
         {
-            LaunchTimer lt(5);
-            int tiles = nb / 128;
-            hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, B.stream, d_groups_d,
-                               d_tasks_d, nb);
+            {
+                LaunchTimer lt(5);
+                int tiles = nb / DG_TILE;
+                hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, B.stream, d_groups_d,
+                                   d_tasks_d, nb);
+            }
+            if (B.opt_count_flops)
+                hipLaunchKernelGGL(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, B.stream, d_tasks_d, nb, B.d_flops + 5);
             B.stats.launches[5]++;
             B.stats.tasks[5] += nd;
             B.stats.alg_bytes[5] += bytes_d;
-            B.stats.flops[5] += 2.0 * (double)nb * nb * nb * (double)nd;
+            B.mfma_flops_executed += 2.0 * (double)nb * nb * nb * (double)nd;
         }
 #endif
         HIP_CHECK(hipGetLastError());
@@ -1239,6 +1296,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         {
             task_t *t = list[i + k];
             slot_t *dst = t->opdst, *diag = t->op1;
+            require_sparse(dst, nb); // a dense-mode destination accumulated its updates in the mirror
             // opdiag may be either half (…0100000.c:143-145,184-186); only the half the solve reads has to exist
             // (a rank that received a remote diagonal for its TSTRFs only may never get the L half)
             const bool want_upper = t->kernel_id == PANGULU_TASK_TSTRF;
@@ -1282,6 +1340,16 @@ void launch_trsm(int nb, task_t **list, size_t n)
             tasks[k] = T;
         }
         commit_segment(seg);
+#if defined(CALCULATE_TYPE_R64)
+        if (!MP.to_sparsify.empty())
+            flush_mirror_jobs(nb, MP.to_sparsify, false);
+        for (size_t k = 0; k < take; k++)
+        {
+            auto it = MP.blocks.find(block_key(list[i + k]->opdst));
+            if (it != MP.blocks.end())
+                it->second.mirror_current = false; // the solve rewrites the sparse values
+        }
+#endif
         {
             LaunchTimer lt(nt >= ng ? 2 : 3);
             int vblocks = (nb + TRSM_WAVES - 1) / TRSM_WAVES;
@@ -1318,6 +1386,10 @@ void launch_getrf(int nb, task_t **list, size_t n)
         B.getrf_scratch_slots = max_slots;
         B.nb_cfg = nb;
     }
+    bool blocked_kernel = false;
+#if defined(CALCULATE_TYPE_R64)
+    blocked_kernel = !B.opt_getrf_strict && (nb % 16 == 0) && nb <= GETRF_BLOCKED_ROWS;
+#endif
     size_t i = 0;
     while (i < n)
     {
@@ -1338,15 +1410,43 @@ void launch_getrf(int nb, task_t **list, size_t n)
             T.uci = up->d_columnindex;
             T.uval = up->d_value;
             T.dense = B.getrf_scratch + (size_t)k * nb * nb;
+            T.preloaded = 0;
+            T.pad_ = 0;
+#if defined(CALCULATE_TYPE_R64)
+            {
+                auto it = MP.blocks.find(block_key(lo));
+                if (it != MP.blocks.end() && it->second.brow == lo->brow_pos && it->second.bcol == lo->bcol_pos && it->second.mirror)
+                {
+                    BlockState &st = it->second;
+                    if (!st.sparse_current)
+                    {
+                        if (blocked_kernel)
+                        {
+                            T.dense = st.mirror; // the mirror IS the dense image the blocked kernel works on
+                            T.preloaded = 1;
+                        }
+                        else
+                        {
+                            MP.to_sparsify.push_back(mirror_job(lo, st.mirror));
+                        }
+                        st.sparse_current = true;
+                    }
+                    st.mirror_current = false;
+                }
+            }
+#endif
             tasks[k] = T;
             by += (2 * SV + 2) * ((double)host_nnz(lo, nb) + host_nnz(up, nb)) + 8.0 * (nb + 1);
         }
         commit_segment(seg);
+#if defined(CALCULATE_TYPE_R64)
+        if (!MP.to_sparsify.empty())
+            flush_mirror_jobs(nb, MP.to_sparsify, false);
+#endif
         {
             LaunchTimer lt(1);
-            bool blocked = false;
+            bool blocked = blocked_kernel;
 #if defined(CALCULATE_TYPE_R64)
-            blocked = !B.opt_getrf_strict && (nb % 16 == 0) && nb <= GETRF_BLOCKED_ROWS;
             if (blocked)
             {
                 size_t lds = sizeof(double) * (2 * GETRF_PANEL * (size_t)(nb + 2) + GETRF_PANEL * GETRF_PANEL) + sizeof(u32) * 2 * (size_t)(nb + 1);
@@ -1692,6 +1792,18 @@ extern "C"
         case PANGULU_HIP_OPT_GETRF_STRICT_ORDER:
             B.opt_getrf_strict = value;
             return 0;
+        case PANGULU_HIP_OPT_COUNT_FLOPS:
+            B.opt_count_flops = value;
+            return 0;
+        case PANGULU_HIP_OPT_SSSSM_GROUP_CHUNK:
+            B.opt_group_chunk = value;
+            return 0;
+        case PANGULU_HIP_OPT_RESET_BLOCK_STATE:
+        {
+            std::lock_guard<std::mutex> g(B.mutex);
+            reset_block_states();
+            return 0;
+        }
         default:
             return 1;
         }
@@ -1714,13 +1826,15 @@ extern "C"
         if (getenv("PANGULU_HIP_DEBUG_GETRF"))
             fprintf(stderr, "[getrf stamps, block 0, 100 MHz ticks] scatter %llu | panel-load %llu | pivots %llu | panel-store %llu | strip %llu | gemm %llu | gather %llu\n",
                     f[8], f[9], f[10], f[11], f[12], f[13], f[14]);
-        for (int c = 1; c <= 4; c++)
+        for (int c = 1; c <= 5; c++)
             B.stats.flops[c] = (double)f[c];
+        B.stats.mfma_flops_executed = B.mfma_flops_executed;
         if (out)
             *out = B.stats;
         if (reset)
         {
             memset(&B.stats, 0, sizeof(B.stats));
+            B.mfma_flops_executed = 0;
             HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(f)));
         }
     }

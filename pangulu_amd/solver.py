@@ -182,4 +182,5 @@ def hip_stats(h_or_lib, reset=False):
     for k, name in _lib.KERNEL_CLASSES.items():
         out[name] = dict(launches=int(st.launches[k]), tasks=int(st.tasks[k]), alg_bytes=float(st.alg_bytes[k]),
                          flops=float(st.flops[k]), elapsed_ms=float(st.elapsed_ms[k]))
+    out["ssssm_dense_mfma"]["mfma_flops_executed"] = float(st.mfma_flops_executed)
     return out

@@ -71,6 +71,36 @@ def test_dense_blocks_take_the_mfma_path():
     assert np.abs(LU - A).max() <= 1e-11 * np.abs(A).max()
 
 
+DENSE_MODE_CASES = [
+    ("fem27_10_nb256", lambda: M.fem27(10), 256, "nd"),
+    ("shell_14x12_nb128", lambda: M.shell(14, 12), 128, "nd"),
+    ("poisson10_nb128_identity", lambda: M.poisson3d(10), 128, "identity"),
+    ("ragged_n700_nb128", lambda: M.random_pattern(700, 0.02, 4), 128, "nd"),
+]
+
+
+@pytest.mark.parametrize("permille", [1, 60, 150, 1001])
+@pytest.mark.parametrize("name,gen,nb,ordering", DENSE_MODE_CASES, ids=[c[0] for c in DENSE_MODE_CASES])
+def test_dense_mode_thresholds(name, gen, nb, ordering, permille):
+    """Every mix of dense-mode (mirrored, MFMA) and sparse blocks must give the same factors: threshold 1 per mille
+    mirrors every block (zero-filled dense images of very sparse blocks included), 1001 disables dense mode."""
+    from pangulu_amd import _lib
+
+    mat = gen()
+    gpu = factorize(mat, nb, "hip", ordering=ordering, hip_options={_lib.HIP_OPT_DENSE_THRESHOLD_PERMILLE: permille})
+    ref = factorize(mat, nb, oracle_library("r64"), ordering=ordering)
+    st = gpu["hip_stats"]
+    if permille == 1:
+        assert st["ssssm_dense_mfma"]["tasks"] > 0 and st["ssssm_sparse"]["tasks"] == 0, st
+    if permille == 1001:
+        assert st["ssssm_dense_mfma"]["tasks"] == 0
+    for f in ("L", "U"):
+        assert max_rel_diff(gpu[f], ref[f]) <= 1e-12, (name, f, permille)
+    assert gpu["residual"] <= 1e-12 and lu_check(mat, gpu) <= 1e-12
+    counted = sum(v["flops"] for v in gpu["hip_stats"].values())
+    assert counted == gpu["info"]["flop"], (counted, gpu["info"]["flop"])
+
+
 BITEXACT_CASES = [
     ("banded", lambda: M.poisson3d(64, 2, 2), 16, "identity"),
     ("fem27_7_nb48", lambda: M.fem27(7), 48, "nd"),
@@ -90,7 +120,9 @@ def test_sparse_path_is_bit_exact_against_fma_oracle(name, gen, nb, ordering):
     mat = gen()
     # strict-order GETRF: the LDS-blocked MFMA variant also applies updates in ascending pivot order, but sums four
     # pivots per matrix-core instruction, whose internal rounding is not specified
-    gpu = factorize(mat, nb, "hip", ordering=ordering, hip_options={_lib.HIP_OPT_GETRF_STRICT_ORDER: 1})
+    # (and no queue splitting: chunks of a split queue merge with atomics, in arrival order)
+    gpu = factorize(mat, nb, "hip", ordering=ordering,
+                    hip_options={_lib.HIP_OPT_GETRF_STRICT_ORDER: 1, _lib.HIP_OPT_SSSSM_GROUP_CHUNK: 0})
     ref = factorize(mat, nb, oracle_library("r64", fma=True), ordering=ordering)
     assert gpu["hip_stats"]["ssssm_dense_mfma"]["tasks"] == 0
     for f in ("L", "U"):
