@@ -199,10 +199,11 @@ extern "C"
      *   PANGULU_HIP_OPT_HOST_MIRROR (default 1): after GETRF/TSTRF/GESSM copy the block's values back into
      *     slot->value like …0201000.cu:639-640,680,714 does (the reference host's MPI send and SpTRSV read
      *     host memory).  The native host keeps factors device-resident and sets 0.
-     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 150): blocks with at least this fill
-     *     (nnz*1000/nb^2) are "dense-mode": they get a dense mirror in HBM, updates into them accumulate there,
-     *     and an update whose three blocks are all dense-mode runs on the f64 MFMA kernel.  1000 = only
-     *     completely full blocks (the reference's cuBLAS-direct rule, …0201000.cu:827); 1001 disables dense mode.
+     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 150): an update C -= A*B whose operands have a
+     *     geometric-mean fill sqrt(dA*dB) of at least this many per mille runs on the f64 MFMA kernel on dense
+     *     mirrors of the three blocks (kept in HBM, built once per block); a destination that has a mirror
+     *     accumulates all its updates there.  1000 = only completely full operands (the reference's
+     *     cuBLAS-direct rule, …0201000.cu:827); 1001 disables the dense path.
      */
 #define PANGULU_HIP_OPT_HOST_MIRROR 1
 #define PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE 2
@@ -228,6 +229,10 @@ extern "C"
      *     cut into chunks of this size that run concurrently and add their partial sums with floating-point
      *     atomics (results then vary in the last bits from run to run).  0 = never split. */
 #define PANGULU_HIP_OPT_SSSSM_GROUP_CHUNK 8
+    /*   PANGULU_HIP_OPT_TRSM_DENSE_PERMILLE (default 100): TSTRF/GESSM on a block with at least this fill (or whose
+     *     updates already live in a dense mirror) run as panel-wise dense solves on the matrix cores against the dense
+     *     LU image GETRF leaves behind; 1001 keeps every solve on the sparse kernel. */
+#define PANGULU_HIP_OPT_TRSM_DENSE_PERMILLE 9
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an
@@ -250,6 +255,7 @@ extern "C"
         double flops[6];
         double elapsed_ms[6];
         double mfma_flops_executed; /* 2*nb^3 per task of class 5: what the matrix cores actually did */
+        unsigned long long trsm_dense_tasks; /* TSTRF/GESSM tasks that took the dense MFMA path */
     } pangulu_hip_stats_t;
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset);
 

@@ -91,6 +91,7 @@ class HipStats(ctypes.Structure):
         ("flops", ctypes.c_double * 6),
         ("elapsed_ms", ctypes.c_double * 6),
         ("mfma_flops_executed", ctypes.c_double),
+        ("trsm_dense_tasks", ctypes.c_ulonglong),
     ]
 
 
@@ -190,6 +191,7 @@ HIP_OPT_GETRF_STRICT_ORDER = 5
 HIP_OPT_COUNT_FLOPS = 6
 HIP_OPT_RESET_BLOCK_STATE = 7
 HIP_OPT_SSSSM_GROUP_CHUNK = 8
+HIP_OPT_TRSM_DENSE_PERMILLE = 9
 
 ORDER_IDENTITY, ORDER_ND, ORDER_USER = 0, 1, 2
 TRANSPORT_HOST, TRANSPORT_RCCL = 0, 1

@@ -9,6 +9,7 @@ struct BlockState
     double *mirror = nullptr;
     bool mirror_current = false; // mirror holds the block's current values
     bool sparse_current = true;  // the sparse record holds the block's current values
+    bool lu_image = false;       // diagonal block: the mirror holds L\\U with inverted diagonal tiles (pg_hip_trsm_dense.h)
     u32 brow = 0, bcol = 0, nnz = 0;
 };
 
@@ -27,21 +28,15 @@ inline bool dense_mode_available(int nb)
     return (nb % DG_TILE == 0) && B.opt_dense_permille <= 1000;
 }
 
-// is the block behind `s` (a diagonal block counts both halves) filled enough for dense mode?
-inline bool is_dense_mode(slot_t *s, int nb)
+// Is C -= A*B worth the matrix cores?  The LDS kernel's time grows with the structural flops, about 2*nnzA*nnzB/nb for
+// evenly spread patterns, at well under 1 TFLOP/s; the MFMA kernel spends 2*nb^3 flops whatever the fill, at tens of
+// TFLOP/s.  The threshold t (per mille, PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE) is the geometric-mean fill of the
+// two operands above which the update goes dense: sqrt(dA*dB) >= t/1000.
+inline bool is_heavy_update(u32 nnz_a, u32 nnz_b, int nb)
 {
-    u64 nnz;
-    if (s->brow_pos == s->bcol_pos)
-    {
-        slot_t *up, *lo;
-        diag_halves(s, &up, &lo);
-        nnz = (u64)host_nnz(lo, nb) + host_nnz(up, nb);
-    }
-    else
-    {
-        nnz = host_nnz(s, nb);
-    }
-    return nnz * 1000ull >= (u64)B.opt_dense_permille * (u64)nb * (u64)nb;
+    const double full = (double)nb * (double)nb;
+    const double t = (double)B.opt_dense_permille / 1000.0;
+    return (double)nnz_a * (double)nnz_b >= t * t * full * full;
 }
 
 inline const void *block_key(slot_t *s)
@@ -131,6 +126,30 @@ MirrorJobD mirror_job(slot_t *s, double *dense)
     return J;
 }
 
+// the block's mirror holds newer values than its sparse record (updates have been accumulating there)
+bool mirror_is_ahead(slot_t *s)
+{
+    s = canon_dst(s);
+    auto it = MP.blocks.find(block_key(s));
+    if (it == MP.blocks.end())
+        return false;
+    const BlockState &st = it->second;
+    return st.brow == s->brow_pos && st.bcol == s->bcol_pos && st.mirror && !st.sparse_current;
+}
+
+// dense LU image of the diagonal block `half` belongs to, if GETRF left one
+const double *lu_image_of(slot_t *half)
+{
+    slot_t *lo = canon_dst(half);
+    auto it = MP.blocks.find(block_key(lo));
+    if (it == MP.blocks.end())
+        return nullptr;
+    const BlockState &st = it->second;
+    if (st.brow != lo->brow_pos || st.bcol != lo->bcol_pos || !st.lu_image)
+        return nullptr;
+    return st.mirror;
+}
+
 // make sure the block has a mirror holding its current values; queues a densify job if it has to be (re)built.
 // Returns nullptr when no mirror can be had.
 double *current_mirror(slot_t *s, int nb)
@@ -180,6 +199,7 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify)
         else
             hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take), dim3(256), 0, B.stream, d_jobs, nb);
         HIP_CHECK(hipGetLastError());
+        release_pending_segments(); // (callers commit their own segment only after this returns)
         i += take;
     }
     jobs.clear();

@@ -260,23 +260,52 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
                 my_a0 = ptr0(A.ptr, (int)my_k);
                 my_a1 = A.ptr[my_k + 1];
             }
-            for (u32 i = 0; i < cnt; i++)
+            // four op2 entries per pass: the first 64 elements of their four op1 columns are requested together
+            // (the walk is latency-bound: one column in flight per wavefront leaves the memory pipe idle), then
+            // applied one after the other -- the order of updates per destination entry stays ascending in k
+            for (u32 i = 0; i < cnt; i += 4)
             {
-                const u32 a0 = __shfl(my_a0, (int)i, 64), a1 = __shfl(my_a1, (int)i, 64);
-#ifdef PANGULU_COMPLEX
-                val_t bv;
-                bv.re = __shfl(my_b.re, (int)i, 64);
-                bv.im = __shfl(my_b.im, (int)i, 64);
-#else
-                const val_t bv = __shfl(my_b, (int)i, 64);
-#endif
-                for (u32 r = a0 + lane; r < a1; r += 64)
+                u32 a0[4], a1[4], row[4];
+                val_t bv[4], av[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
                 {
-                    const u32 row = A.idx[r];
-                    acc[row] = v_submul(acc[row], A.val[r], bv);
-                    fmas++;
+                    const int src = (int)min(i + (u32)u, cnt - 1);
+                    a0[u] = __shfl(my_a0, src, 64);
+                    a1[u] = (i + (u32)u < cnt) ? __shfl(my_a1, src, 64) : a0[u];
+#ifdef PANGULU_COMPLEX
+                    bv[u].re = __shfl(my_b.re, src, 64);
+                    bv[u].im = __shfl(my_b.im, src, 64);
+#else
+                    bv[u] = __shfl(my_b, src, 64);
+#endif
+                    const u32 r = a0[u] + (u32)lane;
+                    ok[u] = r < a1[u];
+                    row[u] = 0;
+                    av[u] = v_make(0);
+                    if (ok[u])
+                    {
+                        row[u] = A.idx[r];
+                        av[u] = A.val[r];
+                    }
                 }
-                wave_lds_fence();
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    if (ok[u])
+                    {
+                        acc[row[u]] = v_submul(acc[row[u]], av[u], bv[u]);
+                        fmas++;
+                    }
+                    for (u32 r = a0[u] + 64 + lane; r < a1[u]; r += 64)
+                    {
+                        const u32 rr = A.idx[r];
+                        acc[rr] = v_submul(acc[rr], A.val[r], bv[u]);
+                        fmas++;
+                    }
+                    wave_lds_fence();
+                }
             }
         }
     }
@@ -323,6 +352,7 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
 #if defined(CALCULATE_TYPE_R64)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 #include "pg_hip_dense.h"
+#include "pg_hip_trsm_dense.h"
 #endif
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -366,23 +396,53 @@ __global__ __launch_bounds__(TRSM_WAVES * 64) void trsm_sparse_kernel(const Trsm
             my_t0 = T.tptr[my_c];
             my_t1 = T.tptr[my_c + 1];
         }
+        // The steps of one vector are strictly sequential, so the only parallelism to be had is in the memory
+        // pipe: while step i is applied, the pivot and the first 64 factor entries of step i+1 are already in flight.
+        u32 n_c, n_t0, n_t1, n_k = 0;
+        val_t n_d = v_make(1), n_v = v_make(0);
+        bool n_ok;
+#define TRSM_FETCH(i_)                                                   \
+    {                                                                    \
+        n_c = __shfl(my_c, (int)(i_), 64);                               \
+        n_t0 = __shfl(my_t0, (int)(i_), 64);                             \
+        n_t1 = __shfl(my_t1, (int)(i_), 64);                             \
+        if (T.is_tstrf)                                                  \
+        {                                                                \
+            n_d = T.tval[n_t0];                                          \
+            n_t0++;                                                      \
+        }                                                                \
+        const u32 r_ = n_t0 + (u32)lane;                                 \
+        n_ok = r_ < n_t1;                                                \
+        if (n_ok)                                                        \
+        {                                                                \
+            n_k = T.tidx[r_];                                            \
+            n_v = T.tval[r_];                                            \
+        }                                                                \
+    }
+        TRSM_FETCH(0)
         for (u32 i = 0; i < cnt; i++)
         {
-            const u32 c = __shfl(my_c, (int)i, 64);
-            u32 t0 = __shfl(my_t0, (int)i, 64);
-            const u32 t1 = __shfl(my_t1, (int)i, 64);
+            const u32 c = n_c, t0 = n_t0, t1 = n_t1, k0 = n_k;
+            const val_t d = n_d, v0 = n_v;
+            const bool ok = n_ok;
+            if (i + 1 < cnt)
+                TRSM_FETCH(i + 1)
             val_t xc = x[c];
             if (T.is_tstrf)
             {
-                xc = v_div(xc, clamp_pivot(T.tval[t0]));
+                xc = v_div(xc, clamp_pivot(d));
                 if (lane == 0)
                 {
                     x[c] = xc;
                     ops += 1;
                 }
-                t0++;
             }
-            for (u32 r = t0 + lane; r < t1; r += 64)
+            if (ok)
+            {
+                x[k0] = v_submul(x[k0], xc, v0);
+                ops += 2;
+            }
+            for (u32 r = t0 + 64 + lane; r < t1; r += 64)
             {
                 const u32 k = T.tidx[r];
                 x[k] = v_submul(x[k], xc, T.tval[r]);
@@ -390,6 +450,7 @@ __global__ __launch_bounds__(TRSM_WAVES * 64) void trsm_sparse_kernel(const Trsm
             }
             wave_lds_fence();
         }
+#undef TRSM_FETCH
     }
     for (u32 p = s + lane; p < e; p += 64)
         T.bval[T.vmap ? T.vmap[p] : p] = x[T.vidx[p]];
@@ -856,9 +917,10 @@ struct DiagAux // column view of a diagonal block's upper (CSR) half, built on f
     u32 brow = 0;
 };
 
-struct Ring // pinned staging + device mirror, reused segment by segment in stream order
+struct Ring // descriptor staging in pinned host memory that the kernels read in place, reused segment by segment
 {
-    static const int NSEG = 8;
+    static const int NSEG = 32;
+    std::vector<int> pending; // segments handed to kernels since the last event record
     size_t seg_bytes = 0;
     char *h = nullptr, *d = nullptr;
     hipEvent_t ev[NSEG];
@@ -886,6 +948,7 @@ struct Backend
     long long opt_getrf_strict = 0;
     long long opt_count_flops = 1;
     long long opt_group_chunk = 8;
+    long long opt_trsm_dense_permille = 100;
     double mfma_flops_executed = 0;
     // resources
     Ring ring;
@@ -916,9 +979,12 @@ void ensure_ready()
     }
     HIP_CHECK(hipSetDevice(B.device));
     HIP_CHECK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
-    B.ring.seg_bytes = (size_t)8 << 20;
-    HIP_CHECK(hipHostMalloc((void **)&B.ring.h, B.ring.seg_bytes * Ring::NSEG, hipHostMallocDefault));
-    HIP_CHECK(hipMalloc((void **)&B.ring.d, B.ring.seg_bytes * Ring::NSEG));
+    // Descriptors are written once by the host and read once per workgroup: the kernels read them straight from
+    // pinned host memory (non-coherent, so the device L2 may cache them) instead of waiting for a staging copy per
+    // launch (rocprofv3 showed ~1900 blit dispatches, ~50 ms, per factorisation of the bench matrix).
+    B.ring.seg_bytes = (size_t)4 << 20;
+    HIP_CHECK(hipHostMalloc((void **)&B.ring.h, B.ring.seg_bytes * Ring::NSEG, hipHostMallocNonCoherent | hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&B.ring.d, B.ring.h, 0));
     for (int i = 0; i < Ring::NSEG; i++)
     {
         HIP_CHECK(hipEventCreateWithFlags(&B.ring.ev[i], hipEventDisableTiming));
@@ -948,13 +1014,27 @@ struct Segment
     }
 };
 
+// Record, behind everything launched so far, that the committed segments may be reused.  Must be called AFTER the
+// kernels reading those segments have been launched (an event recorded earlier would let the host overwrite a
+// segment a queued kernel has yet to read).
+void release_pending_segments()
+{
+    Ring &r = B.ring;
+    for (int i : r.pending)
+    {
+        HIP_CHECK(hipEventRecord(r.ev[i], B.stream));
+        r.used[i] = true;
+    }
+    r.pending.clear();
+}
+
 Segment acquire_segment()
 {
     Ring &r = B.ring;
     int i = r.cur;
     r.cur = (r.cur + 1) % Ring::NSEG;
     if (r.used[i])
-        HIP_CHECK(hipEventSynchronize(r.ev[i])); // the H2D copy that last read this pinned segment is done
+        HIP_CHECK(hipEventSynchronize(r.ev[i])); // the kernels that last read this segment are done
     Segment s;
     s.h = r.h + (size_t)i * r.seg_bytes;
     s.d = r.d + (size_t)i * r.seg_bytes;
@@ -964,12 +1044,10 @@ Segment acquire_segment()
     return s;
 }
 
+// the segment is complete: kernels launched from now on may read it (in place, see ensure_ready)
 void commit_segment(Segment &s)
 {
-    if (s.used)
-        HIP_CHECK(hipMemcpyAsync(s.d, s.h, s.used, hipMemcpyHostToDevice, B.stream));
-    HIP_CHECK(hipEventRecord(B.ring.ev[s.index], B.stream));
-    B.ring.used[s.index] = true;
+    B.ring.pending.push_back(s.index);
 }
 
 hipEvent_t take_event()
@@ -1162,10 +1240,16 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 nnz_c = host_nnz(dst, nb);
             }
 #if defined(CALCULATE_TYPE_R64)
+            // The destination works on its dense mirror when the mirror is already ahead of the sparse record, or
+            // when at least one update of the group is heavy enough for the matrix cores.
             double *cm = nullptr;
-            if (dense_ok && is_dense_mode(dst, nb))
+            if (dense_ok)
             {
-                cm = current_mirror(dst, nb);
+                bool want = mirror_is_ahead(dst);
+                for (size_t t = i; t < j && !want; t++)
+                    want = is_heavy_update(host_nnz(list[t]->op1, nb), host_nnz(list[t]->op2, nb), nb);
+                if (want)
+                    cm = current_mirror(dst, nb);
                 if (cm)
                 {
                     block_state(dst, nb).sparse_current = false; // from now on the mirror is ahead of the record
@@ -1173,7 +1257,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 }
             }
             if (!cm)
-                require_sparse(dst, nb); // (a destination that lost its mirror budget mid-way)
+                require_sparse(dst, nb);
 #endif
             if (!G.cdense)
             {
@@ -1198,7 +1282,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 double by = (SV + 2) * ((double)na + nbz) + (2 * SV + 2) * (double)nnz_c + 12.0 * (nb + 1);
                 bool on_mfma = false;
 #if defined(CALCULATE_TYPE_R64)
-                if (G.cdense && is_dense_mode(a, nb) && is_dense_mode(b, nb))
+                if (G.cdense && is_heavy_update(na, nbz, nb))
                 {
                     double *am = current_mirror(a, nb);
                     double *bm = am ? current_mirror(b, nb) : nullptr;
@@ -1240,7 +1324,6 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             }
             i = j;
         }
-        commit_segment(seg);
 #if defined(CALCULATE_TYPE_R64)
         // mirrors that have to be (re)built for this launch, and sparse records that must catch up first
         if (!MP.to_sparsify.empty())
@@ -1248,6 +1331,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         if (!MP.to_densify.empty())
             flush_mirror_jobs(nb, MP.to_densify, true);
 #endif
+        commit_segment(seg);
         if (gs)
         {
             LaunchTimer lt(4);
@@ -1277,6 +1361,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         }
 #endif
         HIP_CHECK(hipGetLastError());
+        release_pending_segments();
     }
 }
 
@@ -1287,16 +1372,22 @@ void launch_trsm(int nb, task_t **list, size_t n)
     while (i < n)
     {
         Segment seg = acquire_segment();
-        size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + 16));
-        TrsmTaskD *d_tasks;
+        size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64));
+        TrsmTaskD *d_tasks, *d_ftasks;
         TrsmTaskD *tasks = seg.alloc<TrsmTaskD>(take, &d_tasks);
+        TrsmTaskD *ftasks = seg.alloc<TrsmTaskD>(take, &d_ftasks); // sparse views of the dense-path tasks (flop counting)
         double by_t = 0, by_g = 0;
-        size_t nt = 0, ng = 0;
+        size_t nt = 0, ng = 0, nsparse = 0, ndense = 0;
+#if defined(CALCULATE_TYPE_R64)
+        TrsmDenseTaskD *d_dtasks;
+        TrsmDenseTaskD *dtasks = seg.alloc<TrsmDenseTaskD>(take, &d_dtasks);
+        std::vector<slot_t *> solved_dense;
+        const bool dense_ok = dense_mode_available(nb);
+#endif
         for (size_t k = 0; k < take; k++)
         {
             task_t *t = list[i + k];
             slot_t *dst = t->opdst, *diag = t->op1;
-            require_sparse(dst, nb); // a dense-mode destination accumulated its updates in the mirror
             // opdiag may be either half (…0100000.c:143-145,184-186); only the half the solve reads has to exist
             // (a rank that received a remote diagonal for its TSTRFs only may never get the L half)
             const bool want_upper = t->kernel_id == PANGULU_TASK_TSTRF;
@@ -1337,27 +1428,91 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 by_g += (2 * SV + 2) * (double)nnz_b + 4.0 * (nb + 1) + (SV + 2) * (double)host_nnz(lo, nb) + 4.0 * (nb + 1);
                 ng++;
             }
-            tasks[k] = T;
+            bool dense = false;
+#if defined(CALCULATE_TYPE_R64)
+            // dense path: the diagonal block left a dense LU image with inverted diagonal tiles (launch_getrf) and the
+            // block being solved is well filled or already lives in its mirror
+            if (dense_ok && B.opt_trsm_dense_permille <= 1000)
+            {
+                const double *lu = lu_image_of(half);
+                const bool filled = (u64)nnz_b * 1000ull >= (u64)B.opt_trsm_dense_permille * (u64)nb * (u64)nb;
+                if (lu && (filled || mirror_is_ahead(dst)))
+                {
+                    double *bm = current_mirror(dst, nb);
+                    if (bm)
+                    {
+                        TrsmDenseTaskD D;
+                        D.b = bm;
+                        D.lu = lu;
+                        D.is_tstrf = T.is_tstrf;
+                        D.pad_ = 0;
+                        dtasks[ndense] = D;
+                        // the flop counter wants the CSC view of the block in both cases
+                        T.vptr = dst->d_columnpointer;
+                        T.vidx = dst->d_rowindex;
+                        ftasks[ndense++] = T;
+                        solved_dense.push_back(dst);
+                        dense = true;
+                    }
+                }
+            }
+#endif
+            if (!dense)
+            {
+                require_sparse(dst, nb); // updates may have been accumulating in the block's mirror
+                tasks[nsparse++] = T;
+#if defined(CALCULATE_TYPE_R64)
+                auto it = MP.blocks.find(block_key(dst));
+                if (it != MP.blocks.end())
+                    it->second.mirror_current = false; // the sparse solve rewrites the record
+#endif
+            }
         }
-        commit_segment(seg);
 #if defined(CALCULATE_TYPE_R64)
         if (!MP.to_sparsify.empty())
             flush_mirror_jobs(nb, MP.to_sparsify, false);
-        for (size_t k = 0; k < take; k++)
-        {
-            auto it = MP.blocks.find(block_key(list[i + k]->opdst));
-            if (it != MP.blocks.end())
-                it->second.mirror_current = false; // the solve rewrites the sparse values
-        }
+        if (!MP.to_densify.empty())
+            flush_mirror_jobs(nb, MP.to_densify, true);
 #endif
+        commit_segment(seg);
         {
             LaunchTimer lt(nt >= ng ? 2 : 3);
-            int vblocks = (nb + TRSM_WAVES - 1) / TRSM_WAVES;
-            size_t lds = sizeof(val_t) * (size_t)nb * TRSM_WAVES;
-            hipLaunchKernelGGL(trsm_sparse_kernel, dim3((unsigned)(take * vblocks)), dim3(TRSM_WAVES * 64), lds, B.stream, d_tasks, nb,
-                               B.d_flops + 2, B.d_flops + 3);
+            if (nsparse)
+            {
+                int vblocks = (nb + TRSM_WAVES - 1) / TRSM_WAVES;
+                size_t lds = sizeof(val_t) * (size_t)nb * TRSM_WAVES;
+                hipLaunchKernelGGL(trsm_sparse_kernel, dim3((unsigned)(nsparse * vblocks)), dim3(TRSM_WAVES * 64), lds, B.stream, d_tasks,
+                                   nb, B.d_flops + 2, B.d_flops + 3);
+            }
+#if defined(CALCULATE_TYPE_R64)
+            if (ndense)
+                hipLaunchKernelGGL(trsm_dense_f64_kernel, dim3((unsigned)(ndense * (nb / 128))), dim3(256), 0, B.stream, d_dtasks, nb);
+#endif
             HIP_CHECK(hipGetLastError());
         }
+#if defined(CALCULATE_TYPE_R64)
+        if (ndense)
+        {
+            if (B.opt_count_flops)
+                hipLaunchKernelGGL(trsm_flop_count_kernel, dim3((unsigned)ndense), dim3(256), 0, B.stream, d_ftasks, nb, B.d_flops + 2,
+                                   B.d_flops + 3);
+            B.stats.trsm_dense_tasks += ndense;
+        }
+#endif
+        release_pending_segments();
+#if defined(CALCULATE_TYPE_R64)
+        // the solutions live in the mirrors: bring the sparse records (the authoritative form of a finished block) up
+        // to date at once; the mirrors stay valid as MFMA operands
+        for (slot_t *s : solved_dense)
+        {
+            BlockState &st = block_state(s, nb);
+            st.mirror_current = true;
+            MP.to_sparsify.push_back(mirror_job(s, st.mirror));
+            st.sparse_current = true;
+        }
+        if (!MP.to_sparsify.empty())
+            flush_mirror_jobs(nb, MP.to_sparsify, false);
+#endif
         // one launch serves both kinds; book it under the kind with more tasks, count tasks/bytes exactly
         B.stats.launches[nt >= ng ? 2 : 3]++;
         B.stats.tasks[2] += nt;
@@ -1397,6 +1552,9 @@ void launch_getrf(int nb, task_t **list, size_t n)
         size_t take = std::min(n - i, (size_t)B.getrf_scratch_slots);
         GetrfTaskD *d_tasks;
         GetrfTaskD *tasks = seg.alloc<GetrfTaskD>(take, &d_tasks);
+#if defined(CALCULATE_TYPE_R64)
+        std::vector<double *> lu_images; // dense images that will hold L\\U after this launch
+#endif
         double by = 0;
         for (size_t k = 0; k < take; k++)
         {
@@ -1414,35 +1572,40 @@ void launch_getrf(int nb, task_t **list, size_t n)
             T.pad_ = 0;
 #if defined(CALCULATE_TYPE_R64)
             {
-                auto it = MP.blocks.find(block_key(lo));
-                if (it != MP.blocks.end() && it->second.brow == lo->brow_pos && it->second.bcol == lo->bcol_pos && it->second.mirror)
+                // work on the block's own mirror whenever the pool has one: it may already hold the block (updates
+                // accumulated there), and the dense LU it is left with serves the dense TSTRF/GESSM of this level
+                BlockState &st = block_state(lo, nb);
+                if (blocked_kernel)
                 {
-                    BlockState &st = it->second;
-                    if (!st.sparse_current)
+                    double *m = dense_mode_available(nb) ? obtain_mirror(st, nb) : nullptr;
+                    if (m)
                     {
-                        if (blocked_kernel)
-                        {
-                            T.dense = st.mirror; // the mirror IS the dense image the blocked kernel works on
-                            T.preloaded = 1;
-                        }
-                        else
-                        {
-                            MP.to_sparsify.push_back(mirror_job(lo, st.mirror));
-                        }
-                        st.sparse_current = true;
+                        T.dense = m;
+                        T.preloaded = (st.mirror_current && !st.sparse_current) ? 1u : 0u;
+                        lu_images.push_back(m);
+                        st.lu_image = true;
                     }
-                    st.mirror_current = false;
+                    else if (!st.sparse_current && st.mirror)
+                    {
+                        MP.to_sparsify.push_back(mirror_job(lo, st.mirror));
+                    }
                 }
+                else if (!st.sparse_current && st.mirror)
+                {
+                    MP.to_sparsify.push_back(mirror_job(lo, st.mirror));
+                }
+                st.sparse_current = true;
+                st.mirror_current = false;
             }
 #endif
             tasks[k] = T;
             by += (2 * SV + 2) * ((double)host_nnz(lo, nb) + host_nnz(up, nb)) + 8.0 * (nb + 1);
         }
-        commit_segment(seg);
 #if defined(CALCULATE_TYPE_R64)
         if (!MP.to_sparsify.empty())
             flush_mirror_jobs(nb, MP.to_sparsify, false);
 #endif
+        commit_segment(seg);
         {
             LaunchTimer lt(1);
             bool blocked = blocked_kernel;
@@ -1468,6 +1631,18 @@ void launch_getrf(int nb, task_t **list, size_t n)
             }
             HIP_CHECK(hipGetLastError());
         }
+#if defined(CALCULATE_TYPE_R64)
+        if (!lu_images.empty())
+        {
+            // invert the 16 x 16 diagonal tiles of the fresh LU images in place (pg_hip_trsm_dense.h)
+            double **d_imgs;
+            double **imgs = seg.alloc<double *>(lu_images.size(), &d_imgs);
+            memcpy(imgs, lu_images.data(), sizeof(double *) * lu_images.size());
+            hipLaunchKernelGGL(diag_tile_inverse_kernel, dim3((unsigned)(lu_images.size() * (nb / 16))), dim3(64), 0, B.stream, d_imgs, nb);
+            HIP_CHECK(hipGetLastError());
+        }
+#endif
+        release_pending_segments();
         B.stats.launches[1]++;
         B.stats.tasks[1] += take;
         B.stats.alg_bytes[1] += by;
@@ -1661,6 +1836,7 @@ extern "C"
         if (B.opt_assume_independent)
         {
             process_run(nb, tasks, (size_t)ntask, l_getrf, l_trsm, l_ssssm);
+            release_pending_segments();
             return;
         }
         // The reference executes the array serially (...0201000.cu:875-898).  Keep that meaning: cut the array
@@ -1694,6 +1870,7 @@ extern "C"
             written[d] = t.kernel_id;
         }
         process_run(nb, tasks + run_begin, (size_t)ntask - run_begin, l_getrf, l_trsm, l_ssssm);
+        release_pending_segments();
     }
 
     void pangulu_platform_0201001_ssssm_batched(pangulu_inblock_idx nb, pangulu_uint64_t ntask, pangulu_task_t *tasks)
@@ -1797,6 +1974,9 @@ extern "C"
             return 0;
         case PANGULU_HIP_OPT_SSSSM_GROUP_CHUNK:
             B.opt_group_chunk = value;
+            return 0;
+        case PANGULU_HIP_OPT_TRSM_DENSE_PERMILLE:
+            B.opt_trsm_dense_permille = value;
             return 0;
         case PANGULU_HIP_OPT_RESET_BLOCK_STATE:
         {

@@ -1,0 +1,209 @@
+// pg_hip_trsm_dense.h -- TSTRF / GESSM on dense mirrors with the f64 matrix cores (R64; included after pg_hip_dense.h).
+//
+// The sparse solve (trsm_sparse_kernel) walks a row/column entry by entry: nb strictly sequential steps, each
+// waiting on L2 -- about a millisecond for a well-filled 256 x 256 block, on the critical path of every level.
+// Here the block is solved panel by panel (16 columns / rows at a time) on its dense mirror:
+//     TSTRF  X U = B :  X_p = (B_p - sum_{q<p} X_q U_qp) inv(U_pp)        p = 0..nb/16-1, column panels
+//     GESSM  L X = B :  X_p = inv(L_pp) (B_p - sum_{q<p} L_pq X_q)        row panels
+// with every product on v_mfma_f64_16x16x4_f64 and only nb/16 dependent steps.  The diagonal block comes as a dense
+// "LU image" (L strictly below, U on and above the diagonal, as GETRF leaves its dense work image) whose 16 x 16
+// diagonal tiles have been replaced by their inverses (upper part: inv(U_pp); strictly lower part: inv(L_pp) without
+// its unit diagonal) by diag_tile_inverse_kernel.  Inverting 16 x 16 tiles instead of substituting through them is
+// what dense GPU TRSMs do; it costs at most a few ulps more than substitution on these tiny, pivot-clamped tiles.
+//
+// Accumulators are laid out so that they load/store 128-byte column segments AND feed the final tile multiply as its
+// B operand without a shuffle: TSTRF accumulates X^T tiles (register g of lane l = X(r0 + (l&15), 16p + (l>>4) + 4g)),
+// GESSM accumulates X tiles (register g = X(16p + (l>>4) + 4g, c0 + (l&15))).
+#pragma once
+
+struct TrsmDenseTaskD
+{
+    double *b;        // mirror of the block being solved, overwritten by the solution
+    const double *lu; // LU image of the diagonal block with inverted diagonal tiles
+    u32 is_tstrf;
+    u32 pad_;
+};
+
+// one wavefront per 16 x 16 diagonal tile: lane c < 16 computes column c of inv(U_pp) (back substitution) and of
+// inv(L_pp) (forward substitution, unit diagonal), then the tile is overwritten
+__global__ __launch_bounds__(64) void diag_tile_inverse_kernel(double *const *__restrict__ images, int nb)
+{
+    __shared__ double T[16][17];
+    double *D = images[blockIdx.x / (nb / 16)];
+    const int p = blockIdx.x % (nb / 16), lane = threadIdx.x;
+    const size_t base = (size_t)(16 * p) * nb + 16 * p;
+    for (int i = lane; i < 256; i += 64)
+        T[i & 15][i >> 4] = D[base + (size_t)(i >> 4) * nb + (i & 15)]; // T[row][col]
+    __syncthreads();
+    double xu[16], xl[16];
+    if (lane < 16)
+    {
+        const int c = lane;
+        // U x = e_c  (upper, pivots clamped like the factorisation clamps them)
+#pragma unroll
+        for (int r = 15; r >= 0; r--)
+        {
+            double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 15; k > r; k--)
+                s -= T[r][k] * xu[k];
+            double piv = T[r][r];
+            if ((piv < 0 ? -piv : piv) < PANGULU_TOL)
+                piv = PANGULU_TOL;
+            xu[r] = (r > c) ? 0.0 : s / piv;
+        }
+        // L x = e_c  (unit lower)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; k++)
+                s -= T[r][k] * xl[k];
+            xl[r] = (r < c) ? 0.0 : s;
+        }
+    }
+    __syncthreads();
+    if (lane < 16)
+    {
+        const int c = lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            D[base + (size_t)c * nb + r] = (r <= c) ? xu[r] : xl[r];
+    }
+}
+
+// grid = tasks * (nb / 128); workgroup = 4 wavefronts; wave w owns 32 of the workgroup's 128 rows (TSTRF) or columns
+// (GESSM): two 16-wide tiles per panel step
+__global__ __launch_bounds__(256) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks, int nb)
+{
+    const int slabs = nb / 128;
+    const TrsmDenseTaskD T = tasks[blockIdx.x / slabs];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int o0 = (blockIdx.x % slabs) * 128 + wave * 32; // first of this wave's 32 rows (TSTRF) / columns (GESSM)
+    double *__restrict__ Bm = T.b;
+    const double *__restrict__ LU = T.lu;
+    const int npanel = nb / 16;
+
+    for (int p = 0; p < npanel; p++)
+    {
+        v4f64 acc[2];
+        if (T.is_tstrf)
+        {
+            // acc[t][g] = B(o0 + 16t + l15, 16p + l4 + 4g)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    acc[t][g] = Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + 16 * t + l15];
+            for (int q = 0; q < p; q++)
+            {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++)
+                {
+                    // A'[i = c][k] = -U(16q + k, 16p + c);  B'[k][j = r] = X(r, 16q + k)
+                    const double a = -LU[(size_t)(16 * p + l15) * nb + 16 * q + kq * 4 + l4];
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+                    {
+                        const double b = Bm[(size_t)(16 * q + kq * 4 + l4) * nb + o0 + 16 * t + l15];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            // X_p^T = inv(U_pp)^T acc^T :  A''[i = c'][k = c] = invU(c, c'), B''[k = c][j = r] = acc register c>>2...
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+            {
+                v4f64 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++)
+                {
+                    const int c = kq * 4 + l4, cp = l15;       // invU(c, c'), zero below the diagonal (c > c')
+                    const double a = (c <= cp) ? LU[(size_t)(16 * p + cp) * nb + 16 * p + c] : 0.0;
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[t][kq], x, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + 16 * t + l15] = x[g];
+            }
+        }
+        else
+        {
+            // acc[t][g] = B(16p + l4 + 4g, o0 + 16t + l15)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    acc[t][g] = Bm[(size_t)(o0 + 16 * t + l15) * nb + 16 * p + l4 + 4 * g];
+            for (int q = 0; q < p; q++)
+            {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++)
+                {
+                    // A[i = r][k] = -L(16p + r, 16q + k);  B[k][j = c] = X(16q + k, c)
+                    const double a = -LU[(size_t)(16 * q + kq * 4 + l4) * nb + 16 * p + l15];
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+                    {
+                        const double b = Bm[(size_t)(o0 + 16 * t + l15) * nb + 16 * q + kq * 4 + l4];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            // X_p = inv(L_pp) acc :  A[i = r'][k = r] = invL(r', r) (unit diagonal, zero above), B[k = r][j = c] = acc
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+            {
+                v4f64 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++)
+                {
+                    const int r = kq * 4 + l4, rp = l15;
+                    const double a = (rp > r) ? LU[(size_t)(16 * p + r) * nb + 16 * p + rp] : ((rp == r) ? 1.0 : 0.0);
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[t][kq], x, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    Bm[(size_t)(o0 + 16 * t + l15) * nb + 16 * p + l4 + 4 * g] = x[g];
+            }
+        }
+        // the panel just written is read (by this same wavefront only: rows/columns are private to it) in the next
+        // steps: make the stores visible to its own later loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+}
+
+// structural flops of the solves that ran on the dense path (src/pangulu_kernel_interface.c:84-159): one workgroup
+// per task.  T carries the CSC view of the solved block in vptr/vidx and the factor's pointer array in tptr.
+//   TSTRF: every entry (r, c) costs 1 division + 2 per entry of U's row c right of the diagonal
+//   GESSM: every entry (r, c) costs 2 per entry of L's column r
+__global__ __launch_bounds__(256) void trsm_flop_count_kernel(const TrsmTaskD *__restrict__ tasks, int nb,
+                                                              unsigned long long *flop_tstrf, unsigned long long *flop_gessm)
+{
+    const TrsmTaskD T = tasks[blockIdx.x];
+    unsigned long long s = 0;
+    if (T.is_tstrf)
+    {
+        for (int c = threadIdx.x; c < nb; c += blockDim.x)
+        {
+            const unsigned long long nbc = T.vptr[c + 1] - ptr0(T.vptr, c);
+            const unsigned long long nu = T.tptr[c + 1] - T.tptr[c];
+            if (nbc && nu)
+                s += nbc * (1ull + 2ull * (nu - 1));
+        }
+    }
+    else
+    {
+        const u32 nnz = T.vptr[nb];
+        for (u32 p = threadIdx.x; p < nnz; p += blockDim.x)
+        {
+            const u32 r = T.vidx[p];
+            s += 2ull * (T.tptr[r + 1] - T.tptr[r]);
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0 && s)
+        atomicAdd(T.is_tstrf ? flop_tstrf : flop_gessm, s);
+}

@@ -183,4 +183,5 @@ def hip_stats(h_or_lib, reset=False):
         out[name] = dict(launches=int(st.launches[k]), tasks=int(st.tasks[k]), alg_bytes=float(st.alg_bytes[k]),
                          flops=float(st.flops[k]), elapsed_ms=float(st.elapsed_ms[k]))
     out["ssssm_dense_mfma"]["mfma_flops_executed"] = float(st.mfma_flops_executed)
+    out["tstrf"]["dense_path_tasks"] = int(st.trsm_dense_tasks)  # TSTRF + GESSM tasks solved on the matrix cores
     return out

@@ -79,21 +79,25 @@ DENSE_MODE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("permille", [1, 60, 150, 1001])
+@pytest.mark.parametrize("permille", [0, 40, 100, 1001])
 @pytest.mark.parametrize("name,gen,nb,ordering", DENSE_MODE_CASES, ids=[c[0] for c in DENSE_MODE_CASES])
 def test_dense_mode_thresholds(name, gen, nb, ordering, permille):
-    """Every mix of dense-mode (mirrored, MFMA) and sparse blocks must give the same factors: threshold 1 per mille
+    """Every mix of dense-mode (mirrored, MFMA) and sparse blocks must give the same factors: threshold 0
     mirrors every block (zero-filled dense images of very sparse blocks included), 1001 disables dense mode."""
     from pangulu_amd import _lib
 
     mat = gen()
-    gpu = factorize(mat, nb, "hip", ordering=ordering, hip_options={_lib.HIP_OPT_DENSE_THRESHOLD_PERMILLE: permille})
+    # the solves follow: every TSTRF/GESSM on the dense MFMA path at 0, none at 1001
+    gpu = factorize(mat, nb, "hip", ordering=ordering, hip_options={_lib.HIP_OPT_DENSE_THRESHOLD_PERMILLE: permille,
+                                                                     _lib.HIP_OPT_TRSM_DENSE_PERMILLE: permille})
     ref = factorize(mat, nb, oracle_library("r64"), ordering=ordering)
     st = gpu["hip_stats"]
-    if permille == 1:
+    if permille == 0:
         assert st["ssssm_dense_mfma"]["tasks"] > 0 and st["ssssm_sparse"]["tasks"] == 0, st
+    if permille == 0:
+        assert st["tstrf"]["dense_path_tasks"] == st["tstrf"]["tasks"] + st["gessm"]["tasks"] > 0, st
     if permille == 1001:
-        assert st["ssssm_dense_mfma"]["tasks"] == 0
+        assert st["ssssm_dense_mfma"]["tasks"] == 0 and st["tstrf"]["dense_path_tasks"] == 0
     for f in ("L", "U"):
         assert max_rel_diff(gpu[f], ref[f]) <= 1e-12, (name, f, permille)
     assert gpu["residual"] <= 1e-12 and lu_check(mat, gpu) <= 1e-12
