@@ -224,7 +224,7 @@ extern "C"
      *     block values behind the back-end's back (bench.py's reset between repeated factorisations) must call it. */
 #define PANGULU_HIP_OPT_COUNT_FLOPS 6
 #define PANGULU_HIP_OPT_RESET_BLOCK_STATE 7
-    /*   PANGULU_HIP_OPT_SSSSM_GROUP_CHUNK (default 8): updates queued on one destination run as one sequential pass
+    /*   PANGULU_HIP_OPT_SSSSM_GROUP_CHUNK (default 3): updates queued on one destination run as one sequential pass
      *     per destination column (deterministic, no atomics) while there are at most this many; longer queues are
      *     cut into chunks of this size that run concurrently and add their partial sums with floating-point
      *     atomics (results then vary in the last bits from run to run).  0 = never split. */

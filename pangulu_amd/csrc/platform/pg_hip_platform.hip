@@ -947,7 +947,7 @@ struct Backend
     long long opt_assume_independent = 0;
     long long opt_getrf_strict = 0;
     long long opt_count_flops = 1;
-    long long opt_group_chunk = 8;
+    long long opt_group_chunk = 3;
     long long opt_trsm_dense_permille = 100;
     double mfma_flops_executed = 0;
     // resources
@@ -1331,6 +1331,12 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         if (!MP.to_densify.empty())
             flush_mirror_jobs(nb, MP.to_densify, true);
 #endif
+        // longest queues first: workgroups are dispatched in grid order, so the big groups start at once and the small
+        // ones fill the tail of the launch
+        auto by_size = [](const SsssmGroupD &x, const SsssmGroupD &y)
+        { return (x.task_end - x.task_begin) > (y.task_end - y.task_begin); };
+        std::stable_sort(groups_s, groups_s + gs, by_size);
+        std::stable_sort(groups_d, groups_d + gd, by_size);
         commit_segment(seg);
         if (gs)
         {
@@ -1432,7 +1438,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
 #if defined(CALCULATE_TYPE_R64)
             // dense path: the diagonal block left a dense LU image with inverted diagonal tiles (launch_getrf) and the
             // block being solved is well filled or already lives in its mirror
-            if (dense_ok && B.opt_trsm_dense_permille <= 1000)
+            if (dense_ok && (nb == 128 || nb == 256) && B.opt_trsm_dense_permille <= 1000)
             {
                 const double *lu = lu_image_of(half);
                 const bool filled = (u64)nnz_b * 1000ull >= (u64)B.opt_trsm_dense_permille * (u64)nb * (u64)nb;
@@ -1485,8 +1491,10 @@ void launch_trsm(int nb, task_t **list, size_t n)
                                    nb, B.d_flops + 2, B.d_flops + 3);
             }
 #if defined(CALCULATE_TYPE_R64)
-            if (ndense)
-                hipLaunchKernelGGL(trsm_dense_f64_kernel, dim3((unsigned)(ndense * (nb / 128))), dim3(256), 0, B.stream, d_dtasks, nb);
+            if (ndense && nb == 256)
+                hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, B.stream, d_dtasks);
+            else if (ndense)
+                hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, B.stream, d_dtasks);
 #endif
             HIP_CHECK(hipGetLastError());
         }

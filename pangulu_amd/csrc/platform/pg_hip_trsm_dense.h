@@ -73,105 +73,94 @@ __global__ __launch_bounds__(64) void diag_tile_inverse_kernel(double *const *__
     }
 }
 
-// grid = tasks * (nb / 128); workgroup = 4 wavefronts; wave w owns 32 of the workgroup's 128 rows (TSTRF) or columns
-// (GESSM): two 16-wide tiles per panel step
-__global__ __launch_bounds__(256) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks, int nb)
+// grid = tasks * (nb / 64); workgroup = 4 wavefronts; every wavefront solves 16 rows (TSTRF) or 16 columns (GESSM) of
+// the block on its own and keeps ALL its finished 16 x 16 solution tiles in registers (NP tiles x 4 f64): a finished
+// tile in accumulator layout is exactly the B operand the later panels need (register g <-> k = 4g + (l >> 4)), so the
+// only memory traffic inside the panel loop is the factor's tiles, which do not depend on anything computed here and
+// are therefore requested well ahead by the (fully unrolled) instruction stream.  No dependent round trips to L2.
+template <int NP>
+__global__ __launch_bounds__(256) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks)
 {
-    const int slabs = nb / 128;
+    constexpr int nb = NP * 16;
+    const int slabs = nb / 64;
     const TrsmDenseTaskD T = tasks[blockIdx.x / slabs];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int o0 = (blockIdx.x % slabs) * 128 + wave * 32; // first of this wave's 32 rows (TSTRF) / columns (GESSM)
+    const int o0 = (blockIdx.x % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
     double *__restrict__ Bm = T.b;
     const double *__restrict__ LU = T.lu;
-    const int npanel = nb / 16;
+    v4f64 xs[NP];
 
-    for (int p = 0; p < npanel; p++)
+    if (T.is_tstrf)
     {
-        v4f64 acc[2];
-        if (T.is_tstrf)
+        // tile p, register g of lane l  <->  X(o0 + l15, 16p + l4 + 4g)
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                xs[p][g] = Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15];
+#pragma unroll
+        for (int p = 0; p < NP; p++)
         {
-            // acc[t][g] = B(o0 + 16t + l15, 16p + l4 + 4g)
+            v4f64 acc = xs[p];
 #pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    acc[t][g] = Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + 16 * t + l15];
             for (int q = 0; q < p; q++)
-            {
 #pragma unroll
                 for (int kq = 0; kq < 4; kq++)
                 {
-                    // A'[i = c][k] = -U(16q + k, 16p + c);  B'[k][j = r] = X(r, 16q + k)
+                    // A'[i = c][k] = -U(16q + k, 16p + c);  B'[k][j = r] = X(r, 16q + k) = xs[q][kq]
                     const double a = -LU[(size_t)(16 * p + l15) * nb + 16 * q + kq * 4 + l4];
-#pragma unroll
-                    for (int t = 0; t < 2; t++)
-                    {
-                        const double b = Bm[(size_t)(16 * q + kq * 4 + l4) * nb + o0 + 16 * t + l15];
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-                    }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xs[q][kq], acc, 0, 0, 0);
                 }
-            }
-            // X_p^T = inv(U_pp)^T acc^T :  A''[i = c'][k = c] = invU(c, c'), B''[k = c][j = r] = acc register c>>2...
+            // X_p^T = inv(U_pp)^T acc^T :  A''[i = c'][k = c] = invU(c, c') (zero below the diagonal), B''[k = c][j = r] = acc
+            v4f64 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+            for (int kq = 0; kq < 4; kq++)
             {
-                v4f64 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++)
-                {
-                    const int c = kq * 4 + l4, cp = l15;       // invU(c, c'), zero below the diagonal (c > c')
-                    const double a = (c <= cp) ? LU[(size_t)(16 * p + cp) * nb + 16 * p + c] : 0.0;
-                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[t][kq], x, 0, 0, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + 16 * t + l15] = x[g];
+                const int c = kq * 4 + l4, cp = l15;
+                const double a = (c <= cp) ? LU[(size_t)(16 * p + cp) * nb + 16 * p + c] : 0.0;
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[kq], x, 0, 0, 0);
             }
+            xs[p] = x;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] = x[g];
         }
-        else
+    }
+    else
+    {
+        // tile p, register g of lane l  <->  X(16p + l4 + 4g, o0 + l15)
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                xs[p][g] = Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g];
+#pragma unroll
+        for (int p = 0; p < NP; p++)
         {
-            // acc[t][g] = B(16p + l4 + 4g, o0 + 16t + l15)
+            v4f64 acc = xs[p];
 #pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    acc[t][g] = Bm[(size_t)(o0 + 16 * t + l15) * nb + 16 * p + l4 + 4 * g];
             for (int q = 0; q < p; q++)
-            {
 #pragma unroll
                 for (int kq = 0; kq < 4; kq++)
                 {
-                    // A[i = r][k] = -L(16p + r, 16q + k);  B[k][j = c] = X(16q + k, c)
+                    // A[i = r][k] = -L(16p + r, 16q + k);  B[k][j = c] = X(16q + k, c) = xs[q][kq]
                     const double a = -LU[(size_t)(16 * q + kq * 4 + l4) * nb + 16 * p + l15];
-#pragma unroll
-                    for (int t = 0; t < 2; t++)
-                    {
-                        const double b = Bm[(size_t)(o0 + 16 * t + l15) * nb + 16 * q + kq * 4 + l4];
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-                    }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xs[q][kq], acc, 0, 0, 0);
                 }
-            }
             // X_p = inv(L_pp) acc :  A[i = r'][k = r] = invL(r', r) (unit diagonal, zero above), B[k = r][j = c] = acc
+            v4f64 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+            for (int kq = 0; kq < 4; kq++)
             {
-                v4f64 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++)
-                {
-                    const int r = kq * 4 + l4, rp = l15;
-                    const double a = (rp > r) ? LU[(size_t)(16 * p + r) * nb + 16 * p + rp] : ((rp == r) ? 1.0 : 0.0);
-                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[t][kq], x, 0, 0, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    Bm[(size_t)(o0 + 16 * t + l15) * nb + 16 * p + l4 + 4 * g] = x[g];
+                const int r = kq * 4 + l4, rp = l15;
+                const double a = (rp > r) ? LU[(size_t)(16 * p + r) * nb + 16 * p + rp] : ((rp == r) ? 1.0 : 0.0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[kq], x, 0, 0, 0);
             }
+            xs[p] = x;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g] = x[g];
         }
-        // the panel just written is read (by this same wavefront only: rows/columns are private to it) in the next
-        // steps: make the stores visible to its own later loads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
     }
 }
 
