@@ -214,8 +214,11 @@ extern "C"
      *     dependent phases.  The native scheduler sets it. */
 #define PANGULU_HIP_OPT_PROFILE 3
 #define PANGULU_HIP_OPT_ASSUME_INDEPENDENT 4
-    /*   PANGULU_HIP_OPT_GETRF_STRICT_ORDER (default 0): 1 selects the pattern-driven GETRF kernel for every block
-     *     (the only one for value types other than R64); 0 lets R64 blocks use the LDS-blocked MFMA kernel. */
+    /*   PANGULU_HIP_OPT_GETRF_STRICT_ORDER (default 0): 1 = reproducible operation order everywhere: the
+     *     pattern-driven GETRF kernel for every block (the only one for value types other than R64) and the
+     *     one-entry-at-a-time sparse SSSSM kernel (fused multiply-adds in ascending pivot order, no LDS atomics);
+     *     0 lets R64 diagonal blocks use the LDS-blocked MFMA kernel and sparse updates run four op2 entries at a
+     *     time with LDS floating-point atomics. */
 #define PANGULU_HIP_OPT_GETRF_STRICT_ORDER 5
     /*   PANGULU_HIP_OPT_COUNT_FLOPS (default 1): also count the structural flops of updates that run on the dense
      *     MFMA kernel (one extra pass over op2's pattern per such task, like the reference's PERF counters

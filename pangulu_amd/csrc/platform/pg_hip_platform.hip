@@ -86,6 +86,17 @@ __host__ __device__ inline val_t v_div(val_t a, val_t b) { return a / b; }
 __host__ __device__ inline real_t v_realpart(val_t a) { return a; }
 #endif
 
+// LDS accumulator -= v with hardware floating-point atomics
+__device__ inline void lds_atomic_sub(val_t *dst, val_t v)
+{
+#ifdef PANGULU_COMPLEX
+    atomicAdd(&dst->re, -v.re);
+    atomicAdd(&dst->im, -v.im);
+#else
+    atomicAdd(dst, -v);
+#endif
+}
+
 // dst += v with hardware floating-point atomics (skips exact zeros: most of a dense column of a sparse update)
 __device__ inline void v_atomic_add(val_t *dst, val_t v)
 {
@@ -192,22 +203,34 @@ __device__ inline unsigned long long wave_sum(unsigned long long v)
 // destination column cb*WAVES + w of group g.
 // -----------------------------------------------------------------------------------------------------------------
 #define SSSSM_WAVES 4
+#ifndef SSSSM_SUBW
+#define SSSSM_SUBW 8 // lanes per op2 entry in the non-strict kernel (64 / SSSSM_SUBW entries in flight per wavefront)
+#endif
 
+// STRICT = true : one op2 entry at a time over the whole wavefront, every update a fused multiply-add applied in
+//                  ascending k: the order the FMA oracle restates, results reproducible bit for bit.
+// STRICT = false: four op2 entries at a time, one per quarter-wavefront (op1 columns of sparse blocks are short: a
+//                  full wavefront per column leaves most lanes idle and serialises on L2 latency); the four columns
+//                  may hit the same accumulator row in one instruction, so the LDS accumulator takes hardware
+//                  floating-point atomics (ds_add_f64 / ds_add_f32).  Products are rounded before the add.
+template <bool STRICT>
 __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const SsssmGroupD *__restrict__ groups,
-                                                                         const SsssmTaskD *__restrict__ tasks, int nb,
+                                                                         const SsssmTaskD *__restrict__ tasks, int nb, int cpw,
                                                                          unsigned long long *flop_counter)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     val_t *smem = reinterpret_cast<val_t *>(smem_raw);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int colblocks = (nb + SSSSM_WAVES - 1) / SSSSM_WAVES;
+    // a wavefront owns `cpw` adjacent destination columns, one after the other (big batches use cpw > 1: launching a
+    // workgroup per 4 columns costs more than the columns themselves, most of which no update touches)
+    const int colblocks = (nb + SSSSM_WAVES * cpw - 1) / (SSSSM_WAVES * cpw);
     const int g = blockIdx.x / colblocks;
-    const int j = (blockIdx.x % colblocks) * SSSSM_WAVES + wave;
-    if (j >= nb)
-        return;
+    const int jbase = ((blockIdx.x % colblocks) * SSSSM_WAVES + wave) * cpw;
     val_t *acc = smem + (size_t)wave * nb;
     const SsssmGroupD G = groups[g];
-
+    unsigned long long fmas = 0;
+    for (int j = jbase; j < jbase + cpw && j < nb; j++)
+    {
     // does any update of the group touch column j at all?  (cheap uniform scan; most columns of sparse blocks don't)
     bool any = false;
     for (u32 t = G.task_begin; t < G.task_end && !any; t++)
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
         any = bp[j + 1] > ptr0(bp, j);
     }
     if (!any)
-        return;
+        continue;
 
     u32 c0 = 0, c1 = 0, u0 = 0, u1 = 0;
     const bool atomic = G.atomic != 0;
@@ -242,7 +265,6 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
     }
     wave_lds_fence();
 
-    unsigned long long fmas = 0;
     for (u32 t = G.task_begin; t < G.task_end; t++)
     {
         const BlkView A = tasks[t].a, B = tasks[t].b;
@@ -259,6 +281,33 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
                 my_b = B.val[qb + lane];
                 my_a0 = ptr0(A.ptr, (int)my_k);
                 my_a1 = A.ptr[my_k + 1];
+            }
+            if (!STRICT)
+            {
+                const int sub = lane / SSSSM_SUBW, sl = lane % SSSSM_SUBW;
+                for (u32 i = 0; i < cnt; i += 64 / SSSSM_SUBW)
+                {
+                    const int src = (int)min(i + (u32)sub, cnt - 1);
+                    // (all lanes take part in every shuffle: a lane may be the source of another quarter's read)
+                    const u32 a0 = __shfl(my_a0, src, 64);
+                    const u32 a1s = __shfl(my_a1, src, 64);
+                    const u32 a1 = (i + (u32)sub < cnt) ? a1s : a0;
+#ifdef PANGULU_COMPLEX
+                    val_t bv;
+                    bv.re = __shfl(my_b.re, src, 64);
+                    bv.im = __shfl(my_b.im, src, 64);
+#else
+                    const val_t bv = __shfl(my_b, src, 64);
+#endif
+                    for (u32 r = a0 + (u32)sl; r < a1; r += SSSSM_SUBW)
+                    {
+                        const val_t prod = v_mul(A.val[r], bv);
+                        lds_atomic_sub(&acc[A.idx[r]], prod);
+                        fmas++;
+                    }
+                }
+                wave_lds_fence();
+                continue;
             }
             // four op2 entries per pass: the first 64 elements of their four op1 columns are requested together
             // (the walk is latency-bound: one column in flight per wavefront leaves the memory pipe idle), then
@@ -341,6 +390,8 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
                 G.uval[G.uvi[p]] = acc[G.uri[p]];
         }
     }
+    wave_lds_fence(); // the accumulator is reused for the next column
+    } // columns of this wavefront
     fmas = wave_sum(fmas);
     if (lane == 0 && fmas)
         atomicAdd(flop_counter, 2ull * fmas);
@@ -1341,10 +1392,19 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         if (gs)
         {
             LaunchTimer lt(4);
-            int colblocks = (nb + SSSSM_WAVES - 1) / SSSSM_WAVES;
+            // columns per wavefront: 1 unless the grid would exceed 2^20 workgroups (more parallel waves beat fewer launches:
+            // measured 176 ms vs 181 ms per factorisation of the bench matrix with an 8k-workgroup target)
+            int cpw = 1;
+            while (cpw < 64 && gs * (size_t)((nb + SSSSM_WAVES * cpw - 1) / (SSSSM_WAVES * cpw)) > ((size_t)1 << 20))
+                cpw *= 2;
+            int colblocks = (nb + SSSSM_WAVES * cpw - 1) / (SSSSM_WAVES * cpw);
             size_t lds = sizeof(val_t) * (size_t)nb * SSSSM_WAVES;
-            hipLaunchKernelGGL(ssssm_sparse_kernel, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, B.stream,
-                               d_groups_s, d_tasks_s, nb, B.d_flops + 4);
+            if (B.opt_getrf_strict)
+                hipLaunchKernelGGL(ssssm_sparse_kernel<true>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, B.stream,
+                                   d_groups_s, d_tasks_s, nb, cpw, B.d_flops + 4);
+            else
+                hipLaunchKernelGGL(ssssm_sparse_kernel<false>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, B.stream,
+                                   d_groups_s, d_tasks_s, nb, cpw, B.d_flops + 4);
             B.stats.launches[4]++;
             B.stats.tasks[4] += ns;
             B.stats.alg_bytes[4] += bytes_s;
