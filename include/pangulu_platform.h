@@ -236,6 +236,9 @@ extern "C"
      *     updates already live in a dense mirror) run as panel-wise dense solves on the matrix cores against the dense
      *     LU image GETRF leaves behind; 1001 keeps every solve on the sparse kernel. */
 #define PANGULU_HIP_OPT_TRSM_DENSE_PERMILLE 9
+    /*   PANGULU_HIP_OPT_TWO_STREAMS (default 1): run the MFMA update kernel of a batch on a side stream beside the LDS
+     *     update kernel (fork/join with events inside the call; everything else stays on the one in-order stream). */
+#define PANGULU_HIP_OPT_TWO_STREAMS 10
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an

@@ -990,6 +990,9 @@ struct Backend
     bool ready = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // side stream: the MFMA update kernel runs beside the LDS update kernel
+    hipStream_t stream3 = nullptr; // second side stream: GETRFs of a batch run beside its TSTRF/GESSM solves
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
     int nb_cfg = 0;
     // options
     long long opt_host_mirror = 1;
@@ -1000,6 +1003,7 @@ struct Backend
     long long opt_count_flops = 1;
     long long opt_group_chunk = 3;
     long long opt_trsm_dense_permille = 100;
+    long long opt_two_streams = 1;
     double mfma_flops_executed = 0;
     // resources
     Ring ring;
@@ -1030,6 +1034,12 @@ void ensure_ready()
     }
     HIP_CHECK(hipSetDevice(B.device));
     HIP_CHECK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&B.stream2, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&B.ev_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&B.ev_join, hipEventDisableTiming));
+    HIP_CHECK(hipStreamCreateWithFlags(&B.stream3, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&B.ev_fork3, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&B.ev_join3, hipEventDisableTiming));
     // Descriptors are written once by the host and read once per workgroup: the kernels read them straight from
     // pinned host memory (non-coherent, so the device L2 may cache them) instead of waiting for a staging copy per
     // launch (rocprofv3 showed ~1900 blit dispatches, ~50 ms, per factorisation of the bench matrix).
@@ -1117,21 +1127,22 @@ hipEvent_t take_event()
 struct LaunchTimer
 {
     int cls;
+    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    explicit LaunchTimer(int c) : cls(c)
+    explicit LaunchTimer(int c, hipStream_t stream = nullptr) : cls(c), st(stream ? stream : B.stream)
     {
         if (B.opt_profile)
         {
             a = take_event();
             b = take_event();
-            HIP_CHECK(hipEventRecord(a, B.stream));
+            HIP_CHECK(hipEventRecord(a, st));
         }
     }
     ~LaunchTimer()
     {
         if (B.opt_profile)
         {
-            HIP_CHECK(hipEventRecord(b, B.stream));
+            HIP_CHECK(hipEventRecord(b, st));
             B.pending_events.push_back(EventPair{a, b, cls});
         }
     }
@@ -1358,7 +1369,9 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             }
             // cut long queues into chunks that run concurrently and merge with atomics
             const size_t chunk = (size_t)(B.opt_group_chunk > 0 ? B.opt_group_chunk : 1 << 30);
-            const bool split = (ns - s0) > chunk || (nd - d0) > chunk;
+            // ... and a destination updated by both kernels at once (they run side by side on two streams) must take
+            // atomics from both
+            const bool split = (ns - s0) > chunk || (nd - d0) > chunk || ((ns > s0) && (nd > d0) && B.opt_two_streams);
             for (size_t c = s0; c < ns; c += chunk)
             {
                 G.task_begin = (u32)c;
@@ -1389,6 +1402,8 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         std::stable_sort(groups_s, groups_s + gs, by_size);
         std::stable_sort(groups_d, groups_d + gd, by_size);
         commit_segment(seg);
+        if (gs && gd && B.opt_two_streams)
+            HIP_CHECK(hipEventRecord(B.ev_fork, B.stream)); // mirrors are current from here on
         if (gs)
         {
             LaunchTimer lt(4);
@@ -1412,14 +1427,27 @@ void launch_ssssm(int nb, task_t **list, size_t n)
 #if defined(CALCULATE_TYPE_R64)
         if (gd)
         {
+            hipStream_t ds = B.stream;
+            const bool side = B.opt_two_streams && gs;
+            if (side)
             {
-                LaunchTimer lt(5);
+                // fork: the MFMA kernel starts as soon as the mirrors are ready and runs beside the LDS kernel (both
+                // are bound by memory latency and launch tails, not by a shared resource)
+                ds = B.stream2;
+                HIP_CHECK(hipStreamWaitEvent(ds, B.ev_fork, 0));
+            }
+            {
+                LaunchTimer lt(5, ds);
                 int tiles = nb / DG_TILE;
-                hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, B.stream, d_groups_d,
-                                   d_tasks_d, nb);
+                hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, ds, d_groups_d, d_tasks_d, nb);
             }
             if (B.opt_count_flops)
-                hipLaunchKernelGGL(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, B.stream, d_tasks_d, nb, B.d_flops + 5);
+                hipLaunchKernelGGL(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, ds, d_tasks_d, nb, B.d_flops + 5);
+            if (side)
+            {
+                HIP_CHECK(hipEventRecord(B.ev_join, ds));
+                HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join, 0)); // join before anything later on the main stream
+            }
             B.stats.launches[5]++;
             B.stats.tasks[5] += nd;
             B.stats.alg_bytes[5] += bytes_d;
@@ -1541,6 +1569,10 @@ void launch_trsm(int nb, task_t **list, size_t n)
             flush_mirror_jobs(nb, MP.to_densify, true);
 #endif
         commit_segment(seg);
+#if defined(CALCULATE_TYPE_R64)
+        if (ndense && nsparse && B.opt_two_streams)
+            HIP_CHECK(hipEventRecord(B.ev_fork, B.stream)); // mirrors and sparse records are current from here on
+#endif
         {
             LaunchTimer lt(nt >= ng ? 2 : 3);
             if (nsparse)
@@ -1551,10 +1583,22 @@ void launch_trsm(int nb, task_t **list, size_t n)
                                    nb, B.d_flops + 2, B.d_flops + 3);
             }
 #if defined(CALCULATE_TYPE_R64)
-            if (ndense && nb == 256)
-                hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, B.stream, d_dtasks);
-            else if (ndense)
-                hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, B.stream, d_dtasks);
+            if (ndense)
+            {
+                // the dense solves run beside the sparse ones (other blocks, same diagonal operands)
+                hipStream_t ds = (B.opt_two_streams && nsparse) ? B.stream2 : B.stream;
+                if (ds != B.stream)
+                    HIP_CHECK(hipStreamWaitEvent(ds, B.ev_fork, 0));
+                if (nb == 256)
+                    hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks);
+                else
+                    hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks);
+                if (ds != B.stream)
+                {
+                    HIP_CHECK(hipEventRecord(B.ev_join, ds));
+                    HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join, 0));
+                }
+            }
 #endif
             HIP_CHECK(hipGetLastError());
         }
@@ -1595,7 +1639,9 @@ void launch_trsm(int nb, task_t **list, size_t n)
 }
 
 // ---- GETRF -------------------------------------------------------------------------------------------------------
-void launch_getrf(int nb, task_t **list, size_t n)
+// `gs`: stream the factorisation kernels go to (the main stream, or a side stream that has already been made to wait
+// for everything these blocks depend on; the caller joins it back)
+void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs)
 {
     const int max_slots = 256;
     if (!B.getrf_scratch || B.nb_cfg != nb)
@@ -1669,13 +1715,17 @@ void launch_getrf(int nb, task_t **list, size_t n)
             tasks[k] = T;
             by += (2 * SV + 2) * ((double)host_nnz(lo, nb) + host_nnz(up, nb)) + 8.0 * (nb + 1);
         }
+        hipStream_t ks = gs;
 #if defined(CALCULATE_TYPE_R64)
         if (!MP.to_sparsify.empty())
-            flush_mirror_jobs(nb, MP.to_sparsify, false);
+        {
+            flush_mirror_jobs(nb, MP.to_sparsify, false); // (main stream) these blocks must see it: stay on the main stream
+            ks = B.stream;
+        }
 #endif
         commit_segment(seg);
         {
-            LaunchTimer lt(1);
+            LaunchTimer lt(1, ks);
             bool blocked = blocked_kernel;
 #if defined(CALCULATE_TYPE_R64)
             if (blocked)
@@ -1688,14 +1738,14 @@ void launch_getrf(int nb, task_t **list, size_t n)
                     lds_allowed = lds;
                 }
                 static const bool debug_stamps = getenv("PANGULU_HIP_DEBUG_GETRF") != nullptr;
-                hipLaunchKernelGGL(getrf_blocked_f64_kernel, dim3((unsigned)take), dim3(GETRF_BLOCKED_THREADS), lds, B.stream, d_tasks, nb,
+                hipLaunchKernelGGL(getrf_blocked_f64_kernel, dim3((unsigned)take), dim3(GETRF_BLOCKED_THREADS), lds, ks, d_tasks, nb,
                                    B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
             }
 #endif
             if (!blocked)
             {
                 size_t lds = (sizeof(val_t) * 2 + sizeof(u16) * 2) * (size_t)nb;
-                hipLaunchKernelGGL(getrf_kernel, dim3((unsigned)take), dim3(GETRF_THREADS), lds, B.stream, d_tasks, nb, B.d_flops + 1);
+                hipLaunchKernelGGL(getrf_kernel, dim3((unsigned)take), dim3(GETRF_THREADS), lds, ks, d_tasks, nb, B.d_flops + 1);
             }
             HIP_CHECK(hipGetLastError());
         }
@@ -1706,10 +1756,15 @@ void launch_getrf(int nb, task_t **list, size_t n)
             double **d_imgs;
             double **imgs = seg.alloc<double *>(lu_images.size(), &d_imgs);
             memcpy(imgs, lu_images.data(), sizeof(double *) * lu_images.size());
-            hipLaunchKernelGGL(diag_tile_inverse_kernel, dim3((unsigned)(lu_images.size() * (nb / 16))), dim3(64), 0, B.stream, d_imgs, nb);
+            hipLaunchKernelGGL(diag_tile_inverse_kernel, dim3((unsigned)(lu_images.size() * (nb / 16))), dim3(64), 0, ks, d_imgs, nb);
             HIP_CHECK(hipGetLastError());
         }
 #endif
+        if (ks != B.stream)
+        {
+            HIP_CHECK(hipEventRecord(B.ev_join3, ks));
+            HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join3, 0));
+        }
         release_pending_segments();
         B.stats.launches[1]++;
         B.stats.tasks[1] += take;
@@ -1769,8 +1824,17 @@ void process_run(int nb, task_t *tasks, size_t n, std::vector<task_t *> &getrf, 
                              return canon_dst(x->opdst) < canon_dst(y->opdst); });
     }
     launch_ssssm(nb, ssssm.data(), ssssm.size());
-    launch_getrf(nb, getrf.data(), getrf.size());
+    // The factorisations and the solves of one run are independent of each other: the GETRFs go to a side stream that
+    // waits only for what has been queued up to here (the updates), and run beside the TSTRF/GESSM kernels.
+    hipStream_t gstream = B.stream;
+    if (B.opt_two_streams && !getrf.empty() && !trsm.empty())
+    {
+        HIP_CHECK(hipEventRecord(B.ev_fork3, B.stream));
+        HIP_CHECK(hipStreamWaitEvent(B.stream3, B.ev_fork3, 0));
+        gstream = B.stream3;
+    }
     launch_trsm(nb, trsm.data(), trsm.size());
+    launch_getrf(nb, getrf.data(), getrf.size(), gstream);
 }
 
 } // namespace
@@ -2045,6 +2109,9 @@ extern "C"
             return 0;
         case PANGULU_HIP_OPT_TRSM_DENSE_PERMILLE:
             B.opt_trsm_dense_permille = value;
+            return 0;
+        case PANGULU_HIP_OPT_TWO_STREAMS:
+            B.opt_two_streams = value;
             return 0;
         case PANGULU_HIP_OPT_RESET_BLOCK_STATE:
         {
