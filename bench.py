@@ -47,7 +47,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[110, 110], help="shell nx ny of the CPU-baseline sample")
-    ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "host"), choices=["host", "rccl"])
+    ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "rccl"), choices=["host", "rccl"],
+                    help="block exchange for --gpus > 1: RCCL send/recv over xGMI (default; verified by a pairwise self-test at "
+                         "start-up, falling back to host staging on failure) or host-staged TCP")
     return ap.parse_args()
 
 
@@ -150,6 +152,8 @@ def main():
         transport = _lib.TRANSPORT_RCCL if args.transport == "rccl" else _lib.TRANSPORT_HOST
         rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port, transport, None)
         assert rc == 0
+        # what is really in use: RCCL falls back to host staging on all ranks when its pairwise self-test fails
+        args.transport = "rccl" if lib.pangulu_amd_comm_transport() == _lib.TRANSPORT_RCCL else "host"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

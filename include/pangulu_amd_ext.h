@@ -28,6 +28,8 @@ extern "C"
     void pangulu_amd_comm_barrier(void);
     void pangulu_amd_comm_allreduce_max_f64(double *values, int count);
     void pangulu_amd_comm_finalize(void);
+    /* transport in effect (RCCL falls back to HOST on all ranks together when its self-test fails) */
+    int pangulu_amd_comm_transport(void);
     int pangulu_amd_comm_rank(void);
     int pangulu_amd_comm_size(void);
 

@@ -134,6 +134,7 @@ def load(vtype="r64"):
     lib.pangulu_amd_comm_allreduce_max_f64.argtypes = [vp, ctypes.c_int]
     lib.pangulu_amd_comm_allreduce_max_f64.restype = None
     lib.pangulu_amd_comm_finalize.restype = None
+    lib.pangulu_amd_comm_transport.restype = ctypes.c_int
     lib.pangulu_amd_comm_rank.restype = ctypes.c_int
     lib.pangulu_amd_comm_size.restype = ctypes.c_int
     lib.pangulu_amd_use_platform_library.argtypes = [ctypes.c_char_p, ctypes.c_uint]

@@ -176,6 +176,7 @@ extern "C"
     void pangulu_amd_comm_allreduce_max_f64(double *values, int count) { world()->allreduce_max_f64(values, count); }
     void pangulu_amd_comm_finalize(void) { set_world(nullptr); }
     int pangulu_amd_rccl_unique_id(void *out128) { return rccl_make_unique_id(out128); }
+    int pangulu_amd_comm_transport(void) { return world()->transport; }
     int pangulu_amd_comm_rank(void) { return world()->rank; }
     int pangulu_amd_comm_size(void) { return world()->size; }
 

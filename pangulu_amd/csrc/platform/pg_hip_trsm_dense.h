@@ -75,93 +75,127 @@ __global__ __launch_bounds__(64) void diag_tile_inverse_kernel(double *const *__
 
 // grid = tasks * (nb / 64); workgroup = 4 wavefronts; every wavefront solves 16 rows (TSTRF) or 16 columns (GESSM) of
 // the block on its own and keeps ALL its finished 16 x 16 solution tiles in registers (NP tiles x 4 f64): a finished
-// tile in accumulator layout is exactly the B operand the later panels need (register g <-> k = 4g + (l >> 4)), so the
-// only memory traffic inside the panel loop is the factor's tiles, which do not depend on anything computed here and
-// are therefore requested well ahead by the (fully unrolled) instruction stream.  No dependent round trips to L2.
+// tile in accumulator layout is exactly the B operand the later panels need (register g <-> k = 4g + (l >> 4)).
+// The factor's panel (U(0:16p+16, panel p) for TSTRF, L(panel p, 0:16p+16) for GESSM) is the same for the four
+// wavefronts: it is staged through LDS once per workgroup (the next panel is prefetched into registers while the
+// current one is consumed), laid out so that the MFMA A-operand reads are conflict-free:
+//     TSTRF  sT[c * 258 + row]   (c = column within the panel)     GESSM  sT[k * 16 + r]   (r = row within the panel)
 template <int NP>
 __global__ __launch_bounds__(256) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks)
 {
     constexpr int nb = NP * 16;
+    constexpr int LDT = nb + 2;
+    __shared__ __align__(16) double sT[16 * LDT];
     const int slabs = nb / 64;
     const TrsmDenseTaskD T = tasks[blockIdx.x / slabs];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int o0 = (blockIdx.x % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
     double *__restrict__ Bm = T.b;
     const double *__restrict__ LU = T.lu;
+    const bool tstrf = T.is_tstrf != 0;
     v4f64 xs[NP];
 
-    if (T.is_tstrf)
-    {
-        // tile p, register g of lane l  <->  X(o0 + l15, 16p + l4 + 4g)
-#pragma unroll
-        for (int p = 0; p < NP; p++)
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                xs[p][g] = Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15];
-#pragma unroll
-        for (int p = 0; p < NP; p++)
-        {
-            v4f64 acc = xs[p];
-#pragma unroll
-            for (int q = 0; q < p; q++)
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++)
-                {
-                    // A'[i = c][k] = -U(16q + k, 16p + c);  B'[k][j = r] = X(r, 16q + k) = xs[q][kq]
-                    const double a = -LU[(size_t)(16 * p + l15) * nb + 16 * q + kq * 4 + l4];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xs[q][kq], acc, 0, 0, 0);
-                }
-            // X_p^T = inv(U_pp)^T acc^T :  A''[i = c'][k = c] = invU(c, c') (zero below the diagonal), B''[k = c][j = r] = acc
-            v4f64 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kq = 0; kq < 4; kq++)
-            {
-                const int c = kq * 4 + l4, cp = l15;
-                const double a = (c <= cp) ? LU[(size_t)(16 * p + cp) * nb + 16 * p + c] : 0.0;
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[kq], x, 0, 0, 0);
-            }
-            xs[p] = x;
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] = x[g];
-        }
+    // staging map: thread -> 16-byte pieces.  TSTRF panel p: column c = tid >> 4 of the panel, rows 2*(tid & 15) + 32 i
+    // (i < ceil((16p+16)/32)); GESSM panel p: column k = (tid >> 3) + 32 i of the factor, rows 2*(tid & 7) of the panel.
+    constexpr int NPIECE = (nb + 31) / 32;
+    double2 pre[NPIECE];
+    const int t_c = tid >> 4, t_r = 2 * (tid & 15);
+    const int g_k = tid >> 3, g_r = 2 * (tid & 7);
+
+#define TRSM_PREFETCH(p_)                                                                                         \
+    {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NPIECE; i++)                                                        \
+        {                                                                                                         \
+            pre[i] = make_double2(0.0, 0.0);                                                                      \
+            if (tstrf)                                                                                            \
+            {                                                                                                     \
+                const int row = t_r + 32 * i;                                                                     \
+                if (row < 16 * (p_) + 16)                                                                         \
+                    pre[i] = *reinterpret_cast<const double2 *>(LU + (size_t)(16 * (p_) + t_c) * nb + row);       \
+            }                                                                                                     \
+            else                                                                                                  \
+            {                                                                                                     \
+                const int k = g_k + 32 * i;                                                                       \
+                if (k < 16 * (p_) + 16)                                                                           \
+                    pre[i] = *reinterpret_cast<const double2 *>(LU + (size_t)k * nb + 16 * (p_) + g_r);           \
+            }                                                                                                     \
+        }                                                                                                         \
     }
-    else
+#define TRSM_STAGE(p_)                                                                                            \
+    {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NPIECE; i++)                                                        \
+        {                                                                                                         \
+            if (tstrf)                                                                                            \
+            {                                                                                                     \
+                const int row = t_r + 32 * i;                                                                     \
+                if (row < 16 * (p_) + 16)                                                                         \
+                    *reinterpret_cast<double2 *>(&sT[t_c * LDT + row]) = pre[i];                                  \
+            }                                                                                                     \
+            else                                                                                                  \
+            {                                                                                                     \
+                const int k = g_k + 32 * i;                                                                       \
+                if (k < 16 * (p_) + 16)                                                                           \
+                    *reinterpret_cast<double2 *>(&sT[k * 16 + g_r]) = pre[i];                                     \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+
+    // tile p, register g of lane l  <->  TSTRF: X(o0 + l15, 16p + l4 + 4g)    GESSM: X(16p + l4 + 4g, o0 + l15)
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            xs[p][g] = tstrf ? Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] : Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g];
+    TRSM_PREFETCH(0)
+#pragma unroll
+    for (int p = 0; p < NP; p++)
     {
-        // tile p, register g of lane l  <->  X(16p + l4 + 4g, o0 + l15)
+        __syncthreads(); // everyone is done with the previous panel's image
+        TRSM_STAGE(p)
+        __syncthreads();
+        if (p + 1 < NP)
+            TRSM_PREFETCH(p + 1)
+        // four independent accumulation chains (one per k-quarter of a tile): a single chain of up to 60 dependent
+        // MFMAs would leave the matrix core idle for most of each instruction's latency
+        v4f64 part[4];
+        part[0] = xs[p];
+        part[1] = part[2] = part[3] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int p = 0; p < NP; p++)
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                xs[p][g] = Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g];
-#pragma unroll
-        for (int p = 0; p < NP; p++)
-        {
-            v4f64 acc = xs[p];
-#pragma unroll
-            for (int q = 0; q < p; q++)
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++)
-                {
-                    // A[i = r][k] = -L(16p + r, 16q + k);  B[k][j = c] = X(16q + k, c) = xs[q][kq]
-                    const double a = -LU[(size_t)(16 * q + kq * 4 + l4) * nb + 16 * p + l15];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xs[q][kq], acc, 0, 0, 0);
-                }
-            // X_p = inv(L_pp) acc :  A[i = r'][k = r] = invL(r', r) (unit diagonal, zero above), B[k = r][j = c] = acc
-            v4f64 x = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < p; q++)
 #pragma unroll
             for (int kq = 0; kq < 4; kq++)
             {
-                const int r = kq * 4 + l4, rp = l15;
-                const double a = (rp > r) ? LU[(size_t)(16 * p + r) * nb + 16 * p + rp] : ((rp == r) ? 1.0 : 0.0);
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[kq], x, 0, 0, 0);
+                // TSTRF: A'[i = c][k] = -U(16q + k, 16p + c);  GESSM: A[i = r][k] = -L(16p + r, 16q + k);  B operand = xs[q][kq]
+                const int k = 16 * q + kq * 4 + l4;
+                const double a = tstrf ? -sT[l15 * LDT + k] : -sT[k * 16 + l15];
+                part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xs[q][kq], part[kq], 0, 0, 0);
             }
-            xs[p] = x;
+        v4f64 acc = (part[0] + part[1]) + (part[2] + part[3]);
+        // multiply by the inverted diagonal tile (upper part: inv(U_pp); strictly lower part: inv(L_pp), unit diagonal)
+        v4f64 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int g = 0; g < 4; g++)
+        for (int kq = 0; kq < 4; kq++)
+        {
+            const int k = kq * 4 + l4; // TSTRF: A''[i = c'][k = c] = invU(c, c');  GESSM: A[i = r'][k = r] = invL(r', r)
+            double a;
+            if (tstrf)
+                a = (k <= l15) ? sT[l15 * LDT + 16 * p + k] : 0.0;
+            else
+                a = (l15 > k) ? sT[(16 * p + k) * 16 + l15] : ((l15 == k) ? 1.0 : 0.0);
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[kq], x, 0, 0, 0);
+        }
+        xs[p] = x;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            if (tstrf)
+                Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] = x[g];
+            else
                 Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g] = x[g];
         }
     }
+#undef TRSM_PREFETCH
+#undef TRSM_STAGE
 }
 
 // structural flops of the solves that ran on the dense path (src/pangulu_kernel_interface.c:84-159): one workgroup

@@ -1,0 +1,42 @@
+// Stand-alone timing of trsm_dense_f64_kernel (pg_hip_trsm_dense.h)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+typedef double val_t;
+typedef unsigned int u32;
+typedef unsigned short u16;
+#define PANGULU_TOL 1e-16
+struct TrsmTaskD { const u32 *vptr; const u16 *vidx; const u32 *vmap; val_t *bval; const u32 *tptr; const u16 *tidx; const val_t *tval; u32 is_tstrf; u32 pad_; };
+__device__ inline u32 ptr0(const u32 *p, int i) { return i == 0 ? 0u : p[i]; }
+__device__ inline unsigned long long wave_sum(unsigned long long v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; }
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#include "../../pangulu_amd/csrc/platform/pg_hip_trsm_dense.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+int main(int argc, char **argv)
+{
+    int nb = 256, ntask = argc > 1 ? atoi(argv[1]) : 1024, tstrf = argc > 2 ? atoi(argv[2]) : 1, nlu = argc > 3 ? atoi(argv[3]) : 64;
+    size_t mb = (size_t)nb * nb;
+    double *pool;
+    int nmir = ntask + nlu;
+    CK(hipMalloc(&pool, sizeof(double) * mb * nmir));
+    std::vector<double> h(mb);
+    for (size_t i = 0; i < mb; i++) h[i] = ((double)rand() / RAND_MAX - 0.5) * 0.01;
+    for (int i = 0; i < nb; i++) h[(size_t)i * nb + i] = 1.0;
+    for (int i = 0; i < nmir; i++) CK(hipMemcpy(pool + (size_t)i * mb, h.data(), sizeof(double) * mb, hipMemcpyHostToDevice));
+    std::vector<TrsmDenseTaskD> T(ntask);
+    for (int t = 0; t < ntask; t++) { T[t].b = pool + (size_t)t * mb; T[t].lu = pool + (size_t)(ntask + t % nlu) * mb; T[t].is_tstrf = tstrf; T[t].pad_ = 0; }
+    TrsmDenseTaskD *dT; CK(hipMalloc(&dT, sizeof(TrsmDenseTaskD) * ntask));
+    CK(hipMemcpy(dT, T.data(), sizeof(TrsmDenseTaskD) * ntask, hipMemcpyHostToDevice));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 3; rep++)
+    {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3(ntask * (nb / 64)), dim3(256), 0, 0, dT);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("tasks %d tstrf %d distinct LU %d: %.3f ms  %.2f us/task  %.2f TFLOP/s (nb^3 per task)\n", ntask, tstrf, nlu, ms, 1e3 * ms / ntask, (double)nb * nb * nb * ntask / ms / 1e9);
+    }
+    return 0;
+}
