@@ -239,6 +239,9 @@ extern "C"
     /*   PANGULU_HIP_OPT_TWO_STREAMS (default 1): run the MFMA update kernel of a batch on a side stream beside the LDS
      *     update kernel (fork/join with events inside the call; everything else stays on the one in-order stream). */
 #define PANGULU_HIP_OPT_TWO_STREAMS 10
+    /*   PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS (default 512): an update launch with at most this many tasks gives every
+     *     update its own workgroups (chunk 1) - near the root of the elimination tree latency matters, not traffic. */
+#define PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS 11
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an

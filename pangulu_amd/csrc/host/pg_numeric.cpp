@@ -127,12 +127,17 @@ struct Sched
     Platform &plat;
     Comm *comm;
     std::vector<char> sent_flag;
-    std::vector<task_t> batch, ssssm_batch;
+    std::vector<task_t> batch, ssssm_batch, combined;
+    size_t lookahead_max_getrf = 8;  // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
     double t_platform = 0;
     u64 batches = 0;
     bool multi;
 
-    explicit Sched(Solver &s) : S(s), P(s.pat), plat(active_platform()), comm(world()), sent_flag((size_t)s.nproc, 0), multi(s.nproc > 1) {}
+    explicit Sched(Solver &s) : S(s), P(s.pat), plat(active_platform()), comm(world()), sent_flag((size_t)s.nproc, 0), multi(s.nproc > 1)
+    {
+        if (const char *e = getenv("PANGULU_AMD_LOOKAHEAD_MAX_GETRF"))
+            lookahead_max_getrf = (size_t)atol(e);
+    }
 
     // ---- task creation -------------------------------------------------------------------------------
     void push_panel(u32 row, u32 col, u32 level, int kernel, slot_t *dst, slot_t *op1)
@@ -435,6 +440,11 @@ struct Sched
         if (ssssm_batch.empty())
             return;
         run_platform_batch(ssssm_batch);
+        release_update_operands();
+    }
+
+    void release_update_operands()
+    {
         if (multi)
         {
             // operands received from other ranks are dropped once their last consumer has run
@@ -485,8 +495,31 @@ struct Sched
                 rebuild_dirty_list();
         }
         run_updates_and_release_operands();
-        // (2) the panel tasks themselves
-        run_platform_batch(batch);
+        // (2) the panel tasks themselves.  A few diagonal factorisations on their own leave the device almost idle
+        // (one workgroup each): every update queued anywhere else goes into the same call, the back-end runs the
+        // two kinds side by side
+        bool lookahead = false;
+        if (batch.size() <= lookahead_max_getrf && S.pending_total != 0)
+        {
+            lookahead = true;
+            for (auto &t : batch)
+                lookahead = lookahead && t.kernel_id == PANGULU_TASK_GETRF;
+        }
+        if (lookahead)
+        {
+            {
+                std::lock_guard<std::mutex> g(S.info_mutex);
+                for (u32 tile : S.pending_dirty)
+                    take_pending(tile);
+                S.pending_dirty.clear();
+            }
+            combined.assign(batch.begin(), batch.end());
+            combined.insert(combined.end(), ssssm_batch.begin(), ssssm_batch.end());
+            run_platform_batch(combined);
+            release_update_operands();
+        }
+        else
+            run_platform_batch(batch);
         if (multi)
         {
             plat.synchronize(); // finished blocks are about to be sent

@@ -142,34 +142,56 @@ struct MirrorJobD
     double *dense;  // nb x nb column-major
 };
 
+// grid = (jobs, slices): a workgroup owns a run of columns of one block, so that a launch with a single job (the tail
+// of the elimination tree) still spreads over many CUs
 __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restrict__ jobs, int nb)
 {
     const MirrorJobD J = jobs[blockIdx.x];
-    double2 *d2 = reinterpret_cast<double2 *>(J.dense);
-    for (int i = threadIdx.x; i < nb * nb / 2; i += blockDim.x)
-        d2[i] = make_double2(0.0, 0.0);
+    const int per = (nb + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c0 = (int)blockIdx.y * per, c1 = min(nb, c0 + per);
+    if (c0 >= c1)
+        return;
+    double *base = J.dense + (size_t)c0 * nb;
+    const int words = (c1 - c0) * nb;
+    if ((words & 1) == 0 && (((size_t)c0 * nb) & 1) == 0)
+    {
+        double2 *d2 = reinterpret_cast<double2 *>(base); // mirrors are 16-byte aligned
+        for (int i = threadIdx.x; i < words / 2; i += blockDim.x)
+            d2[i] = make_double2(0.0, 0.0);
+    }
+    else
+        for (int i = threadIdx.x; i < words; i += blockDim.x)
+            base[i] = 0.0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int c = wave; c < nb; c += nw)
-    {
+    for (int c = c0 + wave; c < c1; c += nw)
         for (u32 p = ptr0(J.lo.ptr, c) + lane; p < J.lo.ptr[c + 1]; p += 64)
             J.dense[(size_t)c * nb + J.lo.idx[p]] = J.lo.val[p];
-        if (J.up.ptr)
-            for (u32 p = J.up.ptr[c] + lane; p < J.up.ptr[c + 1]; p += 64) // c is a row of the CSR half here
-                J.dense[(size_t)J.up.idx[p] * nb + c] = J.up.val[p];
+    if (J.up.ptr)
+    {
+        // the CSR half of a diagonal block: every workgroup walks all rows and keeps the entries of its own columns
+        for (int r = wave; r < nb; r += nw)
+            for (u32 p = J.up.ptr[r] + lane; p < J.up.ptr[r + 1]; p += 64)
+            {
+                const int c = J.up.idx[p];
+                if (c >= c0 && c < c1)
+                    J.dense[(size_t)c * nb + r] = J.up.val[p];
+            }
     }
 }
 
 __global__ __launch_bounds__(256) void sparsify_kernel(const MirrorJobD *__restrict__ jobs, int nb)
 {
     const MirrorJobD J = jobs[blockIdx.x];
+    const int per = (nb + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c0 = (int)blockIdx.y * per, c1 = min(nb, c0 + per);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int c = wave; c < nb; c += nw)
+    for (int c = c0 + wave; c < c1; c += nw)
     {
         for (u32 p = ptr0(J.lo.ptr, c) + lane; p < J.lo.ptr[c + 1]; p += 64)
             J.lo.val[p] = J.dense[(size_t)c * nb + J.lo.idx[p]];
         if (J.up.ptr)
-            for (u32 p = J.up.ptr[c] + lane; p < J.up.ptr[c + 1]; p += 64)
+            for (u32 p = J.up.ptr[c] + lane; p < J.up.ptr[c + 1]; p += 64) // c is a row of the CSR half here
                 J.up.val[p] = J.dense[(size_t)J.up.idx[p] * nb + c];
     }
 }

@@ -194,10 +194,13 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify)
         MirrorJobD *h = seg.alloc<MirrorJobD>(take, &d_jobs);
         memcpy(h, jobs.data() + i, sizeof(MirrorJobD) * take);
         commit_segment(seg);
+        // few jobs: cut every block into column runs so the launch still covers the chip
+        unsigned slices = take >= 2048 ? 1u : take >= 512 ? 4u : 16u;
+        slices = std::min<unsigned>(slices, (unsigned)std::max(1, nb / 8));
         if (densify)
-            hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take), dim3(256), 0, B.stream, d_jobs, nb);
+            hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, B.stream, d_jobs, nb);
         else
-            hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take), dim3(256), 0, B.stream, d_jobs, nb);
+            hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take, slices), dim3(256), 0, B.stream, d_jobs, nb);
         HIP_CHECK(hipGetLastError());
         release_pending_segments(); // (callers commit their own segment only after this returns)
         i += take;

@@ -993,6 +993,7 @@ struct Backend
     hipStream_t stream2 = nullptr; // side stream: the MFMA update kernel runs beside the LDS update kernel
     hipStream_t stream3 = nullptr; // second side stream: GETRFs of a batch run beside its TSTRF/GESSM solves
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
+    bool getrf_join_pending = false;
     int nb_cfg = 0;
     // options
     long long opt_host_mirror = 1;
@@ -1002,6 +1003,7 @@ struct Backend
     long long opt_getrf_strict = 0;
     long long opt_count_flops = 1;
     long long opt_group_chunk = 3;
+    long long opt_small_launch_tasks = 512;
     long long opt_trsm_dense_permille = 100;
     long long opt_two_streams = 1;
     double mfma_flops_executed = 0;
@@ -1078,12 +1080,12 @@ struct Segment
 // Record, behind everything launched so far, that the committed segments may be reused.  Must be called AFTER the
 // kernels reading those segments have been launched (an event recorded earlier would let the host overwrite a
 // segment a queued kernel has yet to read).
-void release_pending_segments()
+void release_pending_segments(hipStream_t on = nullptr)
 {
     Ring &r = B.ring;
     for (int i : r.pending)
     {
-        HIP_CHECK(hipEventRecord(r.ev[i], B.stream));
+        HIP_CHECK(hipEventRecord(r.ev[i], on ? on : B.stream));
         r.used[i] = true;
     }
     r.pending.clear();
@@ -1368,7 +1370,10 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 }
             }
             // cut long queues into chunks that run concurrently and merge with atomics
-            const size_t chunk = (size_t)(B.opt_group_chunk > 0 ? B.opt_group_chunk : 1 << 30);
+            // (a launch with few updates cannot fill the chip with whole queues: one update per workgroup then)
+            size_t chunk = (size_t)(B.opt_group_chunk > 0 ? B.opt_group_chunk : 1 << 30);
+            if (B.opt_group_chunk > 0 && take <= (size_t)B.opt_small_launch_tasks)
+                chunk = 1;
             // ... and a destination updated by both kernels at once (they run side by side on two streams) must take
             // atomics from both
             const bool split = (ns - s0) > chunk || (nd - d0) > chunk || ((ns > s0) && (nd > d0) && B.opt_two_streams);
@@ -1641,7 +1646,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
 // ---- GETRF -------------------------------------------------------------------------------------------------------
 // `gs`: stream the factorisation kernels go to (the main stream, or a side stream that has already been made to wait
 // for everything these blocks depend on; the caller joins it back)
-void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs)
+void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_join)
 {
     const int max_slots = 256;
     if (!B.getrf_scratch || B.nb_cfg != nb)
@@ -1763,9 +1768,12 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs)
         if (ks != B.stream)
         {
             HIP_CHECK(hipEventRecord(B.ev_join3, ks));
-            HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join3, 0));
+            if (defer_join && !B.opt_host_mirror)
+                B.getrf_join_pending = true; // the caller makes the main stream wait once its own kernels are queued
+            else
+                HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join3, 0));
         }
-        release_pending_segments();
+        release_pending_segments(ks); // (the descriptors are read on ks, which the main stream may not have joined yet)
         B.stats.launches[1]++;
         B.stats.tasks[1] += take;
         B.stats.alg_bytes[1] += by;
@@ -1823,18 +1831,27 @@ void process_run(int nb, task_t *tasks, size_t n, std::vector<task_t *> &getrf, 
                          {
                              return canon_dst(x->opdst) < canon_dst(y->opdst); });
     }
-    launch_ssssm(nb, ssssm.data(), ssssm.size());
-    // The factorisations and the solves of one run are independent of each other: the GETRFs go to a side stream that
-    // waits only for what has been queued up to here (the updates), and run beside the TSTRF/GESSM kernels.
-    hipStream_t gstream = B.stream;
-    if (B.opt_two_streams && !getrf.empty() && !trsm.empty())
+    // The factorisations, the solves and the updates of one run are independent of each other: the GETRFs (a handful of
+    // workgroups, latency-bound) go to a side stream that waits only for what was queued before this run and run beside
+    // the update and TSTRF/GESSM kernels; the main stream joins at the end of the run.
+    bool side = B.opt_two_streams && !getrf.empty() && (!trsm.empty() || !ssssm.empty());
+    if (side)
     {
         HIP_CHECK(hipEventRecord(B.ev_fork3, B.stream));
         HIP_CHECK(hipStreamWaitEvent(B.stream3, B.ev_fork3, 0));
-        gstream = B.stream3;
+        B.getrf_join_pending = false;
+        launch_getrf(nb, getrf.data(), getrf.size(), B.stream3, true);
     }
+    launch_ssssm(nb, ssssm.data(), ssssm.size());
     launch_trsm(nb, trsm.data(), trsm.size());
-    launch_getrf(nb, getrf.data(), getrf.size(), gstream);
+    if (side)
+    {
+        if (B.getrf_join_pending)
+            HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join3, 0));
+        B.getrf_join_pending = false;
+    }
+    else
+        launch_getrf(nb, getrf.data(), getrf.size(), B.stream, false);
 }
 
 } // namespace
@@ -2112,6 +2129,9 @@ extern "C"
             return 0;
         case PANGULU_HIP_OPT_TWO_STREAMS:
             B.opt_two_streams = value;
+            return 0;
+        case PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS:
+            B.opt_small_launch_tasks = value;
             return 0;
         case PANGULU_HIP_OPT_RESET_BLOCK_STATE:
         {
