@@ -242,6 +242,9 @@ extern "C"
     /*   PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS (default 512): an update launch with at most this many tasks gives every
      *     update its own workgroups (chunk 1) - near the root of the elimination tree latency matters, not traffic. */
 #define PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS 11
+    /*   PANGULU_HIP_OPT_XCD_SWIZZLE (default 1): map workgroup ids so that the workgroups of one update queue / one
+     *     destination / one solve run on the same XCD and share its L2 (0: hardware round-robin order). */
+#define PANGULU_HIP_OPT_XCD_SWIZZLE 12
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an

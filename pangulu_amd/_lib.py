@@ -195,6 +195,7 @@ HIP_OPT_SSSSM_GROUP_CHUNK = 8
 HIP_OPT_TRSM_DENSE_PERMILLE = 9
 HIP_OPT_TWO_STREAMS = 10
 HIP_OPT_SMALL_LAUNCH_TASKS = 11
+HIP_OPT_XCD_SWIZZLE = 12
 
 ORDER_IDENTITY, ORDER_ND, ORDER_USER = 0, 1, 2
 TRANSPORT_HOST, TRANSPORT_RCCL = 0, 1

@@ -13,6 +13,16 @@
 // The sparse record stays the authoritative form of every finished block (exchange, solve, download).
 #pragma once
 
+// Occupancy map of a mirror (nb <= 256): 16 x u16 right behind the nb*nb values; word c = which 16-row slabs of the
+// 16-column slab c hold pattern entries.  The pattern is symbolic (fill included) and never changes while the mirror
+// belongs to the block, so whatever lands in the mirror later (updates, solves) stays inside the map.  The MFMA update
+// skips K-slabs in which either operand is structurally zero, the dense solves skip empty strips and leading panels.
+#define MIRROR_MAP_BYTES 64
+__device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
+{
+    return reinterpret_cast<const unsigned short *>(mirror + (size_t)nb * nb);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // C(nb x nb) -= sum_t A_t * B_t on dense mirrors.  Workgroup = 4 wavefronts = one 128 x 128 tile of C; each
 // wavefront a 64 x 64 sub-tile as 4 x 4 accumulators of v_mfma_f64_16x16x4_f64.  K runs over all tasks of the
@@ -26,14 +36,18 @@
 #define DG_K 16
 #define DG_LD 144 // padded slab row (doubles): rows of consecutive k land 32 banks apart
 
-__global__ __launch_bounds__(256) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
+#ifndef DG_WAVES_PER_EU
+#define DG_WAVES_PER_EU 2 // two workgroups per CU: one stages its slab while the other feeds the matrix cores
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PER_EU, DG_WAVES_PER_EU))) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
                                                                const SsssmTaskD *__restrict__ tasks, int nb)
 {
     __shared__ __align__(16) double sA[DG_K * DG_LD];
     __shared__ __align__(16) double sB[DG_K * DG_LD];
     const int tiles = nb / DG_TILE;
-    const int g = blockIdx.x / (tiles * tiles);
-    const int tile = blockIdx.x % (tiles * tiles);
+    const unsigned bid = logical_block_id((unsigned)(tiles * tiles)); // the tiles of one destination share operand halves: same XCD, same L2
+    const int g = bid / (tiles * tiles);
+    const int tile = bid % (tiles * tiles);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int M0 = (tile % tiles) * DG_TILE, N0 = (tile / tiles) * DG_TILE; // workgroup tile origin
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;                   // wavefront sub-tile inside it
@@ -56,7 +70,53 @@ __global__ __launch_bounds__(256) void ssssm_dense_f64_kernel(const SsssmGroupD 
 
     const u32 ntask = G.task_end - G.task_begin;
     const int steps_per_task = nb / DG_K;
-    const int nsteps = (int)ntask * steps_per_task;
+    // K-slabs worth visiting, task by task: bit s of `todo` = slab s of task `cur_t` has pattern entries in this tile's
+    // rows of A AND in this tile's columns of B (occupancy maps behind the mirrors; nb > 256: no maps, every slab).
+    // Everything here is workgroup-uniform.
+    const bool mapped = nb <= 256;
+    const unsigned rowbits = ((1u << (DG_TILE / 16)) - 1u) << (M0 / 16);
+    int cur_t = -1, nxt_step = -1;
+    unsigned long long todo = 0;
+    int done_steps = 0; // (only nb > 256: slabs of the current task handed out so far, 64 at a time)
+
+#define DG_NEXT_STEP(out_)                                                                           \
+    {                                                                                                \
+        (out_) = -1;                                                                                 \
+        while (true)                                                                                 \
+        {                                                                                            \
+            if (todo)                                                                                \
+            {                                                                                        \
+                const int s_ = __builtin_ctzll(todo);                                                \
+                todo &= todo - 1;                                                                    \
+                (out_) = cur_t * steps_per_task + done_steps + s_;                                   \
+                break;                                                                               \
+            }                                                                                        \
+            if (!mapped && cur_t >= 0 && done_steps + 64 < steps_per_task)                           \
+            {                                                                                        \
+                done_steps += 64;                                                                    \
+                const int left_ = steps_per_task - done_steps;                                       \
+                todo = left_ >= 64 ? ~0ull : ((1ull << left_) - 1ull);                               \
+                continue;                                                                            \
+            }                                                                                        \
+            if (++cur_t >= (int)ntask)                                                               \
+                break;                                                                               \
+            done_steps = 0;                                                                          \
+            if (mapped)                                                                              \
+            {                                                                                        \
+                const SsssmTaskD &Tm_ = tasks[G.task_begin + cur_t];                                 \
+                const unsigned short *ma_ = mirror_map(Tm_.a.val, nb), *mb_ = mirror_map(Tm_.b.val, nb); \
+                unsigned cols_ = 0, live_ = 0;                                                       \
+                for (int c_ = N0 / 16; c_ < (N0 + DG_TILE) / 16; c_++)                                \
+                    cols_ |= mb_[c_];                                                                \
+                for (int k_ = 0; k_ < steps_per_task; k_++)                                          \
+                    if ((ma_[k_] & rowbits) && ((cols_ >> k_) & 1u))                                 \
+                        live_ |= 1u << k_;                                                           \
+                todo = live_;                                                                        \
+            }                                                                                        \
+            else                                                                                     \
+                todo = steps_per_task >= 64 ? ~0ull : ((1ull << steps_per_task) - 1ull);             \
+        }                                                                                            \
+    }
 
 #define DG_LOAD_SLAB(step_)                                                                          \
     {                                                                                                \
@@ -74,9 +134,11 @@ __global__ __launch_bounds__(256) void ssssm_dense_f64_kernel(const SsssmGroupD 
         rb3 = *reinterpret_cast<const double2 *>(B_ + (size_t)96 * nb);                              \
     }
 
-    if (nsteps > 0)
-        DG_LOAD_SLAB(0)
-    for (int step = 0; step < nsteps; step++)
+    DG_NEXT_STEP(nxt_step)
+    if (nxt_step < 0)
+        return; // nothing of these updates reaches this tile
+    DG_LOAD_SLAB(nxt_step)
+    while (nxt_step >= 0)
     {
         __syncthreads(); // everyone is done reading the previous slab
         *reinterpret_cast<double2 *>(&sA[(a_k + 0) * DG_LD + a_m]) = ra0;
@@ -92,8 +154,9 @@ __global__ __launch_bounds__(256) void ssssm_dense_f64_kernel(const SsssmGroupD 
         sB[b_k * DG_LD + b_n + 96] = rb3.x;
         sB[(b_k + 1) * DG_LD + b_n + 96] = rb3.y;
         __syncthreads();
-        if (step + 1 < nsteps)
-            DG_LOAD_SLAB(step + 1) // in flight while the matrix cores work
+        DG_NEXT_STEP(nxt_step)
+        if (nxt_step >= 0)
+            DG_LOAD_SLAB(nxt_step) // in flight while the matrix cores work
 #pragma unroll
         for (int kq = 0; kq < DG_K / 4; kq++)
         {
@@ -111,6 +174,7 @@ __global__ __launch_bounds__(256) void ssssm_dense_f64_kernel(const SsssmGroupD 
                     acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
         }
     }
+#undef DG_NEXT_STEP
 #undef DG_LOAD_SLAB
 
     double *__restrict__ C = G.cdense;
@@ -142,15 +206,18 @@ struct MirrorJobD
     double *dense;  // nb x nb column-major
 };
 
-// grid = (jobs, slices): a workgroup owns a run of columns of one block, so that a launch with a single job (the tail
-// of the elimination tree) still spreads over many CUs
+// grid = (jobs, slices): a workgroup owns a run of columns (whole 16-column slabs) of one block, so that a launch with
+// a single job (the tail of the elimination tree) still spreads over many CUs
 __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restrict__ jobs, int nb)
 {
+    __shared__ unsigned occ[16];
     const MirrorJobD J = jobs[blockIdx.x];
     const int per = (nb + (int)gridDim.y - 1) / (int)gridDim.y;
     const int c0 = (int)blockIdx.y * per, c1 = min(nb, c0 + per);
     if (c0 >= c1)
         return;
+    if (threadIdx.x < 16)
+        occ[threadIdx.x] = 0;
     double *base = J.dense + (size_t)c0 * nb;
     const int words = (c1 - c0) * nb;
     if ((words & 1) == 0 && (((size_t)c0 * nb) & 1) == 0)
@@ -163,10 +230,20 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
         for (int i = threadIdx.x; i < words; i += blockDim.x)
             base[i] = 0.0;
     __syncthreads();
+    const bool mapped = nb <= 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     for (int c = c0 + wave; c < c1; c += nw)
+    {
+        unsigned bits = 0;
         for (u32 p = ptr0(J.lo.ptr, c) + lane; p < J.lo.ptr[c + 1]; p += 64)
-            J.dense[(size_t)c * nb + J.lo.idx[p]] = J.lo.val[p];
+        {
+            const u32 r = J.lo.idx[p];
+            J.dense[(size_t)c * nb + r] = J.lo.val[p];
+            bits |= 1u << ((r >> 4) & 31);
+        }
+        if (mapped && bits)
+            atomicOr(&occ[c >> 4], bits);
+    }
     if (J.up.ptr)
     {
         // the CSR half of a diagonal block: every workgroup walks all rows and keeps the entries of its own columns
@@ -175,8 +252,20 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
             {
                 const int c = J.up.idx[p];
                 if (c >= c0 && c < c1)
+                {
                     J.dense[(size_t)c * nb + r] = J.up.val[p];
+                    if (mapped)
+                        atomicOr(&occ[c >> 4], 1u << (r >> 4));
+                }
             }
+    }
+    if (mapped)
+    {
+        __syncthreads();
+        unsigned short *map = reinterpret_cast<unsigned short *>(J.dense + (size_t)nb * nb);
+        const int s = threadIdx.x;
+        if (s < 16 && s * 16 >= c0 && s * 16 < c1)
+            map[s] = (unsigned short)occ[s];
     }
 }
 

@@ -69,7 +69,7 @@ double *obtain_mirror(BlockState &st, int nb)
 {
     if (st.mirror)
         return st.mirror;
-    size_t mb = sizeof(double) * (size_t)nb * nb;
+    size_t mb = sizeof(double) * (size_t)nb * nb + MIRROR_MAP_BYTES; // values + occupancy map (pg_hip_dense.h)
     if (MP.mirror_bytes != mb)
     {
         // block order changed (or first use): start over
@@ -196,7 +196,7 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify)
         commit_segment(seg);
         // few jobs: cut every block into column runs so the launch still covers the chip
         unsigned slices = take >= 2048 ? 1u : take >= 512 ? 4u : 16u;
-        slices = std::min<unsigned>(slices, (unsigned)std::max(1, nb / 8));
+        slices = std::min<unsigned>(slices, (unsigned)std::max(1, nb / 16)); // whole 16-column slabs per workgroup
         if (densify)
             hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, B.stream, d_jobs, nb);
         else

@@ -184,6 +184,21 @@ struct GetrfTaskD
 
 __device__ inline u32 ptr0(const u32 *p, int i) { return i == 0 ? 0u : p[i]; }
 
+// Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  The `per_unit` workgroups that read the same
+// operands (the column runs of one update queue, the tiles of one destination, the strips of one solve) are mapped
+// to the SAME XCD so that they share its L2; units themselves stay dealt round-robin (unit u -> XCD u % 8), which keeps
+// the longest-first launch order balanced over the XCDs.  Returns unit * per_unit + index inside the unit.
+__constant__ int c_xcd_swizzle = 1;
+__device__ inline unsigned logical_block_id(unsigned per_unit)
+{
+    const unsigned n = gridDim.x, b = blockIdx.x;
+    const unsigned round = 8u * per_unit, full = (n / round) * round; // workgroups in complete rounds of 8 units
+    if (!c_xcd_swizzle || b >= full)
+        return b;
+    const unsigned x = b & 7, idx = b >> 3;
+    return (x + 8u * (idx / per_unit)) * per_unit + idx % per_unit;
+}
+
 __device__ inline void wave_lds_fence()
 {
     // LDS operations of one wavefront execute in order; this only stops the compiler from reordering them
@@ -224,8 +239,9 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
     // a wavefront owns `cpw` adjacent destination columns, one after the other (big batches use cpw > 1: launching a
     // workgroup per 4 columns costs more than the columns themselves, most of which no update touches)
     const int colblocks = (nb + SSSSM_WAVES * cpw - 1) / (SSSSM_WAVES * cpw);
-    const int g = blockIdx.x / colblocks;
-    const int jbase = ((blockIdx.x % colblocks) * SSSSM_WAVES + wave) * cpw;
+    const unsigned bid = logical_block_id((unsigned)colblocks);
+    const int g = bid / colblocks;
+    const int jbase = ((bid % colblocks) * SSSSM_WAVES + wave) * cpw;
     val_t *acc = smem + (size_t)wave * nb;
     const SsssmGroupD G = groups[g];
     unsigned long long fmas = 0;
@@ -423,8 +439,9 @@ __global__ __launch_bounds__(TRSM_WAVES * 64) void trsm_sparse_kernel(const Trsm
     val_t *smem = reinterpret_cast<val_t *>(smem_raw);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int vblocks = (nb + TRSM_WAVES - 1) / TRSM_WAVES;
-    const int t = blockIdx.x / vblocks;
-    const int v = (blockIdx.x % vblocks) * TRSM_WAVES + wave;
+    const unsigned bid = logical_block_id((unsigned)vblocks);
+    const int t = bid / vblocks;
+    const int v = (bid % vblocks) * TRSM_WAVES + wave;
     if (v >= nb)
         return;
     const TrsmTaskD T = tasks[t];
@@ -2133,6 +2150,14 @@ extern "C"
         case PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS:
             B.opt_small_launch_tasks = value;
             return 0;
+        case PANGULU_HIP_OPT_XCD_SWIZZLE:
+        {
+            ensure_ready();
+            int v = value ? 1 : 0;
+            HIP_CHECK(hipStreamSynchronize(B.stream));
+            HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_xcd_swizzle), &v, sizeof(v)));
+            return 0;
+        }
         case PANGULU_HIP_OPT_RESET_BLOCK_STATE:
         {
             std::lock_guard<std::mutex> g(B.mutex);

@@ -81,15 +81,16 @@ __global__ __launch_bounds__(64) void diag_tile_inverse_kernel(double *const *__
 // current one is consumed), laid out so that the MFMA A-operand reads are conflict-free:
 //     TSTRF  sT[c * 258 + row]   (c = column within the panel)     GESSM  sT[k * 16 + r]   (r = row within the panel)
 template <int NP>
-__global__ __launch_bounds__(256) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks)
 {
     constexpr int nb = NP * 16;
     constexpr int LDT = nb + 2;
     __shared__ __align__(16) double sT[16 * LDT];
     const int slabs = nb / 64;
-    const TrsmDenseTaskD T = tasks[blockIdx.x / slabs];
+    const unsigned bid = logical_block_id((unsigned)slabs); // the strips of one solve read the same factor image: same XCD
+    const TrsmDenseTaskD T = tasks[bid / slabs];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int o0 = (blockIdx.x % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
+    const int o0 = (bid % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
     double *__restrict__ Bm = T.b;
     const double *__restrict__ LU = T.lu;
     const bool tstrf = T.is_tstrf != 0;
@@ -140,21 +141,51 @@ __global__ __launch_bounds__(256) void trsm_dense_f64_kernel(const TrsmDenseTask
         }                                                                                                         \
     }
 
+    // Structural zeros (occupancy map behind the mirror, pg_hip_dense.h): a strip without pattern entries stays zero,
+    // and a strip's solution is zero in every panel before its first occupied one.  first[w] = first occupied panel of
+    // wavefront w's strip (NP = none); the workgroup starts at the smallest of them and leaves if there is none.
+    const unsigned short *map = mirror_map(Bm, nb);
+    int first[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+    {
+        const int strip = ((bid % slabs) * 64 + w * 16) >> 4;
+        int f = NP;
+        if (tstrf)
+        {
+            for (int c = NP - 1; c >= 0; c--)
+                if ((map[c] >> strip) & 1)
+                    f = c;
+        }
+        else if (map[strip])
+            f = __builtin_ctz((unsigned)map[strip]);
+        first[w] = f;
+    }
+    const int my_first = first[0] * (wave == 0) + first[1] * (wave == 1) + first[2] * (wave == 2) + first[3] * (wave == 3);
+    const int wg_first = min(min(first[0], first[1]), min(first[2], first[3]));
+    if (wg_first >= NP)
+        return;
+
     // tile p, register g of lane l  <->  TSTRF: X(o0 + l15, 16p + l4 + 4g)    GESSM: X(16p + l4 + 4g, o0 + l15)
 #pragma unroll
     for (int p = 0; p < NP; p++)
 #pragma unroll
         for (int g = 0; g < 4; g++)
-            xs[p][g] = tstrf ? Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] : Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g];
-    TRSM_PREFETCH(0)
+            xs[p][g] = (p < my_first) ? 0.0
+                                      : (tstrf ? Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] : Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g]);
+    TRSM_PREFETCH(wg_first)
 #pragma unroll
     for (int p = 0; p < NP; p++)
     {
+        if (p < wg_first)
+            continue; // (workgroup-uniform)
         __syncthreads(); // everyone is done with the previous panel's image
         TRSM_STAGE(p)
         __syncthreads();
         if (p + 1 < NP)
             TRSM_PREFETCH(p + 1)
+        if (p < my_first)
+            continue; // (wavefront-uniform; no barrier below)
         // four independent accumulation chains (one per k-quarter of a tile): a single chain of up to 60 dependent
         // MFMAs would leave the matrix core idle for most of each instruction's latency
         v4f64 part[4];
@@ -162,6 +193,9 @@ __global__ __launch_bounds__(256) void trsm_dense_f64_kernel(const TrsmDenseTask
         part[1] = part[2] = part[3] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < p; q++)
+        {
+            if (q < my_first)
+                continue; // X_q = 0
 #pragma unroll
             for (int kq = 0; kq < 4; kq++)
             {
@@ -170,6 +204,7 @@ __global__ __launch_bounds__(256) void trsm_dense_f64_kernel(const TrsmDenseTask
                 const double a = tstrf ? -sT[l15 * LDT + k] : -sT[k * 16 + l15];
                 part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xs[q][kq], part[kq], 0, 0, 0);
             }
+        }
         v4f64 acc = (part[0] + part[1]) + (part[2] + part[3]);
         // multiply by the inverted diagonal tile (upper part: inv(U_pp); strictly lower part: inv(L_pp), unit diagonal)
         v4f64 x = {0.0, 0.0, 0.0, 0.0};

@@ -13,29 +13,44 @@ struct SsssmGroupD { BlkView c; const u32 *ucp; const u16 *uri; const u32 *uvi; 
 __device__ inline u32 ptr0(const u32 *p, int i) { return i == 0 ? 0u : p[i]; }
 __device__ inline unsigned long long wave_sum(unsigned long long v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; }
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+__constant__ int c_xcd_swizzle = 1;
+__device__ inline unsigned logical_block_id(unsigned per_unit)
+{
+    const unsigned n = gridDim.x, b = blockIdx.x;
+    const unsigned round = 8u * per_unit, full = (n / round) * round;
+    if (!c_xcd_swizzle || b >= full)
+        return b;
+    const unsigned x = b & 7, idx = b >> 3;
+    return (x + 8u * (idx / per_unit)) * per_unit + idx % per_unit;
+}
 #include "../../pangulu_amd/csrc/platform/pg_hip_dense.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 int main(int argc, char **argv)
 {
-    int nb = 256, ngroups = argc > 1 ? atoi(argv[1]) : 1024, tpg = argc > 2 ? atoi(argv[2]) : 8, nmir = 4096, atomic = argc > 3 ? atoi(argv[3]) : 0;
-    size_t mb = (size_t)nb * nb;
+    int nb = 256, ngroups = argc > 1 ? atoi(argv[1]) : 1024, tpg = argc > 2 ? atoi(argv[2]) : 8, nmir = 4096, atomic = argc > 3 ? atoi(argv[3]) : 0, livebits = argc > 4 ? atoi(argv[4]) : 16, ndst = argc > 5 ? atoi(argv[5]) : 1024, nops = argc > 6 ? atoi(argv[6]) : 1500;
+    size_t mb = (size_t)nb * nb + 8; // values + occupancy map
     double *pool;
     CK(hipMalloc(&pool, sizeof(double) * mb * nmir));
     std::vector<double> h(mb * 64);
     for (auto &x : h) x = (double)rand() / RAND_MAX - 0.5;
+    for (int m = 0; m < 64; m++) // occupancy maps: the first `livebits` K-slabs live in every row/column slab
+    {
+        unsigned short *map = reinterpret_cast<unsigned short *>(h.data() + (size_t)m * mb + (size_t)nb * nb);
+        for (int c = 0; c < 16; c++) map[c] = c < livebits ? (unsigned short)((1u << livebits) - 1u) : 0;
+    }
     for (int i = 0; i < nmir; i += 64) CK(hipMemcpy(pool + (size_t)i * mb, h.data(), sizeof(double) * mb * 64, hipMemcpyHostToDevice));
     std::vector<SsssmGroupD> G(ngroups);
     std::vector<SsssmTaskD> T((size_t)ngroups * tpg);
     for (int g = 0; g < ngroups; g++)
     {
         memset(&G[g], 0, sizeof(SsssmGroupD));
-        G[g].cdense = pool + (size_t)(g % 1024) * mb;
+        G[g].cdense = pool + (size_t)((g / ((ngroups + ndst - 1) / ndst)) % 1024) * mb; // consecutive groups (chunks of one queue) share a destination
         G[g].task_begin = g * tpg; G[g].task_end = (g + 1) * tpg; G[g].atomic = atomic;
         for (int t = 0; t < tpg; t++)
         {
             memset(&T[(size_t)g * tpg + t], 0, sizeof(SsssmTaskD));
-            T[(size_t)g * tpg + t].a.val = pool + (size_t)(1024 + rand() % 1500) * mb;
-            T[(size_t)g * tpg + t].b.val = pool + (size_t)(2560 + rand() % 1500) * mb;
+            T[(size_t)g * tpg + t].a.val = pool + (size_t)(1024 + rand() % nops) * mb;
+            T[(size_t)g * tpg + t].b.val = pool + (size_t)(2560 + rand() % nops) * mb;
         }
     }
     SsssmGroupD *dG; SsssmTaskD *dT;
