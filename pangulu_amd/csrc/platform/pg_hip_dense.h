@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     const unsigned bid = logical_block_id((unsigned)(tiles * tiles)); // the tiles of one destination share operand halves: same XCD, same L2
     const int g = bid / (tiles * tiles);
     const int tile = bid % (tiles * tiles);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (scalar: the skip tests below must be scalar branches)
     const int M0 = (tile % tiles) * DG_TILE, N0 = (tile / tiles) * DG_TILE; // workgroup tile origin
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;                   // wavefront sub-tile inside it
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -66,18 +67,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     // 128-byte run of a column.
     const int a_m = 2 * (tid & 63), a_k = tid >> 6;
     const int b_k = 2 * (tid & 7), b_n = tid >> 3;
+    const int a_slab = (tid & 63) >> 3;                            // which 16-row slab of the tile this thread stages
+    const int b_slab = __builtin_amdgcn_readfirstlane(tid >> 7);   // 16-column slab of piece i: b_slab + 2 i
     double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3; // next slab, in flight while the current one is consumed
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_double2(0.0, 0.0);
 
     const u32 ntask = G.task_end - G.task_begin;
     const int steps_per_task = nb / DG_K;
-    // K-slabs worth visiting, task by task: bit s of `todo` = slab s of task `cur_t` has pattern entries in this tile's
-    // rows of A AND in this tile's columns of B (occupancy maps behind the mirrors; nb > 256: no maps, every slab).
-    // Everything here is workgroup-uniform.
+    // Structural zeros, from the occupancy maps behind the mirrors (nb <= 256; otherwise everything counts as live).
+    // For K-slab s of a task:  abits = which of the tile's eight 16-row slabs of A(:, s) hold pattern entries,
+    //                          bbits = which of its eight 16-column slabs of B(s, :) do.
+    // A slab is visited if both are non-zero; only live 16 x 16 pieces are fetched, and a wavefront issues the MFMAs
+    // of a 16 x 16 x 16 product only when both its pieces are live -- for fill-in patterns of a few percent to a few
+    // tens of percent that is a small fraction of the full contraction.  All of this is scalar (workgroup- or
+    // wavefront-uniform) control flow.
     const bool mapped = nb <= 256;
-    const unsigned rowbits = ((1u << (DG_TILE / 16)) - 1u) << (M0 / 16);
     int cur_t = -1, nxt_step = -1;
     unsigned long long todo = 0;
     int done_steps = 0; // (only nb > 256: slabs of the current task handed out so far, 64 at a time)
+    const unsigned short *t_ma = nullptr, *t_mb = nullptr;
+    unsigned nxt_ab = 0xFF, nxt_bb = 0xFF, cur_ab, cur_bb, touched = 0;
 
 #define DG_NEXT_STEP(out_)                                                                           \
     {                                                                                                \
@@ -89,6 +98,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
                 const int s_ = __builtin_ctzll(todo);                                                \
                 todo &= todo - 1;                                                                    \
                 (out_) = cur_t * steps_per_task + done_steps + s_;                                   \
+                if (mapped)                                                                          \
+                {                                                                                    \
+                    nxt_ab = ((unsigned)t_ma[s_] >> (M0 / 16)) & 0xFFu;                              \
+                    nxt_bb = 0;                                                                      \
+                    for (int c_ = 0; c_ < DG_TILE / 16; c_++)                                        \
+                        nxt_bb |= (((unsigned)t_mb[N0 / 16 + c_] >> s_) & 1u) << c_;                 \
+                }                                                                                    \
                 break;                                                                               \
             }                                                                                        \
             if (!mapped && cur_t >= 0 && done_steps + 64 < steps_per_task)                           \
@@ -104,12 +120,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
             if (mapped)                                                                              \
             {                                                                                        \
                 const SsssmTaskD &Tm_ = tasks[G.task_begin + cur_t];                                 \
-                const unsigned short *ma_ = mirror_map(Tm_.a.val, nb), *mb_ = mirror_map(Tm_.b.val, nb); \
+                t_ma = mirror_map(Tm_.a.val, nb);                                                    \
+                t_mb = mirror_map(Tm_.b.val, nb);                                                    \
+                const unsigned rowbits_ = 0xFFu << (M0 / 16);                                        \
                 unsigned cols_ = 0, live_ = 0;                                                       \
                 for (int c_ = N0 / 16; c_ < (N0 + DG_TILE) / 16; c_++)                                \
-                    cols_ |= mb_[c_];                                                                \
+                    cols_ |= t_mb[c_];                                                               \
                 for (int k_ = 0; k_ < steps_per_task; k_++)                                          \
-                    if ((ma_[k_] & rowbits) && ((cols_ >> k_) & 1u))                                 \
+                    if ((t_ma[k_] & rowbits_) && ((cols_ >> k_) & 1u))                               \
                         live_ |= 1u << k_;                                                           \
                 todo = live_;                                                                        \
             }                                                                                        \
@@ -118,29 +136,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         }                                                                                            \
     }
 
-#define DG_LOAD_SLAB(step_)                                                                          \
+#define DG_LOAD_SLAB(step_, ab_, bb_)                                                                \
     {                                                                                                \
         const SsssmTaskD &T_ = tasks[G.task_begin + (step_) / steps_per_task];                       \
         const int k0_ = ((step_) % steps_per_task) * DG_K;                                           \
         const double *A_ = T_.a.val + (size_t)(k0_ + a_k) * nb + M0 + a_m;                           \
         const double *B_ = T_.b.val + (size_t)(N0 + b_n) * nb + k0_ + b_k;                           \
-        ra0 = *reinterpret_cast<const double2 *>(A_);                                                \
-        ra1 = *reinterpret_cast<const double2 *>(A_ + (size_t)4 * nb);                               \
-        ra2 = *reinterpret_cast<const double2 *>(A_ + (size_t)8 * nb);                               \
-        ra3 = *reinterpret_cast<const double2 *>(A_ + (size_t)12 * nb);                              \
-        rb0 = *reinterpret_cast<const double2 *>(B_);                                                \
-        rb1 = *reinterpret_cast<const double2 *>(B_ + (size_t)32 * nb);                              \
-        rb2 = *reinterpret_cast<const double2 *>(B_ + (size_t)64 * nb);                              \
-        rb3 = *reinterpret_cast<const double2 *>(B_ + (size_t)96 * nb);                              \
+        if (((ab_) >> a_slab) & 1u)                                                                  \
+        {                                                                                            \
+            ra0 = *reinterpret_cast<const double2 *>(A_);                                            \
+            ra1 = *reinterpret_cast<const double2 *>(A_ + (size_t)4 * nb);                           \
+            ra2 = *reinterpret_cast<const double2 *>(A_ + (size_t)8 * nb);                           \
+            ra3 = *reinterpret_cast<const double2 *>(A_ + (size_t)12 * nb);                          \
+        }                                                                                            \
+        if (((bb_) >> b_slab) & 1u)                                                                  \
+            rb0 = *reinterpret_cast<const double2 *>(B_);                                            \
+        if (((bb_) >> (b_slab + 2)) & 1u)                                                            \
+            rb1 = *reinterpret_cast<const double2 *>(B_ + (size_t)32 * nb);                          \
+        if (((bb_) >> (b_slab + 4)) & 1u)                                                            \
+            rb2 = *reinterpret_cast<const double2 *>(B_ + (size_t)64 * nb);                          \
+        if (((bb_) >> (b_slab + 6)) & 1u)                                                            \
+            rb3 = *reinterpret_cast<const double2 *>(B_ + (size_t)96 * nb);                          \
     }
 
     DG_NEXT_STEP(nxt_step)
     if (nxt_step < 0)
         return; // nothing of these updates reaches this tile
-    DG_LOAD_SLAB(nxt_step)
+    DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb)
     while (nxt_step >= 0)
     {
+        cur_ab = nxt_ab;
+        cur_bb = nxt_bb;
         __syncthreads(); // everyone is done reading the previous slab
+        // (pieces that were not fetched hold stale finite values; no MFMA reads them)
         *reinterpret_cast<double2 *>(&sA[(a_k + 0) * DG_LD + a_m]) = ra0;
         *reinterpret_cast<double2 *>(&sA[(a_k + 4) * DG_LD + a_m]) = ra1;
         *reinterpret_cast<double2 *>(&sA[(a_k + 8) * DG_LD + a_m]) = ra2;
@@ -156,22 +184,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         __syncthreads();
         DG_NEXT_STEP(nxt_step)
         if (nxt_step >= 0)
-            DG_LOAD_SLAB(nxt_step) // in flight while the matrix cores work
-#pragma unroll
-        for (int kq = 0; kq < DG_K / 4; kq++)
+            DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb) // in flight while the matrix cores work
+        const unsigned a4 = (cur_ab >> (wm / 16)) & 0xFu, b4 = (cur_bb >> (wn / 16)) & 0xFu;
+        if (a4 && b4)
         {
-            double fa[4], fb[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-                fa[mi] = sA[(kq * 4 + l4) * DG_LD + wm + mi * 16 + l15];
 #pragma unroll
             for (int ni = 0; ni < 4; ni++)
-                fb[ni] = sB[(kq * 4 + l4) * DG_LD + wn + ni * 16 + l15];
+                if ((b4 >> ni) & 1u)
+                    touched |= a4 << (4 * ni);
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++)
+            for (int kq = 0; kq < DG_K / 4; kq++)
+            {
+                double fa[4], fb[4];
 #pragma unroll
                 for (int mi = 0; mi < 4; mi++)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+                    fa[mi] = sA[(kq * 4 + l4) * DG_LD + wm + mi * 16 + l15];
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++)
+                    fb[ni] = sB[(kq * 4 + l4) * DG_LD + wn + ni * 16 + l15];
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++)
+                {
+                    if (!((b4 >> ni) & 1u))
+                        continue;
+#pragma unroll
+                    for (int mi = 0; mi < 4; mi++)
+                        if ((a4 >> mi) & 1u)
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+                }
+            }
         }
     }
 #undef DG_NEXT_STEP
@@ -182,6 +223,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     for (int ni = 0; ni < 4; ni++)
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
+        {
+            if (!((touched >> (4 * ni + mi)) & 1u))
+                continue; // no product reached this 16 x 16 piece of C
 #pragma unroll
             for (int r = 0; r < 4; r++)
             {
@@ -194,6 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
                 else
                     C[off] -= acc[ni][mi][r];
             }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

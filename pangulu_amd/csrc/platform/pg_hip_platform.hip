@@ -1014,14 +1014,14 @@ struct Backend
     int nb_cfg = 0;
     // options
     long long opt_host_mirror = 1;
-    long long opt_dense_permille = 150;
+    long long opt_dense_permille = 25;
     long long opt_profile = 0;
     long long opt_assume_independent = 0;
     long long opt_getrf_strict = 0;
     long long opt_count_flops = 1;
-    long long opt_group_chunk = 3;
+    long long opt_group_chunk = 8;
     long long opt_small_launch_tasks = 512;
-    long long opt_trsm_dense_permille = 100;
+    long long opt_trsm_dense_permille = 30;
     long long opt_two_streams = 1;
     double mfma_flops_executed = 0;
     // resources

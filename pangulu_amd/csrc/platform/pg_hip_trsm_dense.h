@@ -141,38 +141,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
         }                                                                                                         \
     }
 
-    // Structural zeros (occupancy map behind the mirror, pg_hip_dense.h): a strip without pattern entries stays zero,
-    // and a strip's solution is zero in every panel before its first occupied one.  first[w] = first occupied panel of
-    // wavefront w's strip (NP = none); the workgroup starts at the smallest of them and leaves if there is none.
+    // Structural zeros (occupancy map behind the mirror, pg_hip_dense.h): bit q of lv[w] = the 16 x 16 tile q of
+    // wavefront w's strip holds pattern entries (fill included, so the solution's tile can be non-zero).  A tile that
+    // is not set is zero before and after the solve: it is neither loaded, multiplied nor stored.  The workgroup starts
+    // at the first panel in which any of its strips has a tile and leaves if there is none.
     const unsigned short *map = mirror_map(Bm, nb);
-    int first[4];
+    unsigned lv[4];
 #pragma unroll
     for (int w = 0; w < 4; w++)
     {
         const int strip = ((bid % slabs) * 64 + w * 16) >> 4;
-        int f = NP;
+        unsigned m = 0;
         if (tstrf)
         {
-            for (int c = NP - 1; c >= 0; c--)
-                if ((map[c] >> strip) & 1)
-                    f = c;
+            for (int c = 0; c < NP; c++)
+                m |= (((unsigned)map[c] >> strip) & 1u) << c;
         }
-        else if (map[strip])
-            f = __builtin_ctz((unsigned)map[strip]);
-        first[w] = f;
+        else
+            m = map[strip];
+        lv[w] = m;
     }
-    const int my_first = first[0] * (wave == 0) + first[1] * (wave == 1) + first[2] * (wave == 2) + first[3] * (wave == 3);
-    const int wg_first = min(min(first[0], first[1]), min(first[2], first[3]));
-    if (wg_first >= NP)
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned my_lv = swave == 0 ? lv[0] : swave == 1 ? lv[1] : swave == 2 ? lv[2] : lv[3];
+    const unsigned wg_lv = lv[0] | lv[1] | lv[2] | lv[3];
+    if (wg_lv == 0)
         return;
+    const int wg_first = __builtin_ctz(wg_lv);
 
     // tile p, register g of lane l  <->  TSTRF: X(o0 + l15, 16p + l4 + 4g)    GESSM: X(16p + l4 + 4g, o0 + l15)
 #pragma unroll
     for (int p = 0; p < NP; p++)
 #pragma unroll
         for (int g = 0; g < 4; g++)
-            xs[p][g] = (p < my_first) ? 0.0
-                                      : (tstrf ? Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] : Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g]);
+            xs[p][g] = !((my_lv >> p) & 1u) ? 0.0
+                                             : (tstrf ? Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] : Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g]);
     TRSM_PREFETCH(wg_first)
 #pragma unroll
     for (int p = 0; p < NP; p++)
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
         __syncthreads();
         if (p + 1 < NP)
             TRSM_PREFETCH(p + 1)
-        if (p < my_first)
+        if (!((my_lv >> p) & 1u))
             continue; // (wavefront-uniform; no barrier below)
         // four independent accumulation chains (one per k-quarter of a tile): a single chain of up to 60 dependent
         // MFMAs would leave the matrix core idle for most of each instruction's latency
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
 #pragma unroll
         for (int q = 0; q < p; q++)
         {
-            if (q < my_first)
+            if (!((my_lv >> q) & 1u))
                 continue; // X_q = 0
 #pragma unroll
             for (int kq = 0; kq < 4; kq++)

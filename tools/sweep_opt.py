@@ -7,12 +7,17 @@ args = sys.argv[1:]
 size = (398, 398)
 if "--size" in args:
     k = args.index("--size"); size = (int(args[k + 1]), int(args[k + 2])); args = args[:k] + args[k + 3:]
+fixed = []
+while "--set" in args:  # --set id=value: other options held fixed during the sweep
+    k = args.index("--set"); o, v = args[k + 1].split("="); fixed.append((int(o), int(v))); args = args[:k] + args[k + 2:]
 opt = int(args[0]); vals = [int(v) for v in args[1:]]
 lib = _lib.load("r64")
 n, cp, ri, va, co = M.shell(*size)
 h = pa.pangulu_init(n, len(va), cp, ri, va, nb=256, coords=co, nthread=32)
 lib.pangulu_amd_snapshot(h.ref)
 lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 0)
+for o, v in fixed:
+    lib.pangulu_platform_0201001_set_option(o, v)
 for v in vals:
     lib.pangulu_platform_0201001_set_option(opt, v)
     ts = []
