@@ -247,86 +247,139 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
 struct MirrorJobD
 {
     BlkView lo;     // CSC view (off-diagonal block, or strictly-lower half of a diagonal block)
-    BlkView up;     // upper CSR half of a diagonal block (ptr == nullptr otherwise)
+    // upper half of a diagonal block through its column view (DiagAux): column pointers, row indices, and the position
+    // of every entry in the CSR value array `uval`; ucp == nullptr for off-diagonal blocks
+    const u32 *ucp;
+    const u16 *uri;
+    const u32 *uvi;
+    double *uval;
     double *dense;  // nb x nb column-major
 };
+
+// Entries ptr[c0] .. ptr[c1] of a CSC block are one contiguous run: the workgroup walks it flat (coalesced, no
+// per-column pointer chasing) and finds the column of entry p by bisection in an LDS copy of the pointer slice.
+#define MIRROR_MAX_COLS 256
+__device__ inline int mirror_column_of(const u32 *sp, int ncols, u32 p)
+{
+    int lo = 0, hi = ncols; // sp[lo] <= p < sp[hi]
+    while (hi - lo > 1)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (sp[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
 
 // grid = (jobs, slices): a workgroup owns a run of columns (whole 16-column slabs) of one block, so that a launch with
 // a single job (the tail of the elimination tree) still spreads over many CUs
 __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restrict__ jobs, int nb)
 {
     __shared__ unsigned occ[16];
+    __shared__ u32 sp[MIRROR_MAX_COLS + 1], su[MIRROR_MAX_COLS + 1];
     const MirrorJobD J = jobs[blockIdx.x];
-    const int per = (nb + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int c0 = (int)blockIdx.y * per, c1 = min(nb, c0 + per);
-    if (c0 >= c1)
-        return;
-    if (threadIdx.x < 16)
-        occ[threadIdx.x] = 0;
-    double *base = J.dense + (size_t)c0 * nb;
-    const int words = (c1 - c0) * nb;
-    if ((words & 1) == 0 && (((size_t)c0 * nb) & 1) == 0)
-    {
-        double2 *d2 = reinterpret_cast<double2 *>(base); // mirrors are 16-byte aligned
-        for (int i = threadIdx.x; i < words / 2; i += blockDim.x)
-            d2[i] = make_double2(0.0, 0.0);
-    }
-    else
-        for (int i = threadIdx.x; i < words; i += blockDim.x)
-            base[i] = 0.0;
-    __syncthreads();
+    int per = (nb + (int)gridDim.y - 1) / (int)gridDim.y;
+    if (per > MIRROR_MAX_COLS)
+        per = MIRROR_MAX_COLS;
     const bool mapped = nb <= 256;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int c = c0 + wave; c < c1; c += nw)
+    unsigned short *map = reinterpret_cast<unsigned short *>(J.dense + (size_t)nb * nb);
+    // (nb > MIRROR_MAX_COLS * slices: the workgroup takes several runs of columns, one after the other)
+    for (int c0 = (int)blockIdx.y * per; c0 < nb; c0 += per * (int)gridDim.y)
     {
-        unsigned bits = 0;
-        for (u32 p = ptr0(J.lo.ptr, c) + lane; p < J.lo.ptr[c + 1]; p += 64)
+        const int c1 = min(nb, c0 + per), ncols = c1 - c0;
+        __syncthreads();
+        if (threadIdx.x < 16)
+            occ[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i <= ncols; i += blockDim.x)
         {
+            sp[i] = ptr0(J.lo.ptr, c0 + i);
+            su[i] = J.ucp ? J.ucp[c0 + i] : 0u;
+        }
+        __syncthreads();
+        const u32 e0 = sp[0], e1 = sp[ncols], f0 = su[0], f1 = su[ncols];
+        const bool by_tiles = mapped && !J.ucp;
+        if (by_tiles)
+        {
+            // Off-diagonal block: everything that reads the mirror goes by the occupancy map (the MFMA update and the
+            // dense solves touch live 16 x 16 tiles only, sparsify reads pattern entries), so only live tiles are
+            // cleared -- for fill of a few percent that is a fraction of the nb*nb image.  (Dead tiles keep whatever
+            // the memory held; the sparse-update kernel carries such values through its column pass unchanged.)
+            for (u32 p = e0 + threadIdx.x; p < e1; p += blockDim.x)
+                atomicOr(&occ[(c0 + mirror_column_of(sp, ncols, p)) >> 4], 1u << (J.lo.idx[p] >> 4));
+            __syncthreads();
+            const int tpc = nb / 2; // 16-byte pieces per column; eight of them per 16-row slab
+            for (int i = threadIdx.x; i < ncols * tpc; i += blockDim.x)
+            {
+                const int c = c0 + i / tpc, within = i % tpc;
+                if ((occ[c >> 4] >> (within >> 3)) & 1u)
+                    reinterpret_cast<double2 *>(J.dense + (size_t)c * nb)[within] = make_double2(0.0, 0.0);
+            }
+        }
+        else
+        {
+            double *base = J.dense + (size_t)c0 * nb;
+            const int words = ncols * nb;
+            if ((words & 1) == 0 && (((size_t)c0 * nb) & 1) == 0)
+            {
+                double2 *d2 = reinterpret_cast<double2 *>(base); // mirrors are 16-byte aligned
+                for (int i = threadIdx.x; i < words / 2; i += blockDim.x)
+                    d2[i] = make_double2(0.0, 0.0);
+            }
+            else
+                for (int i = threadIdx.x; i < words; i += blockDim.x)
+                    base[i] = 0.0;
+        }
+        __syncthreads();
+        for (u32 p = e0 + threadIdx.x; p < e1; p += blockDim.x)
+        {
+            const int c = c0 + mirror_column_of(sp, ncols, p);
             const u32 r = J.lo.idx[p];
             J.dense[(size_t)c * nb + r] = J.lo.val[p];
-            bits |= 1u << ((r >> 4) & 31);
+            if (mapped && !by_tiles)
+                atomicOr(&occ[c >> 4], 1u << (r >> 4));
         }
-        if (mapped && bits)
-            atomicOr(&occ[c >> 4], bits);
-    }
-    if (J.up.ptr)
-    {
-        // the CSR half of a diagonal block: every workgroup walks all rows and keeps the entries of its own columns
-        for (int r = wave; r < nb; r += nw)
-            for (u32 p = J.up.ptr[r] + lane; p < J.up.ptr[r + 1]; p += 64)
-            {
-                const int c = J.up.idx[p];
-                if (c >= c0 && c < c1)
-                {
-                    J.dense[(size_t)c * nb + r] = J.up.val[p];
-                    if (mapped)
-                        atomicOr(&occ[c >> 4], 1u << (r >> 4));
-                }
-            }
-    }
-    if (mapped)
-    {
-        __syncthreads();
-        unsigned short *map = reinterpret_cast<unsigned short *>(J.dense + (size_t)nb * nb);
-        const int s = threadIdx.x;
-        if (s < 16 && s * 16 >= c0 && s * 16 < c1)
-            map[s] = (unsigned short)occ[s];
+        for (u32 p = f0 + threadIdx.x; p < f1; p += blockDim.x) // upper half of a diagonal block
+        {
+            const int c = c0 + mirror_column_of(su, ncols, p);
+            const u32 r = J.uri[p];
+            J.dense[(size_t)c * nb + r] = J.uval[J.uvi[p]];
+            if (mapped)
+                atomicOr(&occ[c >> 4], 1u << (r >> 4));
+        }
+        if (mapped)
+        {
+            __syncthreads();
+            const int s_ = threadIdx.x;
+            if (s_ < 16 && s_ * 16 >= c0 && s_ * 16 < c1)
+                map[s_] = (unsigned short)occ[s_];
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void sparsify_kernel(const MirrorJobD *__restrict__ jobs, int nb)
 {
+    __shared__ u32 sp[MIRROR_MAX_COLS + 1], su[MIRROR_MAX_COLS + 1];
     const MirrorJobD J = jobs[blockIdx.x];
-    const int per = (nb + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int c0 = (int)blockIdx.y * per, c1 = min(nb, c0 + per);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int c = c0 + wave; c < c1; c += nw)
+    int per = (nb + (int)gridDim.y - 1) / (int)gridDim.y;
+    if (per > MIRROR_MAX_COLS)
+        per = MIRROR_MAX_COLS;
+    for (int c0 = (int)blockIdx.y * per; c0 < nb; c0 += per * (int)gridDim.y)
     {
-        for (u32 p = ptr0(J.lo.ptr, c) + lane; p < J.lo.ptr[c + 1]; p += 64)
-            J.lo.val[p] = J.dense[(size_t)c * nb + J.lo.idx[p]];
-        if (J.up.ptr)
-            for (u32 p = J.up.ptr[c] + lane; p < J.up.ptr[c + 1]; p += 64) // c is a row of the CSR half here
-                J.up.val[p] = J.dense[(size_t)J.up.idx[p] * nb + c];
+        const int c1 = min(nb, c0 + per), ncols = c1 - c0;
+        __syncthreads();
+        for (int i = threadIdx.x; i <= ncols; i += blockDim.x)
+        {
+            sp[i] = ptr0(J.lo.ptr, c0 + i);
+            su[i] = J.ucp ? J.ucp[c0 + i] : 0u;
+        }
+        __syncthreads();
+        const u32 e0 = sp[0], e1 = sp[ncols], f0 = su[0], f1 = su[ncols];
+        for (u32 p = e0 + threadIdx.x; p < e1; p += blockDim.x)
+            J.lo.val[p] = J.dense[(size_t)(c0 + mirror_column_of(sp, ncols, p)) * nb + J.lo.idx[p]];
+        for (u32 p = f0 + threadIdx.x; p < f1; p += blockDim.x)
+            J.uval[J.uvi[p]] = J.dense[(size_t)(c0 + mirror_column_of(su, ncols, p)) * nb + J.uri[p]];
     }
 }
 

@@ -107,7 +107,7 @@ double *obtain_mirror(BlockState &st, int nb)
     return st.mirror;
 }
 
-MirrorJobD mirror_job(slot_t *s, double *dense)
+MirrorJobD mirror_job(slot_t *s, double *dense, int nb)
 {
     MirrorJobD J;
     memset(&J, 0, sizeof(J));
@@ -116,7 +116,11 @@ MirrorJobD mirror_job(slot_t *s, double *dense)
         slot_t *up, *lo;
         diag_halves(s, &up, &lo);
         J.lo = BlkView{lo->d_columnpointer, lo->d_rowindex, lo->d_value};
-        J.up = BlkView{up->d_rowpointer, up->d_columnindex, up->d_value};
+        const DiagAux &aux = get_diag_aux(up, nb);
+        J.ucp = aux.d_cp;
+        J.uri = aux.d_ri;
+        J.uvi = aux.d_vi;
+        J.uval = up->d_value;
     }
     else
     {
@@ -160,7 +164,7 @@ double *current_mirror(slot_t *s, int nb)
         return nullptr;
     if (!st.mirror_current)
     {
-        MP.to_densify.push_back(mirror_job(s, m)); // sparse_current holds whenever mirror_current does not
+        MP.to_densify.push_back(mirror_job(s, m, nb)); // sparse_current holds whenever mirror_current does not
         st.mirror_current = true;
     }
     return m;
@@ -178,7 +182,7 @@ void require_sparse(slot_t *s, int nb)
         return;
     if (!st.sparse_current && st.mirror)
     {
-        MP.to_sparsify.push_back(mirror_job(s, st.mirror));
+        MP.to_sparsify.push_back(mirror_job(s, st.mirror, nb));
         st.sparse_current = true;
     }
 }

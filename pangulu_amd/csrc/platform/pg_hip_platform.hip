@@ -1014,14 +1014,14 @@ struct Backend
     int nb_cfg = 0;
     // options
     long long opt_host_mirror = 1;
-    long long opt_dense_permille = 25;
+    long long opt_dense_permille = 10;
     long long opt_profile = 0;
     long long opt_assume_independent = 0;
     long long opt_getrf_strict = 0;
     long long opt_count_flops = 1;
     long long opt_group_chunk = 8;
     long long opt_small_launch_tasks = 512;
-    long long opt_trsm_dense_permille = 30;
+    long long opt_trsm_dense_permille = 10;
     long long opt_two_streams = 1;
     double mfma_flops_executed = 0;
     // resources
@@ -1641,7 +1641,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         {
             BlockState &st = block_state(s, nb);
             st.mirror_current = true;
-            MP.to_sparsify.push_back(mirror_job(s, st.mirror));
+            MP.to_sparsify.push_back(mirror_job(s, st.mirror, nb));
             st.sparse_current = true;
         }
         if (!MP.to_sparsify.empty())
@@ -1723,12 +1723,12 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                     }
                     else if (!st.sparse_current && st.mirror)
                     {
-                        MP.to_sparsify.push_back(mirror_job(lo, st.mirror));
+                        MP.to_sparsify.push_back(mirror_job(lo, st.mirror, nb));
                     }
                 }
                 else if (!st.sparse_current && st.mirror)
                 {
-                    MP.to_sparsify.push_back(mirror_job(lo, st.mirror));
+                    MP.to_sparsify.push_back(mirror_job(lo, st.mirror, nb));
                 }
                 st.sparse_current = true;
                 st.mirror_current = false;
