@@ -13,12 +13,85 @@ struct BlockState
     u32 brow = 0, bcol = 0, nnz = 0;
 };
 
+// Open-addressing table block key -> BlockState.  Looked up three times per update task (destination and both operands)
+// and emptied at every new factorisation: no node allocations, clear() keeps the capacity.
+struct BlockTable
+{
+    struct Entry
+    {
+        const void *key = nullptr;
+        BlockState st;
+    };
+    std::vector<Entry> tab;
+    size_t mask = 0, count = 0;
+    static size_t hash(const void *k)
+    {
+        unsigned long long x = (unsigned long long)(uintptr_t)k >> 3;
+        x *= 0x9E3779B97F4A7C15ull;
+        return (size_t)(x >> 24);
+    }
+    BlockState *find(const void *k)
+    {
+        if (count == 0)
+            return nullptr;
+        for (size_t i = hash(k) & mask;; i = (i + 1) & mask)
+        {
+            if (tab[i].key == k)
+                return &tab[i].st;
+            if (!tab[i].key)
+                return nullptr;
+        }
+    }
+    // (the reference is valid until the next insertion)
+    BlockState &operator[](const void *k)
+    {
+        if ((count + 1) * 2 > tab.size())
+            grow();
+        for (size_t i = hash(k) & mask;; i = (i + 1) & mask)
+        {
+            if (tab[i].key == k)
+                return tab[i].st;
+            if (!tab[i].key)
+            {
+                tab[i].key = k;
+                tab[i].st = BlockState();
+                count++;
+                return tab[i].st;
+            }
+        }
+    }
+    void grow()
+    {
+        std::vector<Entry> old;
+        old.swap(tab);
+        tab.resize(old.empty() ? (size_t)1 << 16 : old.size() * 2);
+        mask = tab.size() - 1;
+        count = 0;
+        for (const Entry &e : old)
+            if (e.key)
+                (*this)[e.key] = e.st;
+    }
+    void clear()
+    {
+        for (Entry &e : tab)
+            e.key = nullptr;
+        count = 0;
+    }
+    template <class F>
+    void for_each(F f)
+    {
+        for (Entry &e : tab)
+            if (e.key)
+                f(e.st);
+    }
+};
+
 struct MirrorPool
 {
     std::vector<char *> chunks;
     size_t chunk_bytes = 0, cursor = 0, mirror_bytes = 0; // cursor counts mirrors handed out since the last reset
     size_t limit_mirrors = 0;
-    std::unordered_map<const void *, BlockState> blocks; // key: d_value of the (lower half of the) block
+    BlockTable blocks; // key: d_value of the (lower half of the) block
     std::vector<MirrorJobD> to_densify, to_sparsify;
 };
 MirrorPool MP;
@@ -76,8 +149,8 @@ double *obtain_mirror(BlockState &st, int nb)
         for (char *c : MP.chunks)
             HIP_CHECK(hipFree(c));
         MP.chunks.clear();
-        for (auto &kv : MP.blocks)
-            kv.second.mirror = nullptr;
+        MP.blocks.for_each([](BlockState &st)
+                           { st.mirror = nullptr; });
         MP.mirror_bytes = mb;
         MP.cursor = 0;
         size_t free_b = 0, total_b = 0;
@@ -134,10 +207,10 @@ MirrorJobD mirror_job(slot_t *s, double *dense, int nb)
 bool mirror_is_ahead(slot_t *s)
 {
     s = canon_dst(s);
-    auto it = MP.blocks.find(block_key(s));
-    if (it == MP.blocks.end())
+    const BlockState *found = MP.blocks.find(block_key(s));
+    if (!found)
         return false;
-    const BlockState &st = it->second;
+    const BlockState &st = *found;
     return st.brow == s->brow_pos && st.bcol == s->bcol_pos && st.mirror && !st.sparse_current;
 }
 
@@ -145,10 +218,10 @@ bool mirror_is_ahead(slot_t *s)
 const double *lu_image_of(slot_t *half)
 {
     slot_t *lo = canon_dst(half);
-    auto it = MP.blocks.find(block_key(lo));
-    if (it == MP.blocks.end())
+    const BlockState *found = MP.blocks.find(block_key(lo));
+    if (!found)
         return nullptr;
-    const BlockState &st = it->second;
+    const BlockState &st = *found;
     if (st.brow != lo->brow_pos || st.bcol != lo->bcol_pos || !st.lu_image)
         return nullptr;
     return st.mirror;
@@ -174,10 +247,10 @@ double *current_mirror(slot_t *s, int nb)
 void require_sparse(slot_t *s, int nb)
 {
     s = canon_dst(s);
-    auto it = MP.blocks.find(block_key(s));
-    if (it == MP.blocks.end())
+    BlockState *found = MP.blocks.find(block_key(s));
+    if (!found)
         return;
-    BlockState &st = it->second;
+    BlockState &st = *found;
     if (st.brow != s->brow_pos || st.bcol != s->bcol_pos)
         return;
     if (!st.sparse_current && st.mirror)
@@ -189,6 +262,7 @@ void require_sparse(slot_t *s, int nb)
 
 void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify)
 {
+    HostTimer ht(3);
     size_t i = 0;
     while (i < jobs.size())
     {

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1094,6 +1095,16 @@ struct Segment
     }
 };
 
+// host-side cost of preparing launches (PANGULU_HIP_HOST_TIMING=1 prints it with every get_stats(reset))
+double g_host_seconds[6] = {0, 0, 0, 0, 0, 0}; // 0 ssssm, 1 trsm, 2 getrf, 3 mirror jobs, 4 waiting for a staging segment, 5 whole calls
+struct HostTimer
+{
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { g_host_seconds[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 // Record, behind everything launched so far, that the committed segments may be reused.  Must be called AFTER the
 // kernels reading those segments have been launched (an event recorded earlier would let the host overwrite a
 // segment a queued kernel has yet to read).
@@ -1114,7 +1125,10 @@ Segment acquire_segment()
     int i = r.cur;
     r.cur = (r.cur + 1) % Ring::NSEG;
     if (r.used[i])
+    {
+        HostTimer ht(4);
         HIP_CHECK(hipEventSynchronize(r.ev[i])); // the kernels that last read this segment are done
+    }
     Segment s;
     s.h = r.h + (size_t)i * r.seg_bytes;
     s.d = r.d + (size_t)i * r.seg_bytes;
@@ -1278,6 +1292,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
 {
     if (n == 0)
         return;
+    HostTimer ht(0);
     const bool dense_ok = dense_mode_available(nb);
     size_t i = 0;
     while (i < n)
@@ -1484,6 +1499,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
 // ---- TSTRF / GESSM -----------------------------------------------------------------------------------------------
 void launch_trsm(int nb, task_t **list, size_t n)
 {
+    HostTimer ht(1);
     size_t i = 0;
     while (i < n)
     {
@@ -1578,9 +1594,8 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 require_sparse(dst, nb); // updates may have been accumulating in the block's mirror
                 tasks[nsparse++] = T;
 #if defined(CALCULATE_TYPE_R64)
-                auto it = MP.blocks.find(block_key(dst));
-                if (it != MP.blocks.end())
-                    it->second.mirror_current = false; // the sparse solve rewrites the record
+                if (BlockState *found = MP.blocks.find(block_key(dst)))
+                    found->mirror_current = false; // the sparse solve rewrites the record
 #endif
             }
         }
@@ -1665,6 +1680,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
 // for everything these blocks depend on; the caller joins it back)
 void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_join)
 {
+    HostTimer ht(2);
     const int max_slots = 256;
     if (!B.getrf_scratch || B.nb_cfg != nb)
     {
@@ -1996,6 +2012,7 @@ extern "C"
         if (ntask == 0)
             return;
         std::lock_guard<std::mutex> g(B.mutex);
+        HostTimer ht_call(5);
         HIP_CHECK(hipSetDevice(B.device));
         check_lds_budget(nb);
         static thread_local std::vector<task_t *> l_getrf, l_trsm, l_ssssm;
@@ -2177,6 +2194,13 @@ extern "C"
 
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset)
     {
+        if (reset && getenv("PANGULU_HIP_HOST_TIMING"))
+        {
+            fprintf(stderr, "[PanguLU-AMD] host seconds in the back-end: calls %.4f (ssssm %.4f, trsm %.4f, getrf %.4f, mirror jobs %.4f, staging waits %.4f)\n",
+                    g_host_seconds[5], g_host_seconds[0], g_host_seconds[1], g_host_seconds[2], g_host_seconds[3], g_host_seconds[4]);
+            for (double &x : g_host_seconds)
+                x = 0;
+        }
         ensure_ready();
         std::lock_guard<std::mutex> g(B.mutex);
         HIP_CHECK(hipStreamSynchronize(B.stream));

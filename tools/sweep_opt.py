@@ -1,5 +1,5 @@
 """Sweep one back-end option on the bench workload: python tools/sweep_opt.py <option id> v1 v2 ... [--size nx ny]"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import pangulu_amd as pa
 from pangulu_amd import _lib, matrices as M
@@ -23,6 +23,8 @@ for v in vals:
     ts = []
     for i in range(3):
         t0 = time.time(); pa.pangulu_gstrf(h); ts.append(time.time() - t0); lib.pangulu_amd_reset_numeric(h.ref)
+        if os.environ.get('PANGULU_HIP_HOST_TIMING'):
+            print('host sched s', h.info()['time_numeric_host_sched'], flush=True); pa.hip_stats(lib, reset=True)
     st = pa.hip_stats(lib, reset=True)
     print("option", opt, "=", v, "ms", [round(x * 1e3, 1) for x in ts], "GF/s %.0f" % (h.info()["flop"] / min(ts) / 1e9),
           "ssssm dense/sparse", st["ssssm_dense_mfma"]["tasks"] // 3, st["ssssm_sparse"]["tasks"] // 3, "trsm dense", st["tstrf"]["dense_path_tasks"] // 3, flush=True)
