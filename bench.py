@@ -47,9 +47,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[110, 110], help="shell nx ny of the CPU-baseline sample")
-    ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "rccl"), choices=["host", "rccl"],
-                    help="block exchange for --gpus > 1: RCCL send/recv over xGMI (default; verified by a pairwise self-test at "
-                         "start-up, falling back to host staging on failure) or host-staged TCP")
+    ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "ipc"), choices=["host", "rccl", "ipc"],
+                    help="block exchange for --gpus > 1: ipc = the consumer pulls each record out of the owner's HBM arena with "
+                         "one peer copy over xGMI (default), rccl = ncclSend/ncclRecv per ordered pair; both are verified by a "
+                         "self-test at start-up and fall back to host-staged TCP on all ranks together on failure")
     return ap.parse_args()
 
 
@@ -149,11 +150,9 @@ def main():
     if world > 1:
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         base_port = int(os.environ.get("MASTER_PORT", "29500")) + 23
-        transport = _lib.TRANSPORT_RCCL if args.transport == "rccl" else _lib.TRANSPORT_HOST
+        transport = {"host": _lib.TRANSPORT_HOST, "rccl": _lib.TRANSPORT_RCCL, "ipc": _lib.TRANSPORT_IPC}[args.transport]
         rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port, transport, None)
         assert rc == 0
-        # what is really in use: RCCL falls back to host staging on all ranks when its pairwise self-test fails
-        args.transport = "rccl" if lib.pangulu_amd_comm_transport() == _lib.TRANSPORT_RCCL else "host"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -168,6 +167,8 @@ def main():
     h = pa.pangulu_init(n, len(va) if va is not None else 0, cp, ri, va, nb=args.nb, ordering=args.ordering,
                         coords=coords if args.ordering == "nd" else None, nthread=nthreads)
     t_init = time.time() - t0
+    # what is really in use: ipc / rccl fall back to host staging on all ranks together when their self-test fails
+    effective_transport = {0: "host", 1: "rccl", 2: "ipc"}[lib.pangulu_amd_comm_transport()] if world > 1 else "none"
     assert lib.pangulu_amd_snapshot(h.ref) == 0
     info0 = h.info()
     flop = float(info0["flop"])
@@ -262,7 +263,8 @@ def main():
                 "ordering": "built-in nested dissection (geometric)" if args.ordering == "nd" else "identity",
                 "symbolic_nnz": int(info["symbolic_nnz"]), "flop": int(info["flop"]),
                 "parallelism": "2D block-cyclic %dx%d" % grid(world),
-                "transport": args.transport if world > 1 else "none",
+                # what is really in use: ipc / rccl fall back to host staging on all ranks when their self-test fails
+                "transport": effective_transport,
                 "blocks": int(info["nblocks_nondiag"]),
                 "tasks": {"getrf": int(info["ntask_getrf"]), "tstrf": int(info["ntask_tstrf"]), "gessm": int(info["ntask_gessm"]),
                           "ssssm": int(info["ntask_ssssm"])},

@@ -19,6 +19,8 @@ extern "C"
     /* ---- process group ---------------------------------------------------------------------------- */
 #define PANGULU_AMD_TRANSPORT_HOST 0 /* block records staged through host memory over TCP (127.0.0.1) */
 #define PANGULU_AMD_TRANSPORT_RCCL 1 /* device-to-device ncclSend/ncclRecv over xGMI, TCP control plane */
+#define PANGULU_AMD_TRANSPORT_IPC 2  /* one node: the consumer pulls the record out of the owner's HBM arena (HIP IPC mapping,
+                                       * one peer copy over the pair's xGMI link), TCP control plane */
     /* One process per GPU.  `base_port + rank` is the TCP port this rank listens on for the control plane
      * (headers, barriers, broadcasts).  For RCCL, `nccl_unique_id` is the 128-byte ncclUniqueId rank 0 made
      * (pangulu_amd_rccl_unique_id) and the launcher distributed.  Returns 0 on success. */

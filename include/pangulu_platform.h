@@ -266,7 +266,8 @@ extern "C"
         double alg_bytes[6];
         double flops[6];
         double elapsed_ms[6];
-        double mfma_flops_executed; /* 2*nb^3 per task of class 5: what the matrix cores actually did */
+        double mfma_flops_executed; /* class 5: flops the matrix cores actually executed (16x16x16 products issued x 8192;
+                                     *  structurally empty tiles are skipped); counted while COUNT_FLOPS is on */
         unsigned long long trsm_dense_tasks; /* TSTRF/GESSM tasks that took the dense MFMA path */
     } pangulu_hip_stats_t;
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset);

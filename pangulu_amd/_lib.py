@@ -198,6 +198,6 @@ HIP_OPT_SMALL_LAUNCH_TASKS = 11
 HIP_OPT_XCD_SWIZZLE = 12
 
 ORDER_IDENTITY, ORDER_ND, ORDER_USER = 0, 1, 2
-TRANSPORT_HOST, TRANSPORT_RCCL = 0, 1
+TRANSPORT_HOST, TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1, 2
 PLATFORM_CPU_NAIVE = 0x0100000
 PLATFORM_GPU_HIP = 0x0201001

@@ -533,7 +533,11 @@ extern "C"
             else
                 plat.malloc_((void **)&S->arena_snapshot, S->storage.arena_bytes);
         }
-        plat.memcpy_(S->arena_snapshot, S->storage.darena, S->storage.arena_bytes, 2);
+        if (plat.host_memory)
+            plat.memcpy_(S->arena_snapshot, S->storage.darena, S->storage.arena_bytes, 2);
+        else
+            for (size_t c = 0; c < S->storage.dchunks.size(); c++)
+                plat.memcpy_(S->arena_snapshot + c * S->storage.dchunk_bytes, S->storage.dchunks[c], S->storage.chunk_len(c), 2);
         plat.synchronize();
         return 0;
     }
@@ -545,7 +549,11 @@ extern "C"
         if (!S->arena_snapshot)
             return 1;
         plat.synchronize();
-        plat.memcpy_(S->storage.darena, S->arena_snapshot, S->storage.arena_bytes, 2);
+        if (plat.host_memory)
+            plat.memcpy_(S->storage.darena, S->arena_snapshot, S->storage.arena_bytes, 2);
+        else
+            for (size_t c = 0; c < S->storage.dchunks.size(); c++)
+                plat.memcpy_(S->storage.dchunks[c], S->arena_snapshot + c * S->storage.dchunk_bytes, S->storage.chunk_len(c), 2);
         plat.synchronize();
         S->remain = S->remain0;
         S->remain_diag = S->remain_diag0;

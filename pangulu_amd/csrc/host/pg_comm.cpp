@@ -54,6 +54,8 @@ Comm *make_socket_comm(int rank, int size, const char *addr, int base_port, int 
 {
     if (transport == PANGULU_AMD_TRANSPORT_RCCL)
         return make_rccl_comm(rank, size, addr, base_port, nccl_id);
+    if (transport == PANGULU_AMD_TRANSPORT_IPC)
+        return make_ipc_comm(rank, size, addr, base_port);
     SocketComm *c = new SocketComm(rank, size, addr, base_port);
     c->transport = PANGULU_AMD_TRANSPORT_HOST;
     return c;

@@ -227,12 +227,7 @@ struct RcclComm : SocketComm
         }
         // the caller has synchronised the compute stream: the record behind d_value is final
         size_t bytes = h.bytes_lo;
-        Frame f{FRAME_BLOCK, 1, bytes};
-        {
-            std::lock_guard<std::mutex> g(wmutex[(size_t)dst]);
-            write_all(fd[(size_t)dst], &f, sizeof(f));
-            write_all(fd[(size_t)dst], &h, sizeof(h));
-        }
+        post_announcement(dst, 1, h); // (never blocks; per-destination order = order of the ncclSends below)
         HIPC(hipSetDevice(device));
         NCCLC(R.Send((const char *)s->d_value - 32, bytes, NCCL_CHAR, 1, send_comm[(size_t)dst], send_stream[(size_t)dst]));
         sent_bytes += bytes;

@@ -186,6 +186,25 @@ struct SocketComm : Comm
         }
     }
 
+    // header-only block frame through the sender thread: the compute thread posts it while holding the scheduler's
+    // mutex and must never block on a full socket (the peer's receive thread may be waiting for ITS scheduler mutex,
+    // held by a compute thread that is itself writing to us)
+    void post_announcement(int dst, u32 tag, const BlockHeader &h)
+    {
+        SendReq r;
+        r.dst = dst;
+        r.f = Frame{FRAME_BLOCK, tag, h.bytes_lo};
+        r.h = h;
+        r.payload = nullptr;
+        r.payload_bytes = 0;
+        {
+            std::lock_guard<std::mutex> g(qmutex);
+            sendq.push_back(r);
+            inflight++;
+        }
+        qcv.notify_one();
+    }
+
     void send_bytes(int dst, int tag, const void *buf, size_t bytes) override
     {
         Frame f{FRAME_BYTES, (u32)tag, bytes};

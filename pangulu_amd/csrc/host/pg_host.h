@@ -145,7 +145,13 @@ struct Storage
     u32 nb = 0;
     std::vector<slot_t> owned;        // bin 0: off-diagonal owned blocks first, then diagonal halves (lower, upper)
     size_t n_owned_nondiag = 0;
-    char *harena = nullptr, *darena = nullptr;
+    char *harena = nullptr, *darena = nullptr; // darena: host-memory platforms only (== harena)
+    // device arena in separately allocated chunks (records never straddle a chunk): every chunk stays far below
+    // 2 GiB, above which mapping another process's allocation (pg_comm_ipc.cpp) was seen to block forever
+    std::vector<char *> dchunks;
+    size_t dchunk_bytes = 0;
+    char *device_ptr(size_t off) const { return dchunks.empty() ? darena + off : dchunks[off / dchunk_bytes] + off % dchunk_bytes; }
+    size_t chunk_len(size_t c) const { return std::min(dchunk_bytes, arena_bytes - c * dchunk_bytes); }
     size_t arena_bytes = 0;
     std::vector<RecvBin> bins;        // bins[0] unused; 1..6 receive classes
     std::mutex mutex;
@@ -205,6 +211,9 @@ public:
     virtual void recv_block(slot_t *s, const BlockHeader &h, int src) = 0;
     // make sure everything posted has left (called before the slot memory may be reused / at the end)
     virtual void flush_sends() = 0;
+    // collective: the device arena holding every record this rank owns (nullptr: records live in host memory);
+    // transports that copy straight between arenas map their peers' here (pg_comm_ipc.cpp)
+    virtual void register_arena(char *const * /*chunks*/, size_t /*nchunks*/, size_t /*chunk_bytes*/, size_t /*total_bytes*/) {}
     u64 sent_bytes = 0, recv_bytes_total = 0;
 };
 Comm *world();             // never null: a 1-rank loopback by default
@@ -212,6 +221,7 @@ void set_world(Comm *c);   // takes ownership
 Comm *make_socket_comm(int rank, int size, const char *addr, int base_port, int transport, const void *nccl_id);
 int rccl_make_unique_id(void *out128); // 0 on success; librccl.so is loaded lazily
 Comm *make_rccl_comm(int rank, int size, const char *addr, int base_port, const void *nccl_id);
+Comm *make_ipc_comm(int rank, int size, const char *addr, int base_port);
 
 // ---------------------------------------------------------------------------------------------------------
 // the solver instance behind the opaque handle

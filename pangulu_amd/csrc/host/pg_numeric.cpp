@@ -128,7 +128,11 @@ struct Sched
     Comm *comm;
     std::vector<char> sent_flag;
     std::vector<task_t> batch, ssssm_batch, combined;
-    size_t lookahead_max_getrf = 8;  // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
+    size_t lookahead_max_getrf = 8; // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
+    // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
+    size_t gather_min_batch = 64;
+    double gather_max_s = 600e-6, gather_quiet_s = 150e-6, t_gather = 0;
+    double t_last_progress = 0, stall_limit_s = 120; // PANGULU_AMD_STALL_S
     double t_platform = 0;
     u64 batches = 0;
     bool multi;
@@ -137,6 +141,14 @@ struct Sched
     {
         if (const char *e = getenv("PANGULU_AMD_LOOKAHEAD_MAX_GETRF"))
             lookahead_max_getrf = (size_t)atol(e);
+        if (const char *e = getenv("PANGULU_AMD_GATHER_MIN_BATCH"))
+            gather_min_batch = (size_t)atol(e);
+        if (const char *e = getenv("PANGULU_AMD_GATHER_MAX_US"))
+            gather_max_s = 1e-6 * atof(e);
+        if (const char *e = getenv("PANGULU_AMD_GATHER_QUIET_US"))
+            gather_quiet_s = 1e-6 * atof(e);
+        if (const char *e = getenv("PANGULU_AMD_STALL_S"))
+            stall_limit_s = atof(e);
     }
 
     // ---- task creation -------------------------------------------------------------------------------
@@ -576,22 +588,70 @@ struct Sched
             plat.get_device_num(&ndev);
             (void)ndev; // the device was selected at init; HIP's current device is per thread
         }
+        static const bool trace = getenv("PANGULU_AMD_TRACE") != nullptr;
+        double t_trace = wall_seconds();
         while (S.rank_remain_task != 0)
         {
+            if (trace && wall_seconds() - t_trace > 2.0)
+            {
+                t_trace = wall_seconds();
+                fprintf(stderr, "[pangulu_amd trace] rank %d: %lld panel tasks, %lld receives outstanding, %llu updates queued, %llu batches so far\n",
+                        S.rank, (long long)S.rank_remain_task, (long long)S.rank_remain_recv, (unsigned long long)S.pending_total,
+                        (unsigned long long)batches);
+            }
             batch.clear();
             task_t t;
             while (S.heap.pop(t))
                 batch.push_back(t);
+            if (multi && (i64)batch.size() < S.rank_remain_task && batch.size() < gather_min_batch)
+            {
+                // Blocks from other ranks arrive one by one, and every launch costs its latency whatever it carries (a
+                // GETRF launch takes as long for 1 block as for 256): dispatching each arrival on its own degenerates
+                // into thousands of single-task launches.  Keep collecting while arrivals keep coming, for a bounded time.
+                const double t_begin = wall_seconds();
+                double t_last = t_begin;
+                size_t seen = batch.size();
+                while (true)
+                {
+                    const double now = wall_seconds();
+                    if (now - t_begin > gather_max_s || now - t_last > gather_quiet_s)
+                        break;
+                    while (S.heap.pop(t))
+                        batch.push_back(t);
+                    if (batch.size() != seen)
+                    {
+                        seen = batch.size();
+                        t_last = now;
+                        if (seen >= gather_min_batch || (i64)seen >= S.rank_remain_task)
+                            break;
+                    }
+                    else
+                        usleep(5);
+                }
+                t_gather += wall_seconds() - t_begin;
+            }
             if (batch.empty())
             {
                 if (!idle_flush())
                 {
                     if (!multi)
                         fatal("scheduler stalled with %lld panel tasks left and nothing runnable", (long long)S.rank_remain_task);
+                    // waiting for blocks of other ranks: fail loudly instead of hanging if nothing moves for a long time
+                    const double now = wall_seconds();
+                    if (t_last_progress == 0)
+                        t_last_progress = now;
+                    if (now - t_last_progress > stall_limit_s)
+                        fatal("rank %d: no runnable task for %.0f s with %lld panel tasks and %lld block receives outstanding "
+                              "(%llu updates queued): a block that was announced never arrived, or a dependency cycle",
+                              S.rank, now - t_last_progress, (long long)S.rank_remain_task, (long long)S.rank_remain_recv,
+                              (unsigned long long)S.pending_total);
                     usleep(20);
                 }
+                else
+                    t_last_progress = 0;
                 continue;
             }
+            t_last_progress = 0;
             S.rank_remain_task -= (i64)batch.size();
             work_batched();
         }
@@ -686,6 +746,8 @@ void numeric_factorize(Solver &S)
 {
     if (S.factored)
         fatal("pangulu_gstrf called twice on one handle (call pangulu_init again)");
+    if (getenv("PANGULU_AMD_TRACE"))
+        fprintf(stderr, "[pangulu_amd trace] rank %d: numeric factorisation starts\n", S.rank);
     Sched sch(S);
     Comm *comm = world();
     Platform &plat = active_platform();
@@ -726,6 +788,8 @@ void numeric_factorize(Solver &S)
         sch.compute_loop();
         plat.synchronize();
     }
+    if (getenv("PANGULU_AMD_TRACE"))
+        fprintf(stderr, "[pangulu_amd trace] rank %d: compute and receive loops done, entering the final barrier\n", S.rank);
     comm->barrier();
     S.info.time_numeric = wall_seconds() - t0;
     S.info.time_numeric_host_sched = S.info.time_numeric - sch.t_platform;

@@ -175,23 +175,33 @@ void preprocess(Solver &S, const CscMatrix &A)
     auto align64 = [](size_t x)
     { return (x + 63) & ~(size_t)63; };
     size_t cursor = 0;
+    const char *chunk_env = getenv("PANGULU_AMD_ARENA_CHUNK_MB");
+    const size_t chunk = (size_t)(chunk_env ? atol(chunk_env) : 1024) << 20;
+    // place a record of `bytes` at the cursor, or at the start of the next chunk if it would straddle a chunk boundary
+    auto place = [&](size_t bytes)
+    {
+        if (bytes > chunk)
+            fatal("a block record of %zu bytes does not fit an arena chunk (PANGULU_AMD_ARENA_CHUNK_MB)", bytes);
+        if (cursor / chunk != (cursor + bytes - 1) / chunk)
+            cursor = (cursor / chunk + 1) * chunk;
+        size_t at = cursor;
+        cursor = align64(cursor + bytes);
+        return at;
+    };
     for (size_t i = 0; i < owned_bidx.size(); i++)
     {
         u64 b = owned_bidx[i];
         u32 br = P.rowidx[b];
         // block column of b: recover by binary search over colptr
-        off[i] = cursor;
         u32 bc = (u32)(std::upper_bound(P.colptr.begin(), P.colptr.end(), b) - P.colptr.begin() - 1);
-        cursor = align64(cursor + record_bytes(nb, P.nnz[b], br > bc));
+        off[i] = place(record_bytes(nb, P.nnz[b], br > bc));
     }
     for (size_t d = 0; d < owned_diag.size(); d++)
     {
         u32 k = owned_diag[d];
         size_t i = owned_bidx.size() + 2 * d;
-        off[i] = cursor;
-        cursor = align64(cursor + record_bytes(nb, P.diag_lower_nnz[k], false));
-        off[i + 1] = cursor;
-        cursor = align64(cursor + record_bytes(nb, P.diag_upper_nnz[k], false));
+        off[i] = place(record_bytes(nb, P.diag_lower_nnz[k], false));
+        off[i + 1] = place(record_bytes(nb, P.diag_upper_nnz[k], false));
     }
     st.arena_bytes = cursor ? cursor : 64;
     if (posix_memalign((void **)&st.harena, 64, st.arena_bytes) != 0)
@@ -203,7 +213,11 @@ void preprocess(Solver &S, const CscMatrix &A)
     }
     else
     {
-        plat.malloc_((void **)&st.darena, st.arena_bytes);
+        st.dchunk_bytes = chunk;
+        size_t nchunks = (st.arena_bytes + chunk - 1) / chunk;
+        st.dchunks.assign(nchunks, nullptr);
+        for (size_t c = 0; c < nchunks; c++)
+            plat.malloc_((void **)&st.dchunks[c], st.chunk_len(c));
     }
 
     S.slot_of.assign(nblk, nullptr);
@@ -221,7 +235,7 @@ void preprocess(Solver &S, const CscMatrix &A)
         s.bin_id = 0;
         s.slot_idx = (i32)i;
         s.data_status = PANGULU_DATA_PREPARING;
-        bind_record(s, nb, P.nnz[b], st.harena + off[i], st.darena + off[i], br > bc, false);
+        bind_record(s, nb, P.nnz[b], st.harena + off[i], st.device_ptr(off[i]), br > bc, false);
         S.slot_of[b] = &s;
     }
     for (size_t d = 0; d < owned_diag.size(); d++)
@@ -237,8 +251,8 @@ void preprocess(Solver &S, const CscMatrix &A)
         lo.related_block = &up;
         up.related_block = &lo;
         lo.data_status = up.data_status = PANGULU_DATA_PREPARING;
-        bind_record(lo, nb, P.diag_lower_nnz[k], st.harena + off[i], st.darena + off[i], false, false);
-        bind_record(up, nb, P.diag_upper_nnz[k], st.harena + off[i + 1], st.darena + off[i + 1], false, true);
+        bind_record(lo, nb, P.diag_lower_nnz[k], st.harena + off[i], st.device_ptr(off[i]), false, false);
+        bind_record(up, nb, P.diag_upper_nnz[k], st.harena + off[i + 1], st.device_ptr(off[i + 1]), false, true);
         S.diag_lower[k] = &lo;
         S.diag_upper[k] = &up;
     }
@@ -624,12 +638,15 @@ void preprocess(Solver &S, const CscMatrix &A)
     // ---- upload -------------------------------------------------------------------------------------------
     if (!plat.host_memory)
     {
-        plat.memcpy_(st.darena, st.harena, st.arena_bytes, 0);
+        for (size_t c = 0; c < st.dchunks.size(); c++)
+            plat.memcpy_(st.dchunks[c], st.harena + c * st.dchunk_bytes, st.chunk_len(c), 0);
         plat.synchronize();
         if (plat.prepare_diag)
             for (u32 k : owned_diag)
                 plat.prepare_diag((pangulu_inblock_idx)nb, S.diag_lower[k]);
     }
+    if (world()->size > 1)
+        world()->register_arena(st.dchunks.data(), plat.host_memory ? 0 : st.dchunks.size(), st.dchunk_bytes, st.arena_bytes); // (collective)
     S.host_values_current = true;
 }
 
@@ -643,7 +660,8 @@ void download_factors(Solver &S)
         plat.synchronize();
         // values are the only part of a record the numeric phase changes; one pass over the arena is simpler
         // and, with records being value-dominated, barely more traffic than per-block copies
-        plat.memcpy_(S.storage.harena, S.storage.darena, S.storage.arena_bytes, 1);
+        for (size_t c = 0; c < S.storage.dchunks.size(); c++)
+            plat.memcpy_(S.storage.harena + c * S.storage.dchunk_bytes, S.storage.dchunks[c], S.storage.chunk_len(c), 1);
     }
     S.host_values_current = true;
 }
@@ -660,8 +678,9 @@ Solver::~Solver()
     }
     if (storage.harena)
     {
-        if (!plat.host_memory && storage.darena)
-            plat.free_(storage.darena);
+        for (char *c : storage.dchunks)
+            if (c)
+                plat.free_(c);
         free(storage.harena);
     }
     for (auto &bin : storage.bins)

@@ -40,7 +40,8 @@ __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 #define DG_WAVES_PER_EU 2 // two workgroups per CU: one stages its slab while the other feeds the matrix cores
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PER_EU, DG_WAVES_PER_EU))) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
-                                                               const SsssmTaskD *__restrict__ tasks, int nb)
+                                                               const SsssmTaskD *__restrict__ tasks, int nb,
+                                                               unsigned long long *__restrict__ product_counter)
 {
     __shared__ __align__(16) double sA[DG_K * DG_LD];
     __shared__ __align__(16) double sB[DG_K * DG_LD];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     unsigned long long todo = 0;
     int done_steps = 0; // (only nb > 256: slabs of the current task handed out so far, 64 at a time)
     const unsigned short *t_ma = nullptr, *t_mb = nullptr;
-    unsigned nxt_ab = 0xFF, nxt_bb = 0xFF, cur_ab, cur_bb, touched = 0;
+    unsigned nxt_ab = 0xFF, nxt_bb = 0xFF, cur_ab, cur_bb, touched = 0, nprod = 0;
 
 #define DG_NEXT_STEP(out_)                                                                           \
     {                                                                                                \
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         const unsigned a4 = (cur_ab >> (wm / 16)) & 0xFu, b4 = (cur_bb >> (wn / 16)) & 0xFu;
         if (a4 && b4)
         {
+            nprod += (unsigned)(__builtin_popcount(a4) * __builtin_popcount(b4));
 #pragma unroll
             for (int ni = 0; ni < 4; ni++)
                 if ((b4 >> ni) & 1u)
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     }
 #undef DG_NEXT_STEP
 #undef DG_LOAD_SLAB
+    if (product_counter && lane == 0 && nprod)
+        atomicAdd(product_counter, (unsigned long long)nprod); // 16 x 16 x 16 products issued to the matrix cores
 
     double *__restrict__ C = G.cdense;
 #pragma unroll

@@ -1476,7 +1476,8 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             {
                 LaunchTimer lt(5, ds);
                 int tiles = nb / DG_TILE;
-                hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, ds, d_groups_d, d_tasks_d, nb);
+                hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, ds, d_groups_d, d_tasks_d, nb,
+                                   B.opt_count_flops ? B.d_flops + 6 : nullptr);
             }
             if (B.opt_count_flops)
                 hipLaunchKernelGGL(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, ds, d_tasks_d, nb, B.d_flops + 5);
@@ -1488,7 +1489,6 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             B.stats.launches[5]++;
             B.stats.tasks[5] += nd;
             B.stats.alg_bytes[5] += bytes_d;
-            B.mfma_flops_executed += 2.0 * (double)nb * nb * nb * (double)nd;
         }
 #endif
         HIP_CHECK(hipGetLastError());
@@ -2212,7 +2212,7 @@ extern "C"
                     f[8], f[9], f[10], f[11], f[12], f[13], f[14]);
         for (int c = 1; c <= 5; c++)
             B.stats.flops[c] = (double)f[c];
-        B.stats.mfma_flops_executed = B.mfma_flops_executed;
+        B.stats.mfma_flops_executed = 8192.0 * (double)f[6]; // 16 x 16 x 16 products counted by the MFMA update kernel
         if (out)
             *out = B.stats;
         if (reset)

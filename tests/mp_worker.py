@@ -31,7 +31,8 @@ def main():
     else:
         lib.pangulu_amd_use_builtin_platform()  # every rank on the one GPU of the test box (LOCAL_RANK % device count)
     base_port = int(os.environ["MASTER_PORT"]) + 40
-    assert lib.pangulu_amd_comm_init(rank, world, b"127.0.0.1", base_port, _lib.TRANSPORT_HOST, None) == 0
+    transport = {"host": _lib.TRANSPORT_HOST, "ipc": _lib.TRANSPORT_IPC, "rccl": _lib.TRANSPORT_RCCL}[os.environ.get("PANGULU_TEST_TRANSPORT", "host")]
+    assert lib.pangulu_amd_comm_init(rank, world, b"127.0.0.1", base_port, transport, None) == 0
     dtype = _lib.VALUE_TYPES[vtype][0]
     gen = {"fem27_6": lambda: M.fem27(6, dtype=dtype), "poisson8": lambda: M.poisson3d(8, dtype=dtype),
            "shell_8x7": lambda: M.shell(8, 7, dtype=dtype), "trefethen": lambda: M.trefethen(dtype=dtype),
@@ -59,7 +60,8 @@ def main():
         np.savez(out_path, L_data=Ls.tocsc().data, L_ind=Ls.tocsc().indices, L_ptr=Ls.tocsc().indptr,
                  U_data=Us.tocsc().data, U_ind=Us.tocsc().indices, U_ptr=Us.tocsc().indptr, residual=res,
                  flop=parts[0][2]["flop"], sent=[p[2]["sent_bytes"] for p in parts], recv=[p[2]["recv_bytes"] for p in parts],
-                 recv_blocks=[p[2]["recv_blocks"] for p in parts], tasks=[p[2]["ntask_ssssm"] for p in parts])
+                 recv_blocks=[p[2]["recv_blocks"] for p in parts], tasks=[p[2]["ntask_ssssm"] for p in parts],
+                 transport=int(lib.pangulu_amd_comm_transport()))
     pa.pangulu_finalize(h)
     lib.pangulu_amd_comm_finalize()
     dist.barrier()

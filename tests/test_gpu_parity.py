@@ -165,3 +165,16 @@ def test_reference_style_per_task_calls_with_host_mirror():
     pa.pangulu_finalize(h)
     ref = factorize(mat, 32, oracle_library("r64"))
     assert max_rel_diff(L, ref["L"]) <= 1e-12 and max_rel_diff(U, ref["U"]) <= 1e-12
+
+
+def test_chunked_device_arena(monkeypatch):
+    """The device arena is a list of separately allocated chunks (records never straddle one; pg_preprocess.cpp).  With
+    1 MiB chunks a small matrix already spans many of them: upload, kernels, snapshot-free download and the solve must
+    not notice."""
+    monkeypatch.setenv("PANGULU_AMD_ARENA_CHUNK_MB", "1")
+    mat = M.fem27(10)
+    gpu = factorize(mat, 256, "hip", ordering="nd")
+    ref = factorize(mat, 256, oracle_library("r64"), ordering="nd")
+    for f in ("L", "U"):
+        assert max_rel_diff(gpu[f], ref[f]) <= 1e-12
+    assert gpu["residual"] <= 1e-12 and lu_check(mat, gpu) <= 1e-12

@@ -25,12 +25,12 @@ def free_port():
     return p
 
 
-def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle"):
+def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transport="host"):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", PANGULU_TEST_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), spec, str(nb), out_path, vtype, platform],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -86,4 +86,38 @@ def test_multirank_on_the_gpu_host_staged(tmp_path, world, spec, nb):
     L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
     U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
     assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
+    assert float(z["residual"]) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (3, "shell_8x7", 24)])
+def test_multirank_on_the_gpu_peer_copies(tmp_path, world, spec, nb):
+    """The one-node transport: every rank maps its peers' HBM arenas (HIP IPC) and pulls announced records with one
+    device-to-device copy.  On the single-GPU test box all ranks share the device, which exercises the mapping,
+    the announcements and the pulls (not the xGMI links)."""
+    from pangulu_amd import _lib
+
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, platform="hip", transport="ipc")
+    z = np.load(out)
+    assert int(z["transport"]) == _lib.TRANSPORT_IPC, "peer-copy transport fell back to host staging"
+    mat = GENS[spec]()
+    n = len(z["L_ptr"]) - 1
+    ref = factorize(mat, nb, oracle_library("r64"), ordering="nd")
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
+    assert float(z["residual"]) < 1e-13
+    assert sum(z["sent"]) == sum(z["recv"]) and sum(z["recv"]) > 0
+
+
+def test_ipc_transport_falls_back_on_a_host_memory_platform(tmp_path):
+    """Requesting peer copies where there is no device arena (the CPU oracle platform) must degrade to host staging on
+    all ranks together, not fail."""
+    from pangulu_amd import _lib
+
+    out = str(tmp_path / "out.npz")
+    run_ranks(2, "fem27_6", 32, out, transport="ipc")
+    z = np.load(out)
+    assert int(z["transport"]) == _lib.TRANSPORT_HOST
     assert float(z["residual"]) < 1e-13

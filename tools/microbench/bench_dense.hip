@@ -62,7 +62,7 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 3; rep++)
     {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3(ngroups * tiles * tiles), dim3(256), 0, 0, dG, dT, nb);
+        hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3(ngroups * tiles * tiles), dim3(256), 0, 0, dG, dT, nb, nullptr);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         double flop = 2.0 * nb * nb * nb * (double)ngroups * tpg;
