@@ -130,8 +130,8 @@ struct Sched
     std::vector<task_t> batch, ssssm_batch, combined;
     size_t lookahead_max_getrf = 8; // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
-    size_t gather_min_batch = 64;
-    double gather_max_s = 600e-6, gather_quiet_s = 150e-6, t_gather = 0;
+    size_t gather_min_batch = 256;
+    double gather_max_s = 2000e-6, gather_quiet_s = 300e-6, t_gather = 0;
     double t_last_progress = 0, stall_limit_s = 120; // PANGULU_AMD_STALL_S
     double t_platform = 0;
     u64 batches = 0;

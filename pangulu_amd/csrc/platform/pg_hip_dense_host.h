@@ -10,6 +10,7 @@ struct BlockState
     bool mirror_current = false; // mirror holds the block's current values
     bool sparse_current = true;  // the sparse record holds the block's current values
     bool lu_image = false;       // diagonal block: the mirror holds L\\U with inverted diagonal tiles (pg_hip_trsm_dense.h)
+    unsigned char image_halves = 0; // ... of which triangles: 1 = strictly lower (L), 2 = upper (U)
     u32 brow = 0, bcol = 0, nnz = 0;
 };
 
@@ -222,9 +223,47 @@ const double *lu_image_of(slot_t *half)
     if (!found)
         return nullptr;
     const BlockState &st = *found;
-    if (st.brow != lo->brow_pos || st.bcol != lo->bcol_pos || !st.lu_image)
+    if (st.brow != lo->brow_pos || st.bcol != lo->bcol_pos || !st.lu_image || !(st.image_halves & (half->is_upper ? 2 : 1)))
         return nullptr;
     return st.mirror;
+}
+
+// A diagonal block factorised on another rank has no image here: queue one to be built from the halves that have
+// arrived (pg_hip_trsm_dense.h, half_image_kernel).  Returns the mirror, or nullptr when the pool is exhausted.
+std::vector<HalfImageJobD> g_half_image_jobs;
+const double *request_half_image(slot_t *half, int nb)
+{
+    slot_t *key_slot = canon_dst(half);
+    BlockState &st = block_state(key_slot, nb);
+    double *m = obtain_mirror(st, nb);
+    if (!m)
+        return nullptr;
+    slot_t *lower = half->is_upper ? half->related_block : half;
+    slot_t *upper = half->is_upper ? half : half->related_block;
+    HalfImageJobD J;
+    memset(&J, 0, sizeof(J));
+    unsigned char halves = 0;
+    if (lower && lower->d_columnpointer)
+    {
+        J.lcp = lower->d_columnpointer;
+        J.lri = lower->d_rowindex;
+        J.lval = lower->d_value;
+        halves |= 1;
+    }
+    if (upper && upper->d_rowpointer)
+    {
+        J.urp = upper->d_rowpointer;
+        J.uci = upper->d_columnindex;
+        J.uval = upper->d_value;
+        halves |= 2;
+    }
+    J.dense = m;
+    g_half_image_jobs.push_back(J);
+    st.lu_image = true;
+    st.image_halves = halves;
+    st.mirror_current = false; // (the mirror is an image now, not the block)
+    st.sparse_current = true;
+    return m;
 }
 
 // make sure the block has a mirror holding its current values; queues a densify job if it has to be (re)built.

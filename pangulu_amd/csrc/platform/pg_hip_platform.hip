@@ -1504,7 +1504,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
     while (i < n)
     {
         Segment seg = acquire_segment();
-        size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64));
+        size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64 + 80)); // (+80: a remote-diagonal image job per task at worst)
         TrsmTaskD *d_tasks, *d_ftasks;
         TrsmTaskD *tasks = seg.alloc<TrsmTaskD>(take, &d_tasks);
         TrsmTaskD *ftasks = seg.alloc<TrsmTaskD>(take, &d_ftasks); // sparse views of the dense-path tasks (flop counting)
@@ -1568,6 +1568,8 @@ void launch_trsm(int nb, task_t **list, size_t n)
             {
                 const double *lu = lu_image_of(half);
                 const bool filled = (u64)nnz_b * 1000ull >= (u64)B.opt_trsm_dense_permille * (u64)nb * (u64)nb;
+                if (!lu && (filled || mirror_is_ahead(dst)))
+                    lu = request_half_image(half, nb); // a diagonal block another rank factorised
                 if (lu && (filled || mirror_is_ahead(dst)))
                 {
                     double *bm = current_mirror(dst, nb);
@@ -1604,6 +1606,29 @@ void launch_trsm(int nb, task_t **list, size_t n)
             flush_mirror_jobs(nb, MP.to_sparsify, false);
         if (!MP.to_densify.empty())
             flush_mirror_jobs(nb, MP.to_densify, true);
+        if (!g_half_image_jobs.empty())
+        {
+            // images of remote diagonal blocks: build, then invert their diagonal tiles (main stream, before the solves)
+            const size_t nj = g_half_image_jobs.size();
+            HalfImageJobD *d_jobs;
+            HalfImageJobD *hj = seg.alloc<HalfImageJobD>(nj, &d_jobs);
+            double **d_imgs;
+            double **imgs = seg.alloc<double *>(nj, &d_imgs);
+            if (!hj || !imgs)
+            {
+                fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
+                exit(EXIT_FAILURE);
+            }
+            for (size_t q = 0; q < nj; q++)
+            {
+                hj[q] = g_half_image_jobs[q];
+                imgs[q] = g_half_image_jobs[q].dense;
+            }
+            g_half_image_jobs.clear();
+            hipLaunchKernelGGL(half_image_kernel, dim3((unsigned)nj), dim3(1024), sizeof(u32) * (size_t)(nb + 1), B.stream, d_jobs, nb);
+            hipLaunchKernelGGL(diag_tile_inverse_kernel, dim3((unsigned)(nj * (nb / 16))), dim3(64), 0, B.stream, d_imgs, nb);
+            HIP_CHECK(hipGetLastError());
+        }
 #endif
         commit_segment(seg);
 #if defined(CALCULATE_TYPE_R64)
@@ -1736,6 +1761,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         T.preloaded = (st.mirror_current && !st.sparse_current) ? 1u : 0u;
                         lu_images.push_back(m);
                         st.lu_image = true;
+                        st.image_halves = 3;
                     }
                     else if (!st.sparse_current && st.mirror)
                     {

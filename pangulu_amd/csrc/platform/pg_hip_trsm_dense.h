@@ -73,6 +73,48 @@ __global__ __launch_bounds__(64) void diag_tile_inverse_kernel(double *const *__
     }
 }
 
+// LU image of a diagonal block factorised on ANOTHER rank, from whichever of its halves have arrived (strictly lower CSC
+// half, upper CSR half): one workgroup per image clears it and scatters the halves flat over their entries; the
+// 16 x 16 diagonal tiles are then inverted by diag_tile_inverse_kernel like those of local images.  A missing half
+// leaves its triangle zero; the solves that need only the other triangle never read it.
+struct HalfImageJobD
+{
+    const u32 *lcp; // lower half, CSC (nullptr: not here)
+    const u16 *lri;
+    const double *lval;
+    const u32 *urp; // upper half, CSR (nullptr: not here)
+    const u16 *uci;
+    const double *uval;
+    double *dense;
+};
+
+__global__ __launch_bounds__(1024) void half_image_kernel(const HalfImageJobD *__restrict__ jobs, int nb)
+{
+    extern __shared__ u32 s_ptr[]; // nb + 1 entries
+    const HalfImageJobD J = jobs[blockIdx.x];
+    for (int i = threadIdx.x; i < nb * nb / 2; i += blockDim.x)
+        reinterpret_cast<double2 *>(J.dense)[i] = make_double2(0.0, 0.0);
+    if (J.lcp)
+    {
+        for (int i = threadIdx.x; i <= nb; i += blockDim.x)
+            s_ptr[i] = ptr0(J.lcp, i);
+        __syncthreads(); // (also orders the clearing before the scatter)
+        const u32 n = s_ptr[nb];
+        for (u32 p = threadIdx.x; p < n; p += blockDim.x)
+            J.dense[(size_t)mirror_column_of(s_ptr, nb, p) * nb + J.lri[p]] = J.lval[p];
+    }
+    __syncthreads();
+    if (J.urp)
+    {
+        for (int i = threadIdx.x; i <= nb; i += blockDim.x)
+            s_ptr[i] = J.urp[i];
+        __syncthreads();
+        const u32 n = s_ptr[nb];
+        for (u32 p = threadIdx.x; p < n; p += blockDim.x)
+            J.dense[(size_t)J.uci[p] * nb + mirror_column_of(s_ptr, nb, p)] = J.uval[p];
+    }
+}
+
 // grid = tasks * (nb / 64); workgroup = 4 wavefronts; every wavefront solves 16 rows (TSTRF) or 16 columns (GESSM) of
 // the block on its own and keeps ALL its finished 16 x 16 solution tiles in registers (NP tiles x 4 f64): a finished
 // tile in accumulator layout is exactly the B operand the later panels need (register g <-> k = 4g + (l >> 4)).

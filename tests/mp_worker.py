@@ -36,7 +36,8 @@ def main():
     dtype = _lib.VALUE_TYPES[vtype][0]
     gen = {"fem27_6": lambda: M.fem27(6, dtype=dtype), "poisson8": lambda: M.poisson3d(8, dtype=dtype),
            "shell_8x7": lambda: M.shell(8, 7, dtype=dtype), "trefethen": lambda: M.trefethen(dtype=dtype),
-           "random200": lambda: M.random_pattern(200, 0.03, 5, dtype=dtype)}[spec]
+           "random200": lambda: M.random_pattern(200, 0.03, 5, dtype=dtype), "fem27_9": lambda: M.fem27(9, dtype=dtype),
+           "shell_20x16": lambda: M.shell(20, 16, dtype=dtype)}[spec]
     n, cp, ri, va, co = gen()
     ordering = "identity" if spec == "trefethen" else "nd"
     if rank == 0:

@@ -47,7 +47,8 @@ def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transpo
 
 
 GENS = {"fem27_6": lambda: M.fem27(6), "poisson8": lambda: M.poisson3d(8), "shell_8x7": lambda: M.shell(8, 7),
-        "trefethen": lambda: M.trefethen(), "random200": lambda: M.random_pattern(200, 0.03, 5)}
+        "trefethen": lambda: M.trefethen(), "random200": lambda: M.random_pattern(200, 0.03, 5), "fem27_9": lambda: M.fem27(9),
+        "shell_20x16": lambda: M.shell(20, 16)}
 
 
 @pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (2, "trefethen", 4), (4, "poisson8", 32), (4, "trefethen", 4),
@@ -90,11 +91,12 @@ def test_multirank_on_the_gpu_host_staged(tmp_path, world, spec, nb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (3, "shell_8x7", 24)])
+@pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (3, "shell_8x7", 24), (2, "fem27_9", 128), (4, "shell_20x16", 128)])
 def test_multirank_on_the_gpu_peer_copies(tmp_path, world, spec, nb):
     """The one-node transport: every rank maps its peers' HBM arenas (HIP IPC) and pulls announced records with one
     device-to-device copy.  On the single-GPU test box all ranks share the device, which exercises the mapping,
-    the announcements and the pulls (not the xGMI links)."""
+    the announcements and the pulls (not the xGMI links).  The nb = 128 cases run the dense (MFMA) paths, including
+    solves against diagonal blocks another rank factorised (LU images rebuilt from the received halves)."""
     from pangulu_amd import _lib
 
     out = str(tmp_path / "out.npz")
