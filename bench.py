@@ -202,6 +202,7 @@ def main():
     info = h.info()
     stats_timed = pa.hip_stats(lib, reset=True)
 
+    default_workload = (not args.mtx and args.workload == "shell" and not args.size and args.nb == 256 and args.ordering == "nd")
     # one extra, un-timed factorisation with per-launch hipEvents to attribute time to kernels
     roofline = None
     kernels = {}
@@ -229,12 +230,24 @@ def main():
                 roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
                             # `achieved` counts the structural (algorithmic) flops of the tasks; the matrix cores execute
-                            # 2*nb^3 per task on the zero-filled mirrors, which is this rate:
+                            # whole 16x16x16 tile products wherever both operand tiles hold pattern entries, at this rate:
                             "mfma_executed_tflops": v["mfma_flops_executed"] / sec / 1e12}
             else:
                 ach = v["alg_bytes"] / sec / 1e9
                 roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process, so the value
+            # is the one the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes measured for this exact workload
+            # (profiles/r01m_final_shell398.md; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+            rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_blocked_f64_kernel",
+                            "tstrf": "void trsm_dense_f64_kernel<16>", "gessm": "void trsm_dense_f64_kernel<16>",
+                            "ssssm_sparse": "void ssssm_sparse_kernel<false>"}.get(dom)
+            traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01m_hbm_traffic_shell398.json")
+            if world == 1 and default_workload and rocprof_name and os.path.exists(traffic_file):
+                t = json.load(open(traffic_file)).get(rocprof_name)
+                if t:
+                    roofline["traffic"] = t["hbm_bytes_per_launch"]
+                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass, profiles/r01m_final_shell398.md)"
             roofline["avg_launch_us"] = kernels[dom]["avg_launch_us"]
             roofline["share_of_kernel_time"] = kernels[dom]["ms"] / sum(k["ms"] for k in kernels.values())
 

@@ -1,55 +1,62 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (kernel stats + one --pmc pass per counter) into one per-kernel table.
+"""Condense rocprofv3 CSV output (one --kernel-trace --stats run + one --pmc pass per counter group) into one table.
 
-    python tools/summarize_rocprof.py <stats_dir> [<pmc_dir> ...] > profiles/<name>.md
+    python tools/summarize_rocprof.py <stats_dir> [<pmc_dir> ...] [--json out.json] > profiles/<name>.md
 
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for
-wide coalesced reads (MI355X_MICROARCH.md, HBM section), so "fetch x2" is the corrected upper estimate.
+FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced
+reads (MI355X_MICROARCH.md, HBM section), so reads are doubled before they are compared with byte counts.
+SQ_* cycle counters are per-SE quad-cycles as that guide describes; only ratios between them are used here.
 """
-import collections
-import csv
-import glob
-import os
-import sys
+import collections, csv, glob, json, os, sys
 
 
-def kernel_stats(d):
-    rows = []
-    for f in glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")):
-        rows += list(csv.DictReader(open(f)))
-    return rows
-
-
-def pmc(d):
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    cnt = collections.defaultdict(int)
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
-        for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0]
-            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-            cnt[(k, row["Counter_Name"])] += 1
-    return agg, cnt
+def files(d, suffix):
+    return glob.glob(os.path.join(d, "*" + suffix)) + glob.glob(os.path.join(d, "*", "*" + suffix))
 
 
 def main():
-    stats = kernel_stats(sys.argv[1])
-    counters = collections.defaultdict(dict)
-    for d in sys.argv[2:]:
-        agg, cnt = pmc(d)
-        for k, v in agg.items():
-            for c, s in v.items():
-                counters[k][c] = (s, cnt[(k, c)])
-    print("| kernel | calls | total ms | avg us | % | FETCH_SIZE GB (x2) | WRITE_SIZE GB | HBM GB per launch (fetch x2 + write) |")
-    print("|---|---|---|---|---|---|---|---|")
+    args = sys.argv[1:]
+    out_json = None
+    if "--json" in args:
+        k = args.index("--json"); out_json = args[k + 1]; args = args[:k] + args[k + 2:]
+    stats = []
+    for f in files(args[0], "_kernel_stats.csv"):
+        stats += list(csv.DictReader(open(f)))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(lambda: collections.defaultdict(set))
+    for d in args[1:]:
+        for f in files(d, "_counter_collection.csv"):
+            for row in csv.DictReader(open(f)):
+                k = row["Kernel_Name"].split("(")[0]
+                agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                disp[k][row["Counter_Name"]].add(row["Dispatch_Id"])
+    cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+            "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE"]
+    print("| kernel | calls | total ms | avg us | % | HBM read GB (FETCH_SIZE x2) | HBM write GB | HBM MB per launch | waiting % of wave cycles | issue-stalled % | MFMA pipes busy % (of 1024 SIMDs) |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    summary = {}
     for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"])):
         name = r["Name"].split("(")[0]
-        c = counters.get(name, {})
-        fetch = c.get("FETCH_SIZE", (0, 0))[0] * 1024 / 1e9
-        write = c.get("WRITE_SIZE", (0, 0))[0] * 1024 / 1e9
+        if "rocclr" in name:
+            continue
+        c = agg.get(name, {})
+        n = {k: max(1, len(disp[name][k])) for k in c}
         calls = int(r["Calls"])
-        per = (2 * fetch + write) / calls if calls and c else float("nan")
-        print("| %s | %d | %.2f | %.1f | %.2f | %.2f (%.2f) | %.2f | %.4f |" % (
-            name, calls, float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"]), fetch, 2 * fetch, write, per))
+        fetch = 2 * c.get("FETCH_SIZE", 0) * 1024 / n.get("FETCH_SIZE", 1)  # bytes per launch
+        write = c.get("WRITE_SIZE", 0) * 1024 / n.get("WRITE_SIZE", 1)
+        wc = c.get("SQ_WAVE_CYCLES", 0)
+        wait = 100 * c.get("SQ_WAIT_ANY", 0) / wc if wc else float("nan")
+        stall = 100 * c.get("SQ_WAIT_INST_ANY", 0) / wc if wc else float("nan")
+        # GRBM_GUI_ACTIVE sums the 8 XCDs; MFMA busy cycles sum the 1024 SIMDs (256 CUs x 4)
+        mfma = 100 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (c["GRBM_GUI_ACTIVE"] / 8 * 1024) if c.get("GRBM_GUI_ACTIVE") else float("nan")
+        print("| %s | %d | %.1f | %.0f | %.1f | %.2f | %.2f | %.1f | %.0f | %.0f | %s |" % (
+            name[:44], calls, float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"]),
+            fetch * calls / 1e9, write * calls / 1e9, (fetch + write) / 1e6, wait, stall,
+            ("%.1f (%.3g MFMA f64 16x16x4)" % (mfma, c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) / 4)) if c.get("GRBM_GUI_ACTIVE") else "n/a"))
+        summary[name] = {"calls": calls, "avg_us": float(r["AverageNs"]) / 1e3, "hbm_bytes_per_launch": fetch + write,
+                         "fetch_bytes_per_launch_x2": fetch, "write_bytes_per_launch": write}
+    if out_json:
+        json.dump(summary, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
