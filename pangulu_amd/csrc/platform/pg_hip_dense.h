@@ -35,6 +35,7 @@ __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 #define DG_TILE 128
 #define DG_K 16
 #define DG_LD 144 // padded slab row (doubles): rows of consecutive k land 32 banks apart
+#define DG_WINDOW 16 // tasks whose bookkeeping is held in LDS at a time
 
 #ifndef DG_WAVES_PER_EU
 #define DG_WAVES_PER_EU 2 // two workgroups per CU: one stages its slab while the other feeds the matrix cores
@@ -86,29 +87,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     int cur_t = -1, nxt_step = -1;
     unsigned long long todo = 0;
     int done_steps = 0; // (only nb > 256: slabs of the current task handed out so far, 64 at a time)
-    const unsigned short *t_ma = nullptr, *t_mb = nullptr;
     unsigned nxt_ab = 0xFF, nxt_bb = 0xFF, cur_ab, cur_bb, touched = 0, nprod = 0;
+    const double *nxt_pa = nullptr, *nxt_pb = nullptr; // mirrors of the task the next step belongs to
+    // Per-task bookkeeping of up to DG_WINDOW tasks at a time lives in LDS, filled by all 256 threads at once (thread
+    // = one (task, slab) pair): chasing task -> mirror -> map through global memory once per task costs microseconds
+    // of exposed latency per task, more than the slabs of a sparse update themselves.
+    __shared__ unsigned short s_abbb[DG_WINDOW * 16];     // (bbits << 8) | abits of (task, slab); 0 = nothing to do
+    __shared__ unsigned s_live[DG_WINDOW];               // per task: which slabs are live
+    __shared__ const double *s_pa[DG_WINDOW], *s_pb[DG_WINDOW];
+    int win0 = -DG_WINDOW; // first task of the window in the tables
+
+#define DG_FILL_WINDOW()                                                                             \
+    {                                                                                                \
+        __syncthreads(); /* nobody reads the previous window any more */                             \
+        const int t_ = tid >> 4, s_ = tid & 15;                                                      \
+        unsigned v_ = 0;                                                                             \
+        if (win0 + t_ < (int)ntask && s_ < steps_per_task)                                           \
+        {                                                                                            \
+            const SsssmTaskD &Tm_ = tasks[G.task_begin + win0 + t_];                                 \
+            const unsigned ab_ = ((unsigned)mirror_map(Tm_.a.val, nb)[s_] >> (M0 / 16)) & 0xFFu;     \
+            const uint4 mb_ = *reinterpret_cast<const uint4 *>(mirror_map(Tm_.b.val, nb) + N0 / 16); \
+            const unsigned w_[4] = {mb_.x, mb_.y, mb_.z, mb_.w};                                     \
+            unsigned bb_ = 0;                                                                        \
+            _Pragma("unroll") for (int c_ = 0; c_ < 8; c_++)                                         \
+                bb_ |= (((w_[c_ >> 1] >> (16 * (c_ & 1))) >> s_) & 1u) << c_;                        \
+            if (ab_ && bb_)                                                                          \
+                v_ = (bb_ << 8) | ab_;                                                               \
+            if (s_ == 0)                                                                             \
+            {                                                                                        \
+                s_pa[t_] = Tm_.a.val;                                                                \
+                s_pb[t_] = Tm_.b.val;                                                                \
+            }                                                                                        \
+        }                                                                                            \
+        s_abbb[tid] = (unsigned short)v_;                                                            \
+        const unsigned long long bal_ = __ballot(v_ != 0);                                           \
+        if ((tid & 63) < 4)                                                                          \
+            s_live[(tid >> 6) * 4 + (tid & 63)] = (unsigned)((bal_ >> (16 * (tid & 63))) & 0xFFFFull); \
+        __syncthreads();                                                                             \
+    }
 
 #define DG_NEXT_STEP(out_)                                                                           \
     {                                                                                                \
         (out_) = -1;                                                                                 \
-        while (true)                                                                                 \
+        while (mapped)                                                                               \
+        {                                                                                            \
+            if (todo)                                                                                \
+            {                                                                                        \
+                const int s_ = __builtin_ctzll(todo);                                                \
+                todo &= todo - 1;                                                                    \
+                const unsigned v_ = s_abbb[(cur_t - win0) * 16 + s_];                                \
+                nxt_ab = v_ & 0xFFu;                                                                 \
+                nxt_bb = v_ >> 8;                                                                    \
+                nxt_pa = s_pa[cur_t - win0];                                                         \
+                nxt_pb = s_pb[cur_t - win0];                                                         \
+                (out_) = cur_t * steps_per_task + s_;                                                \
+                break;                                                                               \
+            }                                                                                        \
+            if (++cur_t >= (int)ntask)                                                               \
+                break;                                                                               \
+            if (cur_t >= win0 + DG_WINDOW)                                                           \
+            {                                                                                        \
+                win0 = cur_t;                                                                        \
+                DG_FILL_WINDOW()                                                                     \
+            }                                                                                        \
+            todo = s_live[cur_t - win0];                                                             \
+        }                                                                                            \
+        while (!mapped)                                                                              \
         {                                                                                            \
             if (todo)                                                                                \
             {                                                                                        \
                 const int s_ = __builtin_ctzll(todo);                                                \
                 todo &= todo - 1;                                                                    \
                 (out_) = cur_t * steps_per_task + done_steps + s_;                                   \
-                if (mapped)                                                                          \
-                {                                                                                    \
-                    nxt_ab = ((unsigned)t_ma[s_] >> (M0 / 16)) & 0xFFu;                              \
-                    nxt_bb = 0;                                                                      \
-                    for (int c_ = 0; c_ < DG_TILE / 16; c_++)                                        \
-                        nxt_bb |= (((unsigned)t_mb[N0 / 16 + c_] >> s_) & 1u) << c_;                 \
-                }                                                                                    \
+                nxt_pa = tasks[G.task_begin + cur_t].a.val;                                          \
+                nxt_pb = tasks[G.task_begin + cur_t].b.val;                                          \
                 break;                                                                               \
             }                                                                                        \
-            if (!mapped && cur_t >= 0 && done_steps + 64 < steps_per_task)                           \
+            if (cur_t >= 0 && done_steps + 64 < steps_per_task)                                      \
             {                                                                                        \
                 done_steps += 64;                                                                    \
                 const int left_ = steps_per_task - done_steps;                                       \
@@ -118,31 +173,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
             if (++cur_t >= (int)ntask)                                                               \
                 break;                                                                               \
             done_steps = 0;                                                                          \
-            if (mapped)                                                                              \
-            {                                                                                        \
-                const SsssmTaskD &Tm_ = tasks[G.task_begin + cur_t];                                 \
-                t_ma = mirror_map(Tm_.a.val, nb);                                                    \
-                t_mb = mirror_map(Tm_.b.val, nb);                                                    \
-                const unsigned rowbits_ = 0xFFu << (M0 / 16);                                        \
-                unsigned cols_ = 0, live_ = 0;                                                       \
-                for (int c_ = N0 / 16; c_ < (N0 + DG_TILE) / 16; c_++)                                \
-                    cols_ |= t_mb[c_];                                                               \
-                for (int k_ = 0; k_ < steps_per_task; k_++)                                          \
-                    if ((t_ma[k_] & rowbits_) && ((cols_ >> k_) & 1u))                               \
-                        live_ |= 1u << k_;                                                           \
-                todo = live_;                                                                        \
-            }                                                                                        \
-            else                                                                                     \
-                todo = steps_per_task >= 64 ? ~0ull : ((1ull << steps_per_task) - 1ull);             \
+            todo = steps_per_task >= 64 ? ~0ull : ((1ull << steps_per_task) - 1ull);                 \
         }                                                                                            \
     }
 
 #define DG_LOAD_SLAB(step_, ab_, bb_)                                                                \
     {                                                                                                \
-        const SsssmTaskD &T_ = tasks[G.task_begin + (step_) / steps_per_task];                       \
         const int k0_ = ((step_) % steps_per_task) * DG_K;                                           \
-        const double *A_ = T_.a.val + (size_t)(k0_ + a_k) * nb + M0 + a_m;                           \
-        const double *B_ = T_.b.val + (size_t)(N0 + b_n) * nb + k0_ + b_k;                           \
+        const double *A_ = nxt_pa + (size_t)(k0_ + a_k) * nb + M0 + a_m;                             \
+        const double *B_ = nxt_pb + (size_t)(N0 + b_n) * nb + k0_ + b_k;                             \
         if (((ab_) >> a_slab) & 1u)                                                                  \
         {                                                                                            \
             ra0 = *reinterpret_cast<const double2 *>(A_);                                            \
@@ -218,6 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         }
     }
 #undef DG_NEXT_STEP
+#undef DG_FILL_WINDOW
 #undef DG_LOAD_SLAB
     if (product_counter && lane == 0 && nprod)
         atomicAdd(product_counter, (unsigned long long)nprod); // 16 x 16 x 16 products issued to the matrix cores
