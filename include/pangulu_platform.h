@@ -239,7 +239,7 @@ extern "C"
     /*   PANGULU_HIP_OPT_TWO_STREAMS (default 1): run the MFMA update kernel of a batch on a side stream beside the LDS
      *     update kernel (fork/join with events inside the call; everything else stays on the one in-order stream). */
 #define PANGULU_HIP_OPT_TWO_STREAMS 10
-    /*   PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS (default 512): an update launch with at most this many tasks gives every
+    /*   PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS (default 2048): an update launch with at most this many tasks gives every
      *     update its own workgroups (chunk 1) - near the root of the elimination tree latency matters, not traffic. */
 #define PANGULU_HIP_OPT_SMALL_LAUNCH_TASKS 11
     /*   PANGULU_HIP_OPT_XCD_SWIZZLE (default 1): map workgroup ids so that the workgroups of one update queue / one
@@ -250,6 +250,12 @@ extern "C"
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an
      * allocation and three small copies inside the factorisation).  `diag` may be either half. */
     void pangulu_platform_0201001_prepare_diag(pangulu_inblock_idx nb, pangulu_storage_slot_t *diag);
+    /* Optional: a waitable handle for "everything queued on the back-end so far" (a hipEvent_t on the back-end's
+     * stream, owned by the back-end).  The native multi-rank scheduler uses it to announce finished blocks and to
+     * recycle receive slots without draining the device after every batch. */
+    void *pangulu_platform_0201001_marker_record(void);
+    int pangulu_platform_0201001_marker_done(void *marker);  /* 1 when everything before the marker has completed */
+    void pangulu_platform_0201001_marker_wait(void *marker);
     /* stream all numeric kernels are launched on (a hipStream_t); for event timing in bench.py */
     void *pangulu_platform_0201001_get_stream(void);
     /* Cumulative per-kernel-class counters since the last reset.  Classes: 1 GETRF, 2 TSTRF, 3 GESSM,

@@ -216,7 +216,24 @@ struct IpcComm : SocketComm
         sent_bytes += h.bytes_lo;
     }
 
+    // announcements can wait for a marker in the sender thread (the data itself never moves on this side)
+    bool set_send_gate(void *marker) override
+    {
+        if (!ipc_ok || !active_platform().marker_wait)
+            return false;
+        send_gate = marker;
+        return true;
+    }
+
     void recv_block(slot_t *s, const BlockHeader &h, int src) override
+    {
+        recv_block_begin(s, h, src);
+        recv_blocks_finish();
+    }
+
+    // the pull is only queued here: the receive thread announces a whole burst of blocks to the copy engine and waits
+    // once (a synchronous copy per block costs 20-30 us of API latency each, tens of thousands of times)
+    void recv_block_begin(slot_t *s, const BlockHeader &h, int src) override
     {
         if (h.reserved == 0)
         {
@@ -230,9 +247,9 @@ struct IpcComm : SocketComm
         const size_t bytes = h.bytes_lo;
         const char *from = peer_chunks[(size_t)src][off / cb] + off % cb;
         if (hipSetDevice(device) != hipSuccess ||
-            hipMemcpyAsync((char *)s->d_value - 32, from, bytes, hipMemcpyDeviceToDevice, copy_stream) != hipSuccess ||
-            hipStreamSynchronize(copy_stream) != hipSuccess)
+            hipMemcpyAsync((char *)s->d_value - 32, from, bytes, hipMemcpyDeviceToDevice, copy_stream) != hipSuccess)
             fatal("rank %d: peer copy of block (%u,%u) from rank %d failed: %s", rank, h.brow, h.bcol, src, hipGetErrorString(hipGetLastError()));
+        copies_in_flight = true;
         // the scheduler reads the pattern's nnz (colptr[nb]) and the header from the host mirror of the slot
         BlockHeader *rec = (BlockHeader *)((char *)s->value - 32);
         *rec = h;
@@ -240,6 +257,16 @@ struct IpcComm : SocketComm
         s->columnpointer[(((char *)s->rowindex - (char *)s->columnpointer) / sizeof(pangulu_inblock_ptr)) - 1] = (pangulu_inblock_ptr)h.nnz;
         recv_bytes_total += bytes;
     }
+
+    void recv_blocks_finish() override
+    {
+        if (!copies_in_flight)
+            return;
+        if (hipStreamSynchronize(copy_stream) != hipSuccess)
+            fatal("rank %d: peer copies failed: %s", rank, hipGetErrorString(hipGetLastError()));
+        copies_in_flight = false;
+    }
+    bool copies_in_flight = false;
 };
 
 } // namespace

@@ -83,7 +83,9 @@ struct SocketComm : Comm
         BlockHeader h;
         const char *payload;
         size_t payload_bytes;
+        void *gate = nullptr; // Platform marker that must have completed before this request leaves
     };
+    void *send_gate = nullptr;
     std::deque<SendReq> sendq;
     std::mutex qmutex;
     std::condition_variable qcv, qdrained;
@@ -171,6 +173,8 @@ struct SocketComm : Comm
                 r = sendq.front();
                 sendq.pop_front();
             }
+            if (r.gate)
+                active_platform().marker_wait(r.gate); // (requests of one queue share ascending markers: mostly a no-op)
             {
                 std::lock_guard<std::mutex> g(wmutex[(size_t)r.dst]);
                 write_all(fd[(size_t)r.dst], &r.f, sizeof(Frame));
@@ -197,6 +201,7 @@ struct SocketComm : Comm
         r.h = h;
         r.payload = nullptr;
         r.payload_bytes = 0;
+        r.gate = send_gate;
         {
             std::lock_guard<std::mutex> g(qmutex);
             sendq.push_back(r);

@@ -68,6 +68,9 @@ struct Platform
     // extension of the HIP back-end (nullptr elsewhere)
     int (*set_option)(int, long long) = nullptr;
     void (*prepare_diag)(pangulu_inblock_idx, slot_t *) = nullptr;
+    void *(*marker_record)() = nullptr;
+    int (*marker_done)(void *) = nullptr;
+    void (*marker_wait)(void *) = nullptr;
 };
 Platform &active_platform();               // built-in HIP unless the test hook replaced it
 bool platform_is_builtin_hip();
@@ -209,8 +212,16 @@ public:
     virtual bool probe_block(BlockHeader &h, int &src) = 0;
     // receive the announced record into the slot's buffers (host mirror and/or device)
     virtual void recv_block(slot_t *s, const BlockHeader &h, int src) = 0;
+    // pipelined variant for transports whose receives are asynchronous device copies: begin() may return before the
+    // data is there, finish() completes everything begun since the last finish (defaults: synchronous receive)
+    virtual void recv_block_begin(slot_t *s, const BlockHeader &h, int src) { recv_block(s, h, src); }
+    virtual void recv_blocks_finish() {}
     // make sure everything posted has left (called before the slot memory may be reused / at the end)
     virtual void flush_sends() = 0;
+    // Blocks posted from now on may only leave once `marker` (Platform::marker_record) has completed; nullptr = at once.
+    // Returns false when the transport cannot defer (host staging copies the values at post time): the caller then
+    // has to drain the device itself before posting.
+    virtual bool set_send_gate(void * /*marker*/) { return false; }
     // collective: the device arena holding every record this rank owns (nullptr: records live in host memory);
     // transports that copy straight between arenas map their peers' here (pg_comm_ipc.cpp)
     virtual void register_arena(char *const * /*chunks*/, size_t /*nchunks*/, size_t /*chunk_bytes*/, size_t /*total_bytes*/) {}

@@ -16,6 +16,7 @@
 //     one in-order stream, so program order is dependency order and the host simply runs ahead.
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <unistd.h>
 
 #include "pg_host.h"
@@ -133,6 +134,16 @@ struct Sched
     size_t gather_min_batch = 256;
     double gather_max_s = 2000e-6, gather_quiet_s = 300e-6, t_gather = 0;
     double t_last_progress = 0, stall_limit_s = 120; // PANGULU_AMD_STALL_S
+    // multi-rank without draining the device after every batch: receive slots are handed back, and finished blocks
+    // announced, once a marker recorded behind the kernels that use / produce them has completed
+    bool use_markers = false;
+    void *last_marker = nullptr; // marker behind the most recent platform call (recorded on demand)
+    struct Retired
+    {
+        slot_t *s;
+        void *marker;
+    };
+    std::deque<Retired> retired;
     double t_platform = 0;
     u64 batches = 0;
     bool multi;
@@ -149,6 +160,7 @@ struct Sched
             gather_quiet_s = 1e-6 * atof(e);
         if (const char *e = getenv("PANGULU_AMD_STALL_S"))
             stall_limit_s = atof(e);
+        use_markers = multi && !plat.host_memory && plat.marker_record && plat.marker_done && plat.marker_wait && !getenv("PANGULU_AMD_SYNC_EVERY_BATCH");
     }
 
     // ---- task creation -------------------------------------------------------------------------------
@@ -412,16 +424,10 @@ struct Sched
             return;
         if (--S.remain_diag[level] == 0)
         {
-            if (S.diag_upper[level])
-            {
-                S.storage.recycle(S.diag_upper[level]);
-                S.diag_upper[level] = nullptr;
-            }
-            if (S.diag_lower[level])
-            {
-                S.storage.recycle(S.diag_lower[level]);
-                S.diag_lower[level] = nullptr;
-            }
+            retire(S.diag_upper[level]);
+            S.diag_upper[level] = nullptr;
+            retire(S.diag_lower[level]);
+            S.diag_lower[level] = nullptr;
         }
     }
 
@@ -434,6 +440,34 @@ struct Sched
         plat.hybrid_batched((pangulu_inblock_idx)S.nb, tasks.size(), tasks.data());
         t_platform += wall_seconds() - t0;
         batches++;
+        last_marker = nullptr;
+    }
+
+    void *current_marker()
+    {
+        if (!last_marker)
+            last_marker = plat.marker_record();
+        return last_marker;
+    }
+
+    // a receive slot whose last consumer has been queued on the device: back to its bin once that work is done
+    void retire(slot_t *s)
+    {
+        if (!s)
+            return;
+        if (use_markers)
+            retired.push_back(Retired{s, current_marker()});
+        else
+            S.storage.recycle(s);
+    }
+
+    void poll_retired()
+    {
+        while (!retired.empty() && plat.marker_done(retired.front().marker))
+        {
+            S.storage.recycle(retired.front().s);
+            retired.pop_front();
+        }
     }
 
     // move the queued updates of the given tiles into ssssm_batch (grouped by tile, queue order kept)
@@ -461,7 +495,7 @@ struct Sched
         {
             // operands received from other ranks are dropped once their last consumer has run
             // (src/pangulu_numeric.c:226-251); the device must be done with them before the slot is reused
-            bool synced = false;
+            bool synced = use_markers;
             std::lock_guard<std::mutex> g(S.info_mutex);
             for (auto &t : ssssm_batch)
             {
@@ -478,7 +512,7 @@ struct Sched
                             plat.synchronize();
                             synced = true;
                         }
-                        S.storage.recycle(S.slot_of[b]);
+                        retire(S.slot_of[b]);
                         S.slot_of[b] = nullptr;
                     }
                 }
@@ -534,7 +568,10 @@ struct Sched
             run_platform_batch(batch);
         if (multi)
         {
-            plat.synchronize(); // finished blocks are about to be sent
+            // finished blocks are about to be announced: either the transport holds the announcements back until a
+            // marker behind this batch has completed, or the device is drained here
+            if (!(use_markers && comm->set_send_gate(current_marker())))
+                plat.synchronize();
         }
         // (3) successor release
         std::lock_guard<std::mutex> g(S.info_mutex);
@@ -599,6 +636,8 @@ struct Sched
                         S.rank, (long long)S.rank_remain_task, (long long)S.rank_remain_recv, (unsigned long long)S.pending_total,
                         (unsigned long long)batches);
             }
+            if (use_markers)
+                poll_retired();
             batch.clear();
             task_t t;
             while (S.heap.pop(t))
@@ -618,6 +657,8 @@ struct Sched
                         break;
                     while (S.heap.pop(t))
                         batch.push_back(t);
+                    if (use_markers)
+                        poll_retired();
                     if (batch.size() != seen)
                     {
                         seen = batch.size();
@@ -708,13 +749,35 @@ struct Sched
 
     void receive_loop()
     {
+        struct Begun
+        {
+            slot_t *s;
+            BlockHeader h;
+        };
+        std::vector<Begun> begun; // receives started but not completed (pipelined transports)
+        auto finish = [&]()
+        {
+            if (begun.empty())
+                return;
+            comm->recv_blocks_finish();
+            for (auto &p : begun)
+            {
+                S.rank_remain_recv--;
+                handle_arrival(p.s, p.h);
+            }
+            begun.clear();
+        };
         while (S.rank_remain_recv != 0)
         {
             BlockHeader h;
             int src = -1;
-            if (!comm->probe_block(h, src))
+            if ((i64)begun.size() == S.rank_remain_recv || !comm->probe_block(h, src))
             {
-                usleep(10);
+                // nothing more waiting right now: complete what was started, then idle
+                if (!begun.empty())
+                    finish();
+                else
+                    usleep(10);
                 continue;
             }
             size_t bytes = h.bytes_lo;
@@ -723,6 +786,7 @@ struct Sched
             while (!(s = S.storage.allocate(bytes)))
             {
                 // all slots of every fitting class are in use: wait for the compute thread to retire consumers
+                finish(); // (the blocks already on their way may be what those consumers wait for)
                 if (++spins == 1)
                     fprintf(stderr, "[pangulu_amd] rank %d: receive buffers exhausted, waiting (raise PANGULU_AMD_RECV_BUDGET_GB or mpi_recv_buffer_level)\n", S.rank);
                 usleep(200);
@@ -733,9 +797,10 @@ struct Sched
             s->brow_pos = h.brow;
             s->bcol_pos = h.bcol;
             s->is_upper = (i32)h.is_upper;
-            comm->recv_block(s, h, src);
-            S.rank_remain_recv--;
-            handle_arrival(s, h);
+            comm->recv_block_begin(s, h, src);
+            begun.push_back(Begun{s, h});
+            if (begun.size() >= 128)
+                finish();
         }
     }
 };
@@ -781,7 +846,9 @@ void numeric_factorize(Solver &S)
         sch.receive_loop();
         worker.join();
         plat.synchronize();
+        sch.poll_retired(); // (everything has completed: all of them go back)
         comm->flush_sends();
+        comm->set_send_gate(nullptr);
     }
     else
     {

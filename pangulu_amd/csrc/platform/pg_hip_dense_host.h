@@ -312,7 +312,11 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify)
         memcpy(h, jobs.data() + i, sizeof(MirrorJobD) * take);
         commit_segment(seg);
         // few jobs: cut every block into column runs so the launch still covers the chip
-        unsigned slices = take >= 2048 ? 1u : take >= 512 ? 4u : 16u;
+        // (enough workgroups to hide the per-workgroup chain of dependent loads: aim at ~16k)
+        static const long target_env = getenv("PANGULU_HIP_MIRROR_JOB_WGS") ? atol(getenv("PANGULU_HIP_MIRROR_JOB_WGS")) : 16384;
+        unsigned slices = 16;
+        while (slices > 1 && (size_t)slices * take > (size_t)target_env)
+            slices >>= 1;
         slices = std::min<unsigned>(slices, (unsigned)std::max(1, nb / 16)); // whole 16-column slabs per workgroup
         if (densify)
             hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, B.stream, d_jobs, nb);

@@ -1021,7 +1021,7 @@ struct Backend
     long long opt_getrf_strict = 0;
     long long opt_count_flops = 1;
     long long opt_group_chunk = 8;
-    long long opt_small_launch_tasks = 512;
+    long long opt_small_launch_tasks = 2048;
     long long opt_trsm_dense_permille = 10;
     long long opt_two_streams = 1;
     double mfma_flops_executed = 0;
@@ -2148,6 +2148,44 @@ extern "C"
         else
             hipLaunchKernelGGL(sptrsv_kernel, dim3(1), dim3(256), lds, B.stream, (int)nb, s->d_rowpointer, s->d_columnindex, s->d_value, xval, 1);
         HIP_CHECK(hipGetLastError());
+    }
+
+    // ---- markers: "everything queued on the back-end up to now" as a waitable handle -----------------------------
+    // (a ring of events, never freed: a handle that is re-recorded meanwhile simply completes later)
+    void *pangulu_platform_0201001_marker_record(void)
+    {
+        ensure_ready();
+        std::lock_guard<std::mutex> g(B.mutex);
+        HIP_CHECK(hipSetDevice(B.device));
+        static std::vector<hipEvent_t> ring;
+        static size_t next = 0;
+        if (ring.empty())
+        {
+            ring.resize(1024);
+            for (hipEvent_t &e : ring)
+                HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        hipEvent_t e = ring[next];
+        next = (next + 1) % ring.size();
+        HIP_CHECK(hipEventRecord(e, B.stream)); // (side streams have been joined into the main stream by every call)
+        return (void *)e;
+    }
+
+    int pangulu_platform_0201001_marker_done(void *marker)
+    {
+        hipError_t r = hipEventQuery((hipEvent_t)marker);
+        if (r == hipSuccess)
+            return 1;
+        if (r != hipErrorNotReady)
+            HIP_CHECK(r);
+        (void)hipGetLastError();
+        return 0;
+    }
+
+    void pangulu_platform_0201001_marker_wait(void *marker)
+    {
+        HIP_CHECK(hipSetDevice(B.device));
+        HIP_CHECK(hipEventSynchronize((hipEvent_t)marker));
     }
 
     void pangulu_platform_0201001_prepare_diag(pangulu_inblock_idx nb, pangulu_storage_slot_t *diag)

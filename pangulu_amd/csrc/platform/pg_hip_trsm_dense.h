@@ -221,13 +221,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
 #pragma unroll
     for (int p = 0; p < NP; p++)
     {
-        if (p < wg_first)
-            continue; // (workgroup-uniform)
+        if (!((wg_lv >> p) & 1u))
+            continue; // (workgroup-uniform) no strip of this workgroup has a tile in panel p: X_p = 0 for all of them
         __syncthreads(); // everyone is done with the previous panel's image
         TRSM_STAGE(p)
         __syncthreads();
-        if (p + 1 < NP)
-            TRSM_PREFETCH(p + 1)
+        {
+            // the next panel any strip needs goes in flight now
+            const unsigned later = (p + 1 < NP) ? (wg_lv >> (p + 1)) : 0u;
+            if (later)
+            {
+                const int np = p + 1 + __builtin_ctz(later);
+                TRSM_PREFETCH(np)
+            }
+        }
         if (!((my_lv >> p) & 1u))
             continue; // (wavefront-uniform; no barrier below)
         // four independent accumulation chains (one per k-quarter of a tile): a single chain of up to 60 dependent
