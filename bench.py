@@ -36,8 +36,8 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (v_mfma_f64_16x16x4
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="shell", choices=["shell", "fem27", "poisson", "kkt"])
     ap.add_argument("--size", type=int, nargs="*", default=None, help="generator size arguments (shell: nx ny)")
     ap.add_argument("--mtx", default=None, help="MatrixMarket file to factorise instead of the synthetic stand-in")
