@@ -133,7 +133,7 @@ struct Sched
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
     double gather_max_s = 2000e-6, gather_quiet_s = 300e-6, t_gather = 0;
-    double t_last_progress = 0, stall_limit_s = 120; // PANGULU_AMD_STALL_S
+    double t_last_progress = 0, t_last_arrival = 0, stall_limit_s = 120; // PANGULU_AMD_STALL_S
     // multi-rank without draining the device after every batch: receive slots are handed back, and finished blocks
     // announced, once a marker recorded behind the kernels that use / produce them has completed
     bool use_markers = false;
@@ -777,9 +777,18 @@ struct Sched
                 if (!begun.empty())
                     finish();
                 else
+                {
+                    const double now = wall_seconds();
+                    if (t_last_arrival == 0)
+                        t_last_arrival = now;
+                    if (now - t_last_arrival > stall_limit_s)
+                        fatal("rank %d: no block arrived for %.0f s with %lld receives outstanding: a peer stopped sending (see its output)",
+                              S.rank, now - t_last_arrival, (long long)S.rank_remain_recv);
                     usleep(10);
+                }
                 continue;
             }
+            t_last_arrival = 0;
             size_t bytes = h.bytes_lo;
             slot_t *s = nullptr;
             int spins = 0;
