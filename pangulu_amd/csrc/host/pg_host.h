@@ -287,10 +287,26 @@ struct Solver
     // statistics
     pangulu_amd_info_t info;
     TaskModel model;
-    int owner(u32 br, u32 bc) const { return (int)((br % (u32)p) * (u32)q + (bc % (u32)q)); }
+    // Ownership.  The reference is purely 2D block-cyclic (src/pangulu.c:83-90, owner = (br mod p) q + (bc mod q)).  Here
+    // the panels (diagonal block, L column, U row) of every block column inside a SUBTREE of the block elimination
+    // tree that was given to one rank belong to that rank (home[min(br,bc)] >= 0): disjoint subtrees are independent
+    // computations, so the bottom of the tree -- where most levels are -- runs without any exchange and in lock-step
+    // batches per rank; only the top of the tree (home < 0) is 2D block-cyclic.  Filled by assign_subtrees().
+    std::vector<int> home;
+    int owner(u32 br, u32 bc) const
+    {
+        if (!home.empty())
+        {
+            const int h = home[br < bc ? br : bc];
+            if (h >= 0)
+                return h;
+        }
+        return (int)((br % (u32)p) * (u32)q + (bc % (u32)q));
+    }
     ~Solver();
 };
 
+void assign_subtrees(Solver &S);                          // subtree-to-rank mapping (multi-rank runs)
 void preprocess(Solver &S, const CscMatrix &Aperm);       // records, counters, bins, upload
 void numeric_factorize(Solver &S);                        // the hot path
 void download_factors(Solver &S);                         // device -> host mirror of owned values

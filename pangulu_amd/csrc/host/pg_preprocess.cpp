@@ -7,6 +7,7 @@
 // Unlike the reference (rank 0 builds everything and ships it), every rank derives its own records from the
 // replicated symbolic pattern, in parallel, and uploads them with one copy.
 #include <algorithm>
+#include <queue>
 #include <omp.h>
 
 #include "pg_host.h"
@@ -144,8 +145,86 @@ void transpose_inblock(u32 nb, const pangulu_inblock_ptr *cp, const pangulu_inbl
 
 } // namespace
 
+// Proportional mapping of the block elimination tree: split the tree from the top until no remaining subtree carries
+// more than 1/(subtrees_per_rank * nproc) of the work, give every remaining subtree to one rank (largest first, to the
+// least loaded rank); the nodes split off on the way stay with the 2D block-cyclic rule.  Deterministic: every rank
+// computes the same map from the same block pattern.
+void assign_subtrees(Solver &S)
+{
+    S.home.clear();
+    const char *env = getenv("PANGULU_AMD_SUBTREE_MAP");
+    if (S.nproc <= 1 || (env && atoi(env) == 0))
+        return;
+    const BlockPattern &P = S.pat;
+    const u32 nbk = S.nbk, NONE = 0xFFFFFFFFu;
+    std::vector<u32> parent(nbk, NONE);
+    std::vector<double> sub(nbk, 0.0);
+    std::vector<std::vector<u32>> kids(nbk);
+    double total = 0;
+    for (u32 k = 0; k < nbk; k++)
+    {
+        const double nl = (double)(P.colptr[k + 1] - P.first_after_diag[k]);
+        const double nu = (double)(P.rowptr[k + 1] - P.first_after_diag_csr[k]);
+        sub[k] += 1.0 + nl + nu + nl * nu; // panel tasks + updates released by level k
+        if (P.first_after_diag[k] < P.colptr[k + 1])
+            parent[k] = P.rowidx[P.first_after_diag[k]];
+        if (parent[k] != NONE)
+        {
+            sub[parent[k]] += sub[k]; // (parent > k: its own term is added when the loop gets there)
+            kids[parent[k]].push_back(k);
+        }
+        else
+            total += sub[k];
+    }
+    const char *per_env = getenv("PANGULU_AMD_SUBTREES_PER_RANK");
+    const double per_rank = per_env ? atof(per_env) : 8.0;
+    const double target = total / (per_rank * (double)S.nproc);
+    auto cmp = [&](u32 a, u32 b)
+    { return sub[a] < sub[b] || (sub[a] == sub[b] && a > b); };
+    std::priority_queue<u32, std::vector<u32>, decltype(cmp)> pq(cmp);
+    for (u32 k = 0; k < nbk; k++)
+        if (parent[k] == NONE)
+            pq.push(k);
+    S.home.assign(nbk, -1);
+    while (!pq.empty() && sub[pq.top()] > target)
+    {
+        u32 k = pq.top();
+        pq.pop(); // stays block-cyclic
+        for (u32 c : kids[k])
+            pq.push(c);
+    }
+    std::vector<double> load((size_t)S.nproc, 0.0);
+    std::vector<u32> stack;
+    size_t nsub = 0;
+    while (!pq.empty())
+    {
+        u32 root = pq.top();
+        pq.pop();
+        int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[(size_t)r] += sub[root];
+        nsub++;
+        stack.assign(1, root);
+        while (!stack.empty())
+        {
+            u32 k = stack.back();
+            stack.pop_back();
+            S.home[k] = r;
+            for (u32 c : kids[k])
+                stack.push_back(c);
+        }
+    }
+    if (S.rank == 0 && getenv("PANGULU_AMD_TRACE"))
+    {
+        size_t top = 0;
+        for (int h : S.home)
+            top += h < 0;
+        fprintf(stderr, "[pangulu_amd trace] subtree mapping: %zu subtrees over %d ranks, %zu of %u block columns stay block-cyclic\n", nsub, S.nproc, top, nbk);
+    }
+}
+
 void preprocess(Solver &S, const CscMatrix &A)
 {
+    assign_subtrees(S);
     const BlockPattern &P = S.pat;
     const Symbolic &sym = S.sym;
     Platform &plat = active_platform();

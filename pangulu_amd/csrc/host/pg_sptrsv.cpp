@@ -1,7 +1,7 @@
 // pg_sptrsv.cpp -- block forward/backward substitution for pangulu_gstrs ("next" row f1 of SURVEY.md §8).
 //
-// Same sweep as the reference (src/pangulu_sptrsv.c:24-191): block row by block row, every rank of the
-// diagonal owner's process row adds the products of its own blocks, the diagonal owner sums the partial
+// Same sweep as the reference (src/pangulu_sptrsv.c:24-191): block row by block row, every rank that owns
+// blocks of the row (the diagonal owner's process row, or any rank under the subtree mapping) adds their products, the diagonal owner sums the partial
 // vectors, solves with its diagonal half and broadcasts the finished segment.  Like the reference (which pins
 // the solve to PANGULU_PLATFORM_CPU_NAIVE, src/pangulu_sptrsv.c:62,94,126,159) it runs on the host copies of
 // the factors; the in-block kernels follow ...0100000.c:435-506.
@@ -79,7 +79,8 @@ void triangular_solve(Solver &S, val_t *rhs)
     Comm *comm = world();
     const BlockPattern &P = S.pat;
     u32 nb = S.nb, nbk = S.nbk;
-    int q = S.q, me = S.rank;
+    int me = S.rank;
+    std::vector<char> contributes((size_t)S.nproc, 0);
     std::vector<val_t> x((size_t)nbk * nb, vmake(0)), acc(nb), tmp(nb);
     std::copy(rhs, rhs + S.n, x.begin());
     const int TAG_PART = 0x100000;
@@ -92,13 +93,17 @@ void triangular_solve(Solver &S, val_t *rhs)
             u32 brow = lower ? step : nbk - 1 - step;
             val_t *seg = x.data() + (size_t)brow * nb;
             int diag_rank = S.owner(brow, brow);
-            bool in_row = (me / q) == (diag_rank / q);
-            if (in_row)
+            // the ranks that hold blocks of block row brow on the relevant side of the diagonal (with the subtree
+            // mapping these are not confined to the diagonal owner's process row): each adds the products of its
+            // own blocks, the diagonal owner sums the partial vectors
+            u64 rb = lower ? P.rowptr[brow] : P.first_after_diag_csr[brow];
+            u64 re = lower ? P.first_after_diag_csr[brow] : P.rowptr[brow + 1];
+            std::fill(contributes.begin(), contributes.end(), 0);
+            for (u64 r = rb; r < re; r++)
+                contributes[(size_t)S.owner(brow, P.colidx[r])] = 1;
+            if (contributes[(size_t)me] || me == diag_rank)
             {
                 std::fill(acc.begin(), acc.end(), vmake(0));
-                // my blocks of block row brow on the relevant side of the diagonal
-                u64 rb = lower ? P.rowptr[brow] : P.first_after_diag_csr[brow];
-                u64 re = lower ? P.first_after_diag_csr[brow] : P.rowptr[brow + 1];
                 for (u64 r = rb; r < re; r++)
                 {
                     u32 bcol = P.colidx[r];
@@ -109,9 +114,9 @@ void triangular_solve(Solver &S, val_t *rhs)
                 }
                 if (me == diag_rank)
                 {
-                    for (int r = (me / q) * q; r < (me / q + 1) * q; r++)
+                    for (int r = 0; r < S.nproc; r++)
                     {
-                        if (r == me)
+                        if (r == me || !contributes[(size_t)r])
                             continue;
                         comm->recv_bytes(r, TAG_PART + (int)(brow & 0xfffff), tmp.data(), sizeof(val_t) * nb);
                         for (u32 i = 0; i < nb; i++)

@@ -52,7 +52,9 @@ GENS = {"fem27_6": lambda: M.fem27(6), "poisson8": lambda: M.poisson3d(8), "shel
 
 
 @pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (2, "trefethen", 4), (4, "poisson8", 32), (4, "trefethen", 4),
-                                           (3, "shell_8x7", 24), (2, "random200", 16)])
+                                           (3, "shell_8x7", 24), (2, "random200", 16),
+                                           # subtree-to-rank mapping takes blocks out of the 2D block-cyclic process rows
+                                           (4, "shell_20x16", 24), (4, "fem27_9", 16)])
 def test_multirank_matches_single_rank(tmp_path, world, spec, nb):
     out = str(tmp_path / "out.npz")
     run_ranks(world, spec, nb, out)
