@@ -16,7 +16,9 @@
 //     one in-order stream, so program order is dependency order and the host simply runs ahead.
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <thread>
 #include <unistd.h>
 
 #include "pg_host.h"
@@ -129,7 +131,7 @@ struct Sched
     Comm *comm;
     std::vector<char> sent_flag;
     std::vector<task_t> batch, ssssm_batch, combined;
-    size_t lookahead_max_getrf = 8; // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
+    size_t lookahead_max_getrf = 128; // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
     double gather_max_s = 2000e-6, gather_quiet_s = 300e-6, t_gather = 0;
@@ -144,9 +146,21 @@ struct Sched
         void *marker;
     };
     std::deque<Retired> retired;
-    double t_platform = 0;
+    double t_platform = 0, t_sched = 0;
     u64 batches = 0;
     bool multi;
+    // Single-rank runs on a device: the platform calls (descriptor building and launches) cost about as much host time
+    // as the scheduling itself, and nothing the scheduler does next depends on their return -- the back-end's streams
+    // keep program order.  A launcher thread makes the calls in batch order while this thread releases successors and
+    // drains the next batch.  Opt-in (PANGULU_AMD_ASYNC_LAUNCH=1): on the bench host the one-thread loop already stays
+    // ahead of the device (it spends 27 of its 66 ms waiting for descriptor segments), so the thread buys nothing there.
+    bool async_launch = false;
+    std::thread launcher;
+    std::mutex lq_mutex;
+    std::condition_variable lq_cv, lq_idle_cv;
+    std::deque<std::vector<task_t>> lq;
+    std::vector<std::vector<task_t>> lq_free;
+    bool lq_stop = false, lq_busy = false;
 
     explicit Sched(Solver &s) : S(s), P(s.pat), plat(active_platform()), comm(world()), sent_flag((size_t)s.nproc, 0), multi(s.nproc > 1)
     {
@@ -161,6 +175,60 @@ struct Sched
         if (const char *e = getenv("PANGULU_AMD_STALL_S"))
             stall_limit_s = atof(e);
         use_markers = multi && !plat.host_memory && plat.marker_record && plat.marker_done && plat.marker_wait && !getenv("PANGULU_AMD_SYNC_EVERY_BATCH");
+        const char *al = getenv("PANGULU_AMD_ASYNC_LAUNCH");
+        async_launch = !multi && !plat.host_memory && al && atoi(al) != 0;
+        if (async_launch)
+            launcher = std::thread([this]()
+                                   { launcher_loop(); });
+    }
+
+    ~Sched()
+    {
+        if (launcher.joinable())
+        {
+            {
+                std::lock_guard<std::mutex> g(lq_mutex);
+                lq_stop = true;
+            }
+            lq_cv.notify_all();
+            launcher.join();
+        }
+    }
+
+    void launcher_loop()
+    {
+        std::unique_lock<std::mutex> lk(lq_mutex);
+        while (true)
+        {
+            lq_cv.wait(lk, [this]()
+                       { return lq_stop || !lq.empty(); });
+            if (lq.empty())
+                return; // (stop requested and nothing left)
+            std::vector<task_t> tasks = std::move(lq.front());
+            lq.pop_front();
+            lq_busy = true;
+            lk.unlock();
+            double t0 = wall_seconds();
+            plat.hybrid_batched((pangulu_inblock_idx)S.nb, tasks.size(), tasks.data());
+            double dt = wall_seconds() - t0;
+            lk.lock();
+            t_platform += dt;
+            lq_busy = false;
+            tasks.clear();
+            lq_free.push_back(std::move(tasks));
+            if (lq.empty())
+                lq_idle_cv.notify_all();
+        }
+    }
+
+    // every platform call handed to the launcher has returned (their kernels are queued on the device)
+    void drain_launcher()
+    {
+        if (!async_launch)
+            return;
+        std::unique_lock<std::mutex> lk(lq_mutex);
+        lq_idle_cv.wait(lk, [this]()
+                        { return lq.empty() && !lq_busy; });
     }
 
     // ---- task creation -------------------------------------------------------------------------------
@@ -436,10 +504,29 @@ struct Sched
     {
         if (tasks.empty())
             return;
+        batches++;
+        if (async_launch)
+        {
+            std::vector<task_t> copy;
+            {
+                std::lock_guard<std::mutex> g(lq_mutex);
+                if (!lq_free.empty())
+                {
+                    copy = std::move(lq_free.back());
+                    lq_free.pop_back();
+                }
+            }
+            copy.assign(tasks.begin(), tasks.end());
+            {
+                std::lock_guard<std::mutex> g(lq_mutex);
+                lq.push_back(std::move(copy));
+            }
+            lq_cv.notify_one();
+            return;
+        }
         double t0 = wall_seconds();
         plat.hybrid_batched((pangulu_inblock_idx)S.nb, tasks.size(), tasks.data());
         t_platform += wall_seconds() - t0;
-        batches++;
         last_marker = nullptr;
     }
 
@@ -627,6 +714,7 @@ struct Sched
         }
         static const bool trace = getenv("PANGULU_AMD_TRACE") != nullptr;
         double t_trace = wall_seconds();
+        const double t_loop_begin = t_trace;
         while (S.rank_remain_task != 0)
         {
             if (trace && wall_seconds() - t_trace > 2.0)
@@ -699,6 +787,8 @@ struct Sched
         // updates into tiles are always flushed by the tile's own panel task, so nothing can be left
         if (S.pending_total != 0)
             fatal("scheduler finished with %llu queued updates", (unsigned long long)S.pending_total);
+        t_sched = wall_seconds() - t_loop_begin;
+        drain_launcher();
     }
 
     // ---- arrivals (receive thread) -------------------------------------------------------------------------
@@ -868,7 +958,8 @@ void numeric_factorize(Solver &S)
         fprintf(stderr, "[pangulu_amd trace] rank %d: compute and receive loops done, entering the final barrier\n", S.rank);
     comm->barrier();
     S.info.time_numeric = wall_seconds() - t0;
-    S.info.time_numeric_host_sched = S.info.time_numeric - sch.t_platform;
+    // host time the scheduler itself needed: with the launcher thread, the time until the last batch was handed over
+    S.info.time_numeric_host_sched = sch.async_launch ? sch.t_sched : S.info.time_numeric - sch.t_platform;
     S.info.batches = sch.batches;
     S.info.sent_bytes = comm->sent_bytes;
     S.info.recv_bytes = comm->recv_bytes_total;
