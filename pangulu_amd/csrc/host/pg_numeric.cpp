@@ -132,6 +132,7 @@ struct Sched
     std::vector<char> sent_flag;
     std::vector<task_t> batch, ssssm_batch, combined;
     size_t lookahead_max_getrf = 128; // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
+    bool panel_lookahead_on = true;   // PANGULU_AMD_PANEL_LOOKAHEAD (0 disables)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
     double gather_max_s = 2000e-6, gather_quiet_s = 300e-6, t_gather = 0;
@@ -166,6 +167,8 @@ struct Sched
     {
         if (const char *e = getenv("PANGULU_AMD_LOOKAHEAD_MAX_GETRF"))
             lookahead_max_getrf = (size_t)atol(e);
+        if (const char *e = getenv("PANGULU_AMD_PANEL_LOOKAHEAD"))
+            panel_lookahead_on = atoi(e) != 0;
         if (const char *e = getenv("PANGULU_AMD_GATHER_MIN_BATCH"))
             gather_min_batch = (size_t)atol(e);
         if (const char *e = getenv("PANGULU_AMD_GATHER_MAX_US"))
@@ -631,20 +634,42 @@ struct Sched
         // (2) the panel tasks themselves.  A few diagonal factorisations on their own leave the device almost idle
         // (one workgroup each): every update queued anywhere else goes into the same call, the back-end runs the
         // two kinds side by side
-        bool lookahead = false;
-        if (batch.size() <= lookahead_max_getrf && S.pending_total != 0)
-        {
-            lookahead = true;
-            for (auto &t : batch)
-                lookahead = lookahead && t.kernel_id == PANGULU_TASK_GETRF;
-        }
-        if (lookahead)
+        bool all_getrf = S.pending_total != 0;
+        for (auto &t : batch)
+            all_getrf = all_getrf && t.kernel_id == PANGULU_TASK_GETRF;
+        const bool lookahead = all_getrf && batch.size() <= lookahead_max_getrf;
+        // A larger batch of diagonal factorisations: the updates queued on the PANEL tiles of these levels (the blocks
+        // below and right of each diagonal block) do not depend on the factorisations either -- every one of them was
+        // queued before the diagonal block became ready (same descendants, src/pangulu_numeric.c:436-601) -- and the
+        // panel solves are what follows.  They run beside the GETRFs instead of between them and the solves; unlike the
+        // flush above this creates no extra pass over any tile.
+        const bool panel_lookahead = all_getrf && !lookahead && panel_lookahead_on;
+        if (lookahead || panel_lookahead)
         {
             {
                 std::lock_guard<std::mutex> g(S.info_mutex);
-                for (u32 tile : S.pending_dirty)
-                    take_pending(tile);
-                S.pending_dirty.clear();
+                if (lookahead)
+                {
+                    for (u32 tile : S.pending_dirty)
+                        take_pending(tile);
+                    S.pending_dirty.clear();
+                }
+                else
+                {
+                    for (auto &t : batch)
+                    {
+                        const u32 k = t.task_level;
+                        for (u64 b = P.first_after_diag[k]; b < P.colptr[k + 1]; b++)
+                            if (S.slot_of[b] && S.owner(P.rowidx[b], k) == S.rank)
+                                take_pending(tile_index(S.slot_of[b]));
+                        for (u64 r = P.first_after_diag_csr[k]; r < P.rowptr[k + 1]; r++)
+                        {
+                            const u64 b = P.csr_to_csc[r];
+                            if (S.slot_of[b] && S.owner(k, P.colidx[r]) == S.rank)
+                                take_pending(tile_index(S.slot_of[b]));
+                        }
+                    }
+                }
             }
             combined.assign(batch.begin(), batch.end());
             combined.insert(combined.end(), ssssm_batch.begin(), ssssm_batch.end());

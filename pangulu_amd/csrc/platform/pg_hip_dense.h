@@ -298,6 +298,8 @@ struct MirrorJobD
     const u32 *uvi;
     double *uval;
     double *dense;  // nb x nb column-major
+    const double *diag_tiles; // sparsify of a fresh LU image: its nb/16 diagonal tiles as GETRF left them (16 x 16 column-major
+                              // each; the image's own have been inverted in place since), or nullptr
 };
 
 // Entries ptr[c0] .. ptr[c1] of a CSC block are one contiguous run: the workgroup walks it flat (coalesced, no
@@ -421,9 +423,19 @@ __global__ __launch_bounds__(256) void sparsify_kernel(const MirrorJobD *__restr
         __syncthreads();
         const u32 e0 = sp[0], e1 = sp[ncols], f0 = su[0], f1 = su[ncols];
         for (u32 p = e0 + threadIdx.x; p < e1; p += blockDim.x)
-            J.lo.val[p] = J.dense[(size_t)(c0 + mirror_column_of(sp, ncols, p)) * nb + J.lo.idx[p]];
+        {
+            const int c = c0 + mirror_column_of(sp, ncols, p);
+            const u32 r = J.lo.idx[p];
+            J.lo.val[p] = (J.diag_tiles && (r >> 4) == (u32)(c >> 4)) ? J.diag_tiles[((c >> 4) << 8) + ((c & 15) << 4) + (r & 15)]
+                                                                   : J.dense[(size_t)c * nb + r];
+        }
         for (u32 p = f0 + threadIdx.x; p < f1; p += blockDim.x)
-            J.uval[J.uvi[p]] = J.dense[(size_t)(c0 + mirror_column_of(su, ncols, p)) * nb + J.uri[p]];
+        {
+            const int c = c0 + mirror_column_of(su, ncols, p);
+            const u32 r = J.uri[p];
+            J.uval[J.uvi[p]] = (J.diag_tiles && (r >> 4) == (u32)(c >> 4)) ? J.diag_tiles[((c >> 4) << 8) + ((c & 15) << 4) + (r & 15)]
+                                                                        : J.dense[(size_t)c * nb + r];
+        }
     }
 }
 

@@ -143,7 +143,8 @@ double *obtain_mirror(BlockState &st, int nb)
 {
     if (st.mirror)
         return st.mirror;
-    size_t mb = sizeof(double) * (size_t)nb * nb + MIRROR_MAP_BYTES; // values + occupancy map (pg_hip_dense.h)
+    // values + occupancy map (pg_hip_dense.h) + the nb/16 diagonal tiles a blocked GETRF saves before they are inverted
+    size_t mb = sizeof(double) * (size_t)nb * nb + MIRROR_MAP_BYTES + sizeof(double) * 16 * (size_t)nb;
     if (MP.mirror_bytes != mb)
     {
         // block order changed (or first use): start over
@@ -299,9 +300,23 @@ void require_sparse(slot_t *s, int nb)
     }
 }
 
-void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify)
+// `on_records_stream` (sparsify jobs of blocks that are FINISHED, whose mirrors nothing will write again): the launch
+// goes to the records stream, ordered behind everything queued on `after` so far, and the main stream does not wait for it
+// (`fork_recorded`: the caller has already recorded B.ev_rec_fork at the point the jobs depend on)
+void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify, bool on_records_stream = false, hipStream_t after = nullptr,
+                       bool fork_recorded = false)
 {
     HostTimer ht(3);
+    hipStream_t st = B.stream;
+    if (on_records_stream && !densify && B.opt_records_stream && !jobs.empty())
+    {
+        st = B.stream_rec;
+        if (!fork_recorded)
+            HIP_CHECK(hipEventRecord(B.ev_rec_fork, after ? after : B.stream));
+        HIP_CHECK(hipStreamWaitEvent(st, B.ev_rec_fork, 0));
+    }
+    // (main-stream jobs need no join with the records stream: its jobs in flight write the records of FINISHED blocks
+    // whose mirrors stay current; densify reads, and sparsify on the main stream rewrites, records of unfinished ones)
     size_t i = 0;
     while (i < jobs.size())
     {
@@ -319,12 +334,17 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify)
             slices >>= 1;
         slices = std::min<unsigned>(slices, (unsigned)std::max(1, nb / 16)); // whole 16-column slabs per workgroup
         if (densify)
-            hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, B.stream, d_jobs, nb);
+            hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
         else
-            hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take, slices), dim3(256), 0, B.stream, d_jobs, nb);
+            hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
         HIP_CHECK(hipGetLastError());
-        release_pending_segments(); // (callers commit their own segment only after this returns)
+        release_pending_segments(st); // (callers commit their own segment only after this returns)
         i += take;
+    }
+    if (st == B.stream_rec)
+    {
+        HIP_CHECK(hipEventRecord(B.ev_rec, st));
+        B.rec_dirty.store(true, std::memory_order_release);
     }
     jobs.clear();
 }

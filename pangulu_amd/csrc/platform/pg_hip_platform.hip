@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <unordered_set>
@@ -180,7 +181,9 @@ struct GetrfTaskD
     val_t *uval;
     val_t *dense; // nb*nb scratch, only touched on the pattern
     u32 preloaded; // blocked kernel: `dense` already holds the block (a dense-mode mirror): skip zero + scatter
-    u32 pad_;
+    u32 defer_gather; // blocked kernel on a mirror: leave the factors in the dense image, save the 16 x 16 diagonal tiles
+                      // behind the mirror (they are about to be inverted in place) -- a sparsify job on the records
+                      // stream brings the sparse record up to date off the critical path
 };
 
 __device__ inline u32 ptr0(const u32 *p, int i) { return i == 0 ? 0u : p[i]; }
@@ -636,7 +639,6 @@ __global__ __launch_bounds__(GETRF_THREADS) void getrf_kernel(const GetrfTaskD *
 // -----------------------------------------------------------------------------------------------------------------
 #if defined(CALCULATE_TYPE_R64)
 #define GETRF_PANEL 16
-#define GETRF_BLOCKED_THREADS 1024
 #define GETRF_BLOCKED_ROWS 256 // one row thread per row: nb <= 256
 
 // index i with ptr[i] <= p < ptr[i+1] (ptr ascending, ptr[0] = 0, p < ptr[n])
@@ -662,7 +664,11 @@ __device__ inline int owner_of(const u32 *ptr, int n, u32 p)
         stamp_ = now_;                                                     \
     }
 
-__global__ __launch_bounds__(GETRF_BLOCKED_THREADS) void getrf_blocked_f64_kernel(const GetrfTaskD *__restrict__ tasks, int nb,
+// THREADS = 1024: sixteen wavefronts, the whole register file of the CU (fastest for a block on its own).
+// THREADS = 512: eight wavefronts capped at 128 registers -- half of the CU stays free, so the update and densify
+// workgroups of a look-ahead batch run on the same CUs beside a launch that has a diagonal block for every CU.
+template <int GETRF_BLOCKED_THREADS>
+__global__ __launch_bounds__(GETRF_BLOCKED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void getrf_blocked_f64_kernel(const GetrfTaskD *__restrict__ tasks, int nb,
                                                                                   unsigned long long *flop_counter,
                                                                                   unsigned long long *dbg)
 {
@@ -867,10 +873,72 @@ __global__ __launch_bounds__(GETRF_BLOCKED_THREADS) void getrf_blocked_f64_kerne
         GETRF_STAMP(5)
     }
 
-    for (u32 p = tid; p < nnzL; p += GETRF_BLOCKED_THREADS)
-        T.lval[p] = D[(size_t)owner_of(sLcp, nb, p) * nb + T.lri[p]];
-    for (u32 p = tid; p < nnzU; p += GETRF_BLOCKED_THREADS)
-        T.uval[p] = D[(size_t)T.uci[p] * nb + owner_of(sUrp, nb, p)];
+    if (T.defer_gather)
+    {
+        // the factors stay in the dense image; the diagonal tiles are saved behind the mirror (values + occupancy map)
+        // because diag_tile_inverse_kernel replaces them by their inverses before the sparsify job reads the image
+        double *__restrict__ saved = D + (size_t)nb * nb + MIRROR_MAP_BYTES / sizeof(double);
+        for (int i = tid; i < nb * 16; i += GETRF_BLOCKED_THREADS)
+        {
+            const int pt = i >> 8, cc = (i >> 4) & 15, rr = i & 15;
+            saved[i] = D[(size_t)(16 * pt + cc) * nb + 16 * pt + rr];
+        }
+    }
+    else
+    {
+        // gather the factors back into the sparse record: four entries per thread and pass, so that the index loads, the
+        // searches and the reads of D of different entries overlap (one entry at a time is a chain of three dependent L2
+        // round trips per entry: 56 of the kernel's 330 us)
+        constexpr int GU = 4;
+        for (u32 p0 = tid; p0 < nnzL; p0 += GU * GETRF_BLOCKED_THREADS)
+        {
+            u32 r[GU];
+            double v[GU];
+    #pragma unroll
+            for (int u = 0; u < GU; u++)
+            {
+                const u32 p = p0 + u * GETRF_BLOCKED_THREADS;
+                r[u] = p < nnzL ? T.lri[p] : 0u;
+            }
+    #pragma unroll
+            for (int u = 0; u < GU; u++)
+            {
+                const u32 p = p0 + u * GETRF_BLOCKED_THREADS;
+                v[u] = p < nnzL ? D[(size_t)owner_of(sLcp, nb, p) * nb + r[u]] : 0.0;
+            }
+    #pragma unroll
+            for (int u = 0; u < GU; u++)
+            {
+                const u32 p = p0 + u * GETRF_BLOCKED_THREADS;
+                if (p < nnzL)
+                    T.lval[p] = v[u];
+            }
+        }
+        for (u32 p0 = tid; p0 < nnzU; p0 += GU * GETRF_BLOCKED_THREADS)
+        {
+            u32 c[GU];
+            double v[GU];
+    #pragma unroll
+            for (int u = 0; u < GU; u++)
+            {
+                const u32 p = p0 + u * GETRF_BLOCKED_THREADS;
+                c[u] = p < nnzU ? T.uci[p] : 0u;
+            }
+    #pragma unroll
+            for (int u = 0; u < GU; u++)
+            {
+                const u32 p = p0 + u * GETRF_BLOCKED_THREADS;
+                v[u] = p < nnzU ? D[(size_t)c[u] * nb + owner_of(sUrp, nb, p)] : 0.0;
+            }
+    #pragma unroll
+            for (int u = 0; u < GU; u++)
+            {
+                const u32 p = p0 + u * GETRF_BLOCKED_THREADS;
+                if (p < nnzU)
+                    T.uval[p] = v[u];
+            }
+        }
+    }
     __syncthreads();
     GETRF_STAMP(6)
     ops = wave_sum(ops);
@@ -1012,6 +1080,14 @@ struct Backend
     hipStream_t stream3 = nullptr; // second side stream: GETRFs of a batch run beside its TSTRF/GESSM solves
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
     bool getrf_join_pending = false;
+    // Records stream: the sparse record stays the authoritative form of every finished block, but the dense kernels
+    // of the following steps read mirrors and LU images only.  The sparsify jobs behind the dense solves and behind
+    // the blocked GETRF run here, beside whatever comes next; everything that reads or rewrites sparse records (the
+    // LDS update kernel, sparse solves, densify, copies to the host, markers, synchronize) joins it first.
+    hipStream_t stream_rec = nullptr;
+    hipEvent_t ev_rec_fork = nullptr, ev_rec = nullptr;
+    std::atomic<bool> rec_dirty{false};
+    long long opt_records_stream = 1; // PANGULU_HIP_RECORDS_STREAM=0: sparsify on the main stream as before
     int nb_cfg = 0;
     // options
     long long opt_host_mirror = 1;
@@ -1060,6 +1136,11 @@ void ensure_ready()
     HIP_CHECK(hipStreamCreateWithFlags(&B.stream3, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_fork3, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_join3, hipEventDisableTiming));
+    HIP_CHECK(hipStreamCreateWithFlags(&B.stream_rec, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&B.ev_rec_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&B.ev_rec, hipEventDisableTiming));
+    if (const char *e = getenv("PANGULU_HIP_RECORDS_STREAM"))
+        B.opt_records_stream = atol(e);
     // Descriptors are written once by the host and read once per workgroup: the kernels read them straight from
     // pinned host memory (non-coherent, so the device L2 may cache them) instead of waiting for a staging copy per
     // launch (rocprofv3 showed ~1900 blit dispatches, ~50 ms, per factorisation of the bench matrix).
@@ -1117,6 +1198,16 @@ void release_pending_segments(hipStream_t on = nullptr)
         r.used[i] = true;
     }
     r.pending.clear();
+}
+
+// sparse records are about to be read or rewritten on stream s: wait for the sparsify jobs of the records stream
+void join_records(hipStream_t s)
+{
+    if (!B.rec_dirty.load(std::memory_order_acquire))
+        return;
+    HIP_CHECK(hipStreamWaitEvent(s, B.ev_rec, 0));
+    if (s == B.stream)
+        B.rec_dirty.store(false, std::memory_order_release);
 }
 
 Segment acquire_segment()
@@ -1276,6 +1367,7 @@ const DiagAux &get_diag_aux(slot_t *upper, int nb)
 void mirror_to_host(slot_t *s, int nb)
 {
     size_t bytes = sizeof(val_t) * (size_t)host_nnz(s, nb);
+    join_records(B.stream);
     if (bytes)
         HIP_CHECK(hipMemcpyAsync(s->value, s->d_value, bytes, hipMemcpyDeviceToHost, B.stream));
 }
@@ -1443,6 +1535,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             HIP_CHECK(hipEventRecord(B.ev_fork, B.stream)); // mirrors are current from here on
         if (gs)
         {
+            join_records(B.stream); // operands and destinations of the LDS kernel are sparse records
             LaunchTimer lt(4);
             // columns per wavefront: 1 unless the grid would exceed 2^20 workgroups (more parallel waves beat fewer launches:
             // measured 176 ms vs 181 ms per factorisation of the bench matrix with an 8k-workgroup target)
@@ -1639,6 +1732,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
             LaunchTimer lt(nt >= ng ? 2 : 3);
             if (nsparse)
             {
+                join_records(B.stream); // the sparse solves read the diagonal halves' records (behind the fork: the dense solves do not wait)
                 int vblocks = (nb + TRSM_WAVES - 1) / TRSM_WAVES;
                 size_t lds = sizeof(val_t) * (size_t)nb * TRSM_WAVES;
                 hipLaunchKernelGGL(trsm_sparse_kernel, dim3((unsigned)(nsparse * vblocks)), dim3(TRSM_WAVES * 64), lds, B.stream, d_tasks,
@@ -1685,7 +1779,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
             st.sparse_current = true;
         }
         if (!MP.to_sparsify.empty())
-            flush_mirror_jobs(nb, MP.to_sparsify, false);
+            flush_mirror_jobs(nb, MP.to_sparsify, false, true);
 #endif
         // one launch serves both kinds; book it under the kind with more tasks, count tasks/bytes exactly
         B.stats.launches[nt >= ng ? 2 : 3]++;
@@ -1731,6 +1825,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
         GetrfTaskD *tasks = seg.alloc<GetrfTaskD>(take, &d_tasks);
 #if defined(CALCULATE_TYPE_R64)
         std::vector<double *> lu_images; // dense images that will hold L\\U after this launch
+        std::vector<MirrorJobD> deferred; // their sparse records are written by sparsify jobs on the records stream
 #endif
         double by = 0;
         for (size_t k = 0; k < take; k++)
@@ -1746,7 +1841,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             T.uval = up->d_value;
             T.dense = B.getrf_scratch + (size_t)k * nb * nb;
             T.preloaded = 0;
-            T.pad_ = 0;
+            T.defer_gather = 0;
 #if defined(CALCULATE_TYPE_R64)
             {
                 // work on the block's own mirror whenever the pool has one: it may already hold the block (updates
@@ -1759,6 +1854,13 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                     {
                         T.dense = m;
                         T.preloaded = (st.mirror_current && !st.sparse_current) ? 1u : 0u;
+                        if (B.opt_records_stream && nb <= 256)
+                        {
+                            T.defer_gather = 1;
+                            MirrorJobD J = mirror_job(lo, m, nb);
+                            J.diag_tiles = m + (size_t)nb * nb + MIRROR_MAP_BYTES / sizeof(double);
+                            deferred.push_back(J);
+                        }
                         lu_images.push_back(m);
                         st.lu_image = true;
                         st.image_halves = 3;
@@ -1788,6 +1890,8 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
         }
 #endif
         commit_segment(seg);
+        // (no join with the records stream: its jobs in flight write the records of blocks that are finished, these
+        // kernels touch the records of the blocks they factorise)
         {
             LaunchTimer lt(1, ks);
             bool blocked = blocked_kernel;
@@ -1798,12 +1902,20 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 static size_t lds_allowed = 0;
                 if (lds > lds_allowed)
                 {
-                    HIP_CHECK(hipFuncSetAttribute((const void *)getrf_blocked_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)getrf_blocked_f64_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)getrf_blocked_f64_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     lds_allowed = lds;
                 }
                 static const bool debug_stamps = getenv("PANGULU_HIP_DEBUG_GETRF") != nullptr;
-                hipLaunchKernelGGL(getrf_blocked_f64_kernel, dim3((unsigned)take), dim3(GETRF_BLOCKED_THREADS), lds, ks, d_tasks, nb,
-                                   B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
+                // (measured: 64.2 ms per factorisation of the bench matrix with the 512-thread variant from 129 blocks against 64.6 ms
+                // without -- both kernels slow down when they share CUs; off by default)
+                static const long narrow_from = getenv("PANGULU_HIP_GETRF_NARROW_FROM") ? atol(getenv("PANGULU_HIP_GETRF_NARROW_FROM")) : 1 << 30;
+                if ((long)take >= narrow_from)
+                    hipLaunchKernelGGL(getrf_blocked_f64_kernel<512>, dim3((unsigned)take), dim3(512), lds, ks, d_tasks, nb,
+                                       B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
+                else
+                    hipLaunchKernelGGL(getrf_blocked_f64_kernel<1024>, dim3((unsigned)take), dim3(1024), lds, ks, d_tasks, nb,
+                                       B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
             }
 #endif
             if (!blocked)
@@ -1814,6 +1926,8 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             HIP_CHECK(hipGetLastError());
         }
 #if defined(CALCULATE_TYPE_R64)
+        if (!deferred.empty())
+            HIP_CHECK(hipEventRecord(B.ev_rec_fork, ks)); // behind the factorisation, before the tile inversion
         if (!lu_images.empty())
         {
             // invert the 16 x 16 diagonal tiles of the fresh LU images in place (pg_hip_trsm_dense.h)
@@ -1833,6 +1947,10 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join3, 0));
         }
         release_pending_segments(ks); // (the descriptors are read on ks, which the main stream may not have joined yet)
+#if defined(CALCULATE_TYPE_R64)
+        if (!deferred.empty())
+            flush_mirror_jobs(nb, deferred, false, true, nullptr, true);
+#endif
         B.stats.launches[1]++;
         B.stats.tasks[1] += take;
         B.stats.alg_bytes[1] += by;
@@ -1936,6 +2054,7 @@ extern "C"
     void pangulu_platform_0201001_synchronize(void)
     {
         ensure_ready();
+        join_records(B.stream);
         HIP_CHECK(hipStreamSynchronize(B.stream));
     }
 
@@ -1972,6 +2091,7 @@ extern "C"
     {
         ensure_ready();
         // ordered after everything queued on the back-end stream, complete on return
+        join_records(B.stream);
         HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), B.stream));
         HIP_CHECK(hipStreamSynchronize(B.stream));
     }
@@ -1982,6 +2102,8 @@ extern "C"
         // stream == NULL is what the reference host passes from its receive thread
         // (src/pangulu_communication.c:1850,1880): use the back-end stream so later kernels are ordered behind it
         hipStream_t s = stream ? (hipStream_t)stream : B.stream;
+        if (kind != 0)
+            join_records(s); // (uploads of received blocks write receive slots, which no sparsify job touches)
         HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), s));
         if (!stream)
             HIP_CHECK(hipStreamSynchronize(s)); // the source is pageable host memory the caller may reuse at once
@@ -2126,6 +2248,7 @@ extern "C"
     void pangulu_platform_0201001_spmv(pangulu_inblock_idx nb, pangulu_storage_slot_t *a, calculate_type *x, calculate_type *y)
     {
         ensure_ready();
+        join_records(B.stream);
         hipLaunchKernelGGL(spmv_kernel, dim3(1), dim3(256), 0, B.stream, (int)nb, a->d_columnpointer, a->d_rowindex, a->d_value, x, y);
         HIP_CHECK(hipGetLastError());
     }
@@ -2143,6 +2266,7 @@ extern "C"
     {
         ensure_ready();
         size_t lds = sizeof(val_t) * (size_t)nb;
+        join_records(B.stream);
         if (uplo == PANGULU_LOWER)
             hipLaunchKernelGGL(sptrsv_kernel, dim3(1), dim3(256), lds, B.stream, (int)nb, s->d_columnpointer, s->d_rowindex, s->d_value, xval, 0);
         else
@@ -2167,6 +2291,7 @@ extern "C"
         }
         hipEvent_t e = ring[next];
         next = (next + 1) % ring.size();
+        join_records(B.stream); // a marker stands for "the blocks finished so far can be sent": their records included
         HIP_CHECK(hipEventRecord(e, B.stream)); // (side streams have been joined into the main stream by every call)
         return (void *)e;
     }
@@ -2267,6 +2392,7 @@ extern "C"
         }
         ensure_ready();
         std::lock_guard<std::mutex> g(B.mutex);
+        join_records(B.stream);
         HIP_CHECK(hipStreamSynchronize(B.stream));
         harvest_events();
         unsigned long long f[16];

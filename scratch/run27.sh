@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp
+export PANGULU_HIP_GETRF_NARROW_FROM=129
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r1r -o tl -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-profile-pass --steps 1 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/prof_r1r.log 2>&1
+cd $GRAFT_REPO_ROOT
+f=$(find gpurun_out/prof_r1r -name "*kernel_trace.csv" | head -1)
+python tools/timeline.py $f > gpurun_out/timeline_r1r.txt 2>&1
+rm -f $f

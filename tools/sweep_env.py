@@ -17,6 +17,6 @@ lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 0)
 for v in vals:
     os.environ[var] = v
     ts = []
-    for i in range(4):
+    for i in range(int(os.environ.get('SWEEP_REPS', '4'))):
         t0 = time.time(); pa.pangulu_gstrf(h); ts.append(time.time() - t0); lib.pangulu_amd_reset_numeric(h.ref)
-    print(var, "=", v, "ms", [round(x * 1e3, 1) for x in ts], "GF/s %.0f" % (h.info()["flop"] / min(ts) / 1e9), "batches", h.info()["batches"], flush=True)
+    print(var, "=", v, "ms", [round(x * 1e3, 1) for x in ts], "min %.1f median %.1f" % (min(ts) * 1e3, sorted(ts)[len(ts) // 2] * 1e3), "GF/s %.0f" % (h.info()["flop"] / min(ts) / 1e9), "batches", h.info()["batches"], flush=True)
