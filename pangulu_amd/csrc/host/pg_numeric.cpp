@@ -15,6 +15,7 @@
 //   * single-rank runs never synchronise with the device inside the loop: every batch goes to the back-end's
 //     one in-order stream, so program order is dependency order and the host simply runs ahead.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -136,6 +137,11 @@ struct Sched
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
     double gather_max_s = 2000e-6, gather_quiet_s = 300e-6, t_gather = 0;
+    // ... but only while blocks ARE arriving: the receive thread counts arrivals and pulls in flight; a drain that
+    // follows a dispatch with neither (the subtree phase of the factorisation exchanges nothing) goes out at once
+    std::atomic<u64> arrivals{0};
+    std::atomic<int> recv_inflight{0};
+    u64 arrivals_seen = 0;
     double t_last_progress = 0, t_last_arrival = 0, stall_limit_s = 120; // PANGULU_AMD_STALL_S
     // multi-rank without draining the device after every batch: receive slots are handed back, and finished blocks
     // announced, once a marker recorded behind the kernels that use / produce them has completed
@@ -755,7 +761,8 @@ struct Sched
             task_t t;
             while (S.heap.pop(t))
                 batch.push_back(t);
-            if (multi && (i64)batch.size() < S.rank_remain_task && batch.size() < gather_min_batch)
+            const bool expecting = multi && (recv_inflight.load(std::memory_order_relaxed) > 0 || arrivals.load(std::memory_order_relaxed) != arrivals_seen);
+            if (expecting && (i64)batch.size() < S.rank_remain_task && batch.size() < gather_min_batch)
             {
                 // Blocks from other ranks arrive one by one, and every launch costs its latency whatever it carries (a
                 // GETRF launch takes as long for 1 block as for 256): dispatching each arrival on its own degenerates
@@ -784,6 +791,8 @@ struct Sched
                 }
                 t_gather += wall_seconds() - t_begin;
             }
+            if (multi && !batch.empty())
+                arrivals_seen = arrivals.load(std::memory_order_relaxed);
             if (batch.empty())
             {
                 if (!idle_flush())
@@ -879,8 +888,10 @@ struct Sched
             {
                 S.rank_remain_recv--;
                 handle_arrival(p.s, p.h);
+                arrivals.fetch_add(1, std::memory_order_relaxed);
             }
             begun.clear();
+            recv_inflight.store(0, std::memory_order_relaxed);
         };
         while (S.rank_remain_recv != 0)
         {
@@ -923,6 +934,7 @@ struct Sched
             s->is_upper = (i32)h.is_upper;
             comm->recv_block_begin(s, h, src);
             begun.push_back(Begun{s, h});
+            recv_inflight.store((int)begun.size(), std::memory_order_relaxed);
             if (begun.size() >= 128)
                 finish();
         }
