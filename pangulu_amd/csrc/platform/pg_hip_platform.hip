@@ -181,6 +181,8 @@ struct GetrfTaskD
     val_t *uval;
     val_t *dense; // nb*nb scratch, only touched on the pattern
     u32 preloaded; // blocked kernel: `dense` already holds the block (a dense-mode mirror): skip zero + scatter
+    u32 invert_tiles; // blocked kernel: the image will serve the dense solves -- replace its 16 x 16 diagonal tiles by their
+                      // inverses before leaving (pg_hip_trsm_dense.h), after the factors have been gathered / the tiles saved
     u32 defer_gather; // blocked kernel on a mirror: leave the factors in the dense image, save the 16 x 16 diagonal tiles
                       // behind the mirror (they are about to be inverted in place) -- a sparsify job on the records
                       // stream brings the sparse record up to date off the critical path
@@ -941,6 +943,14 @@ __global__ __launch_bounds__(GETRF_BLOCKED_THREADS) __attribute__((amdgpu_waves_
     }
     __syncthreads();
     GETRF_STAMP(6)
+    if (T.invert_tiles)
+    {
+        // one wavefront per diagonal tile, 16 x 17 doubles of the (now free) panel image each
+        double(*Tw)[17] = reinterpret_cast<double(*)[17]>(smem_raw) + wave * 16;
+        for (int p0 = 0; p0 < nb / 16; p0 += nwaves)
+            invert_diag_tile(D, nb, p0 + wave, Tw, lane, p0 + wave < nb / 16, []()
+                             { __syncthreads(); });
+    }
     ops = wave_sum(ops);
     if (lane == 0 && ops)
         atomicAdd(flop_counter, ops);
@@ -1842,6 +1852,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             T.dense = B.getrf_scratch + (size_t)k * nb * nb;
             T.preloaded = 0;
             T.defer_gather = 0;
+            T.invert_tiles = 0;
 #if defined(CALCULATE_TYPE_R64)
             {
                 // work on the block's own mirror whenever the pool has one: it may already hold the block (updates
@@ -1854,6 +1865,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                     {
                         T.dense = m;
                         T.preloaded = (st.mirror_current && !st.sparse_current) ? 1u : 0u;
+                        T.invert_tiles = 1;
                         if (B.opt_records_stream && nb <= 256)
                         {
                             T.defer_gather = 1;
@@ -1927,16 +1939,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
         }
 #if defined(CALCULATE_TYPE_R64)
         if (!deferred.empty())
-            HIP_CHECK(hipEventRecord(B.ev_rec_fork, ks)); // behind the factorisation, before the tile inversion
-        if (!lu_images.empty())
-        {
-            // invert the 16 x 16 diagonal tiles of the fresh LU images in place (pg_hip_trsm_dense.h)
-            double **d_imgs;
-            double **imgs = seg.alloc<double *>(lu_images.size(), &d_imgs);
-            memcpy(imgs, lu_images.data(), sizeof(double *) * lu_images.size());
-            hipLaunchKernelGGL(diag_tile_inverse_kernel, dim3((unsigned)(lu_images.size() * (nb / 16))), dim3(64), 0, ks, d_imgs, nb);
-            HIP_CHECK(hipGetLastError());
-        }
+            HIP_CHECK(hipEventRecord(B.ev_rec_fork, ks)); // behind the factorisation
 #endif
         if (ks != B.stream)
         {

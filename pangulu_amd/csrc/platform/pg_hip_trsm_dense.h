@@ -25,18 +25,18 @@ struct TrsmDenseTaskD
 };
 
 // one wavefront per 16 x 16 diagonal tile: lane c < 16 computes column c of inv(U_pp) (back substitution) and of
-// inv(L_pp) (forward substitution, unit diagonal), then the tile is overwritten
-__global__ __launch_bounds__(64) void diag_tile_inverse_kernel(double *const *__restrict__ images, int nb)
+// inv(L_pp) (forward substitution, unit diagonal), then the tile is overwritten.  T: 16 x 17 doubles of LDS owned by
+// the calling wavefront; `sync` is a barrier for whoever shares the call (the wavefront's workgroup).
+template <typename Sync>
+__device__ inline void invert_diag_tile(double *D, int nb, int p, double (*T)[17], int lane, bool active, Sync sync)
 {
-    __shared__ double T[16][17];
-    double *D = images[blockIdx.x / (nb / 16)];
-    const int p = blockIdx.x % (nb / 16), lane = threadIdx.x;
     const size_t base = (size_t)(16 * p) * nb + 16 * p;
-    for (int i = lane; i < 256; i += 64)
-        T[i & 15][i >> 4] = D[base + (size_t)(i >> 4) * nb + (i & 15)]; // T[row][col]
-    __syncthreads();
+    if (active)
+        for (int i = lane; i < 256; i += 64)
+            T[i & 15][i >> 4] = D[base + (size_t)(i >> 4) * nb + (i & 15)]; // T[row][col]
+    sync();
     double xu[16], xl[16];
-    if (lane < 16)
+    if (active && lane < 16)
     {
         const int c = lane;
         // U x = e_c  (upper, pivots clamped like the factorisation clamps them)
@@ -63,14 +63,23 @@ __global__ __launch_bounds__(64) void diag_tile_inverse_kernel(double *const *__
             xl[r] = (r < c) ? 0.0 : s;
         }
     }
-    __syncthreads();
-    if (lane < 16)
+    sync();
+    if (active && lane < 16)
     {
         const int c = lane;
 #pragma unroll
         for (int r = 0; r < 16; r++)
             D[base + (size_t)c * nb + r] = (r <= c) ? xu[r] : xl[r];
     }
+}
+
+// images whose tiles were not inverted by the kernel that produced them (LU images rebuilt from received halves)
+__global__ __launch_bounds__(64) void diag_tile_inverse_kernel(double *const *__restrict__ images, int nb)
+{
+    __shared__ double T[16][17];
+    double *D = images[blockIdx.x / (nb / 16)];
+    invert_diag_tile(D, nb, (int)(blockIdx.x % (nb / 16)), T, (int)threadIdx.x, true, []()
+                     { __syncthreads(); });
 }
 
 // LU image of a diagonal block factorised on ANOTHER rank, from whichever of its halves have arrived (strictly lower CSC
