@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
             unsigned bb_ = 0;                                                                        \
             _Pragma("unroll") for (int c_ = 0; c_ < 8; c_++)                                         \
                 bb_ |= (((w_[c_ >> 1] >> (16 * (c_ & 1))) >> s_) & 1u) << c_;                        \
-            if (ab_ && bb_)                                                                          \
+            if (ab_ && bb_ && (!G.slab_mask || ((G.slab_mask >> s_) & 1u)))                          \
                 v_ = (bb_ << 8) | ab_;                                                               \
             if (s_ == 0)                                                                             \
             {                                                                                        \

@@ -153,7 +153,10 @@ struct SsssmGroupD
     // from zero and ADDS its partial sum to the destination with floating-point atomics (otherwise the longest
     // queue sets the duration of the whole launch)
     u32 atomic;
-    u32 pad_;
+    // MFMA kernel, nb <= 256: bit s set = this group works on K-slab s (16 wide) of every task; 0 = all slabs.  A launch
+    // with a handful of updates (the diagonal block's update near the root of the tree, on the critical path of
+    // every level) is cut four ways along K so that 16 CUs instead of 4 share a 256 x 256 x 256 product.
+    u32 slab_mask;
 };
 
 struct TrsmTaskD
@@ -1390,6 +1393,7 @@ const double SV = (double)sizeof(val_t);
 // Tasks arrive grouped by destination.  Per group the destination is either dense-mode (updates accumulate in its
 // mirror) or sparse; per task the update runs on the matrix cores when destination and both operands have mirrors,
 // on the LDS-accumulator kernel otherwise.
+#define DG_TILE_HOST 128 // = DG_TILE of pg_hip_dense.h (R64 only; harmless elsewhere)
 void launch_ssssm(int nb, task_t **list, size_t n)
 {
     if (n == 0)
@@ -1407,8 +1411,10 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         SsssmGroupD *d_groups_s, *d_groups_d;
         SsssmTaskD *tasks_s = seg.alloc<SsssmTaskD>(take, &d_tasks_s);
         SsssmTaskD *tasks_d = seg.alloc<SsssmTaskD>(take, &d_tasks_d);
+        const int tiles_per_dim = nb >= DG_TILE_HOST ? nb / DG_TILE_HOST : 1;
+        const unsigned ksplit = (nb <= 256 && nb % 64 == 0 && take * (size_t)(tiles_per_dim * tiles_per_dim) <= 64) ? 4u : 1u;
         SsssmGroupD *groups_s = seg.alloc<SsssmGroupD>(take, &d_groups_s);
-        SsssmGroupD *groups_d = seg.alloc<SsssmGroupD>(take, &d_groups_d);
+        SsssmGroupD *groups_d = seg.alloc<SsssmGroupD>(take * ksplit, &d_groups_d);
         if (!tasks_s || !tasks_d || !groups_s || !groups_d)
         {
             fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
@@ -1522,9 +1528,15 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             {
                 G.task_begin = (u32)c;
                 G.task_end = (u32)std::min(nd, c + chunk);
-                G.atomic = split ? 1u : 0u;
-                groups_d[gd++] = G;
+                G.atomic = (split || ksplit > 1) ? 1u : 0u;
+                const unsigned slabs = (unsigned)nb / 16u, per = slabs / ksplit;
+                for (unsigned q = 0; q < ksplit; q++)
+                {
+                    G.slab_mask = ksplit > 1 ? (((1u << per) - 1u) << (q * per)) : 0u;
+                    groups_d[gd++] = G;
+                }
             }
+            G.slab_mask = 0;
             i = j;
         }
 #if defined(CALCULATE_TYPE_R64)
