@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, nargs=2, default=[110, 110], help="shell nx ny of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, nargs=2, default=[200, 200], help="shell nx ny of the CPU-baseline sample (about 15 s of one core)")
     ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "ipc"), choices=["host", "rccl", "ipc"],
                     help="block exchange for --gpus > 1: ipc = the consumer pulls each record out of the owner's HBM arena with "
                          "one peer copy over xGMI (default), rccl = ncclSend/ncclRecv per ordered pair; both are verified by a "
@@ -154,10 +154,6 @@ def main():
         rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port, transport, None)
         assert rc == 0
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, pa, M, lib)
-
     if rank == 0:
         mat, workload = make_matrix(args, M)
         n, cp, ri, va, coords = mat
@@ -238,16 +234,16 @@ def main():
                             "frac": ach / HBM_PEAK_GBS, "traffic": None}
             # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process, so the value
             # is the one the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes measured for this exact workload
-            # (profiles/r01m_final_shell398.md; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+            # (profiles/r01t_final_shell398.md; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
             rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_blocked_f64_kernel",
                             "tstrf": "void trsm_dense_f64_kernel<16>", "gessm": "void trsm_dense_f64_kernel<16>",
                             "ssssm_sparse": "void ssssm_sparse_kernel<false>"}.get(dom)
-            traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01m_hbm_traffic_shell398.json")
+            traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01t_hbm_traffic_shell398.json")
             if world == 1 and default_workload and rocprof_name and os.path.exists(traffic_file):
                 t = json.load(open(traffic_file)).get(rocprof_name)
                 if t:
                     roofline["traffic"] = t["hbm_bytes_per_launch"]
-                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass, profiles/r01m_final_shell398.md)"
+                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass, profiles/r01t_final_shell398.md)"
             roofline["avg_launch_us"] = kernels[dom]["avg_launch_us"]
             roofline["share_of_kernel_time"] = kernels[dom]["ms"] / sum(k["ms"] for k in kernels.values())
 
@@ -264,6 +260,12 @@ def main():
     if world > 1:
         lib.pangulu_amd_comm_finalize()
 
+    # the CPU baseline runs LAST: measured before the GPU steps it left them 15 % slower (72 instead of 61 ms per step
+    # after ten seconds of host-only work, whatever the warm-up count: the device's clocks take a while to come back)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, pa, M, lib)
+
     if rank == 0:
         value = flop / (ms_per_step / 1e3) / 1e9
         line = {
@@ -275,7 +277,7 @@ def main():
                 "workload": workload, "n": int(info["n"]), "nnz": int(info["nnz"]), "nb": int(info["nb"]),
                 "ordering": "built-in nested dissection (geometric)" if args.ordering == "nd" else "identity",
                 "symbolic_nnz": int(info["symbolic_nnz"]), "flop": int(info["flop"]),
-                "parallelism": "2D block-cyclic %dx%d" % grid(world),
+                "parallelism": "2D block-cyclic %dx%d" % grid(world) + (" above subtrees of the block elimination tree mapped to single ranks" if world > 1 else ""),
                 # what is really in use: ipc / rccl fall back to host staging on all ranks when their self-test fails
                 "transport": effective_transport,
                 "blocks": int(info["nblocks_nondiag"]),
