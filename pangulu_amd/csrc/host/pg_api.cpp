@@ -171,6 +171,19 @@ extern "C"
             set_world(nullptr);
             return 0;
         }
+        // the device transports capture the calling thread's current device: select this rank's GPU first, by the same
+        // rule pangulu_init uses (LOCAL_RANK, else the rank, modulo the visible devices)
+        Platform &plat = active_platform();
+        if (!plat.host_memory && plat.get_device_num && plat.set_default_device)
+        {
+            int ndev = 0;
+            plat.get_device_num(&ndev);
+            if (ndev > 0)
+            {
+                const char *lr = getenv("LOCAL_RANK");
+                plat.set_default_device(lr ? atoi(lr) % ndev : rank % ndev);
+            }
+        }
         Comm *c = make_socket_comm(rank, size, addr ? addr : "127.0.0.1", base_port, transport, nccl_unique_id);
         set_world(c);
         return 0;

@@ -82,6 +82,8 @@ struct IpcComm : SocketComm
     {
         close_peers();
         ipc_ok = false;
+        if (nchunks > 0 && hipGetDevice(&device) != hipSuccess) // (the caller has selected this rank's device by now)
+            device = 0;
         const bool trace = getenv("PANGULU_AMD_TRACE") != nullptr;
         if (trace)
             fprintf(stderr, "[pangulu_amd trace] rank %d: registering a %.2f GB arena (%zu chunks) for peer copies\n", rank, (double)total_bytes / 1e9, nchunks);
