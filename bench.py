@@ -261,7 +261,7 @@ def main():
         lib.pangulu_amd_comm_finalize()
 
     # the CPU baseline runs LAST: measured before the GPU steps it left them 15 % slower (72 instead of 61 ms per step
-    # after ten seconds of host-only work, whatever the warm-up count: the device's clocks take a while to come back)
+    # after ten seconds of host-only work with the device idle, whatever the warm-up count; cause not isolated)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, pa, M, lib)
