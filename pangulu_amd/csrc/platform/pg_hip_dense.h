@@ -42,8 +42,19 @@ __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PER_EU, DG_WAVES_PER_EU))) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
                                                                const SsssmTaskD *__restrict__ tasks, int nb,
-                                                               unsigned long long *__restrict__ product_counter)
+                                                               unsigned long long *__restrict__ product_counter,
+                                                               unsigned long long *dbg)
 {
+    // (debug stamps: every 64th workgroup adds its phase times; PANGULU_HIP_DEBUG_SSSSM)
+    const bool stamping = dbg && threadIdx.x == 0 && (blockIdx.x & 63) == 0;
+    unsigned long long stamp_ = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define DG_STAMP(slot)                                                     \
+    if (stamping)                                                          \
+    {                                                                      \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+        atomicAdd(&dbg[slot], now_ - stamp_);                              \
+        stamp_ = now_;                                                     \
+    }
     __shared__ __align__(16) double sA[DG_K * DG_LD];
     __shared__ __align__(16) double sB[DG_K * DG_LD];
     const int tiles = nb / DG_TILE;
@@ -200,14 +211,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     }
 
     DG_NEXT_STEP(nxt_step)
+    DG_STAMP(0)
     if (nxt_step < 0)
+    {
+        if (stamping)
+            atomicAdd(&dbg[7], 1ull << 32); // (empty workgroups in the high word)
         return; // nothing of these updates reaches this tile
+    }
     DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb)
     while (nxt_step >= 0)
     {
         cur_ab = nxt_ab;
         cur_bb = nxt_bb;
         __syncthreads(); // everyone is done reading the previous slab
+        DG_STAMP(1)
         // (pieces that were not fetched hold stale finite values; no MFMA reads them)
         *reinterpret_cast<double2 *>(&sA[(a_k + 0) * DG_LD + a_m]) = ra0;
         *reinterpret_cast<double2 *>(&sA[(a_k + 4) * DG_LD + a_m]) = ra1;
@@ -221,10 +238,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         sB[(b_k + 1) * DG_LD + b_n + 64] = rb2.y;
         sB[b_k * DG_LD + b_n + 96] = rb3.x;
         sB[(b_k + 1) * DG_LD + b_n + 96] = rb3.y;
+        DG_STAMP(2)
         __syncthreads();
+        DG_STAMP(3)
         DG_NEXT_STEP(nxt_step)
         if (nxt_step >= 0)
             DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb) // in flight while the matrix cores work
+        DG_STAMP(4)
         const unsigned a4 = (cur_ab >> (wm / 16)) & 0xFu, b4 = (cur_bb >> (wn / 16)) & 0xFu;
         if (a4 && b4)
         {
@@ -255,6 +275,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
                 }
             }
         }
+        DG_STAMP(5)
+        if (stamping)
+            atomicAdd(&dbg[7], 1ull); // slab steps in the low word
     }
 #undef DG_NEXT_STEP
 #undef DG_FILL_WINDOW
@@ -263,26 +286,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         atomicAdd(product_counter, (unsigned long long)nprod); // 16 x 16 x 16 products issued to the matrix cores
 
     double *__restrict__ C = G.cdense;
+    // Read-modify-write of the touched 16 x 16 pieces, a column of four pieces (16 values per lane) at a time: all its
+    // loads go out together, then all its stores.  Piece by piece (load 4, store 4, load 4 ...) every load waits for the
+    // stores before it as well -- loads and stores share one counter and cannot be waited on separately -- which made this
+    // epilogue 16 dependent memory round trips, 14 us of a workgroup's 42.
 #pragma unroll
     for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
+    {
+        const unsigned t4 = (touched >> (4 * ni)) & 0xFu;
+        if (!t4)
+            continue; // no product reached this column of pieces
+        if (G.atomic)
         {
-            if (!((touched >> (4 * ni + mi)) & 1u))
-                continue; // no product reached this 16 x 16 piece of C
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int mi = 0; mi < 4; mi++)
             {
-                const size_t off = (size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15);
-                if (G.atomic)
+                if (!((t4 >> mi) & 1u))
+                    continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
                 {
+                    const size_t off = (size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15);
                     if (acc[ni][mi][r] != 0.0)
                         atomicAdd(&C[off], -acc[ni][mi][r]);
                 }
-                else
-                    C[off] -= acc[ni][mi][r];
             }
+            continue;
         }
+        double old[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                old[mi][r] = ((t4 >> mi) & 1u) ? C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)] : 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+        {
+            if (!((t4 >> mi) & 1u))
+                continue; // no product reached this 16 x 16 piece of C
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)] = old[mi][r] - acc[ni][mi][r];
+        }
+    }
+    DG_STAMP(6)
+#undef DG_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1591,8 +1591,9 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             {
                 LaunchTimer lt(5, ds);
                 int tiles = nb / DG_TILE;
+                static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, ds, d_groups_d, d_tasks_d, nb,
-                                   B.opt_count_flops ? B.d_flops + 6 : nullptr);
+                                   B.opt_count_flops ? B.d_flops + 6 : nullptr, debug_ssssm ? B.d_flops + 8 : nullptr);
             }
             if (B.opt_count_flops)
                 hipLaunchKernelGGL(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, ds, d_tasks_d, nb, B.d_flops + 5);
@@ -1767,10 +1768,12 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 hipStream_t ds = (B.opt_two_streams && nsparse) ? B.stream2 : B.stream;
                 if (ds != B.stream)
                     HIP_CHECK(hipStreamWaitEvent(ds, B.ev_fork, 0));
+                static const bool debug_trsm = getenv("PANGULU_HIP_DEBUG_TRSM") != nullptr; // (stamps share the GETRF debug slots)
+                unsigned long long *dbg = debug_trsm ? B.d_flops + 8 : nullptr;
                 if (nb == 256)
-                    hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks);
+                    hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks, dbg);
                 else
-                    hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks);
+                    hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks, dbg);
                 if (ds != B.stream)
                 {
                     HIP_CHECK(hipEventRecord(B.ev_join, ds));
@@ -2412,6 +2415,12 @@ extern "C"
         harvest_events();
         unsigned long long f[16];
         HIP_CHECK(hipMemcpy(f, B.d_flops, sizeof(f), hipMemcpyDeviceToHost));
+        if (getenv("PANGULU_HIP_DEBUG_SSSSM"))
+            fprintf(stderr, "[ssssm_dense stamps, every 64th workgroup, shader clocks] bookkeeping+first step %llu | barrier A %llu | LDS stage (waits for the slab) %llu | barrier B %llu | next step + loads issued %llu | mfma %llu | C update %llu | slab steps %llu, empty workgroups %llu\n",
+                    f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15] & 0xFFFFFFFFull, f[15] >> 32);
+        if (getenv("PANGULU_HIP_DEBUG_TRSM"))
+            fprintf(stderr, "[trsm stamps, workgroup 0, shader clocks] setup+x loads %llu | prefetch issue %llu | barrier A %llu | stage %llu | barrier B %llu | mfma loop %llu | tail chain %llu | stores %llu\n",
+                    f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15]);
         if (getenv("PANGULU_HIP_DEBUG_GETRF"))
             fprintf(stderr, "[getrf stamps, block 0, 100 MHz ticks] scatter %llu | panel-load %llu | pivots %llu | panel-store %llu | strip %llu | gemm %llu | gather %llu\n",
                     f[8], f[9], f[10], f[11], f[12], f[13], f[14]);

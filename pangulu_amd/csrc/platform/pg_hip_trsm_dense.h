@@ -132,8 +132,16 @@ __global__ __launch_bounds__(1024) void half_image_kernel(const HalfImageJobD *_
 // current one is consumed), laid out so that the MFMA A-operand reads are conflict-free:
 //     TSTRF  sT[c * 258 + row]   (c = column within the panel)     GESSM  sT[k * 16 + r]   (r = row within the panel)
 template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks, unsigned long long *dbg)
 {
+    unsigned long long stamp_ = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define TRSM_STAMP(slot)                                                   \
+    if (dbg && threadIdx.x == 0 && blockIdx.x == 0)                        \
+    {                                                                      \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+        dbg[slot] += now_ - stamp_;                                        \
+        stamp_ = now_;                                                     \
+    }
     constexpr int nb = NP * 16;
     constexpr int LDT = nb + 2;
     __shared__ __align__(16) double sT[16 * LDT];
@@ -226,15 +234,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
         for (int g = 0; g < 4; g++)
             xs[p][g] = !((my_lv >> p) & 1u) ? 0.0
                                              : (tstrf ? Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] : Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g]);
+    TRSM_STAMP(0)
     TRSM_PREFETCH(wg_first)
+    TRSM_STAMP(1)
 #pragma unroll
     for (int p = 0; p < NP; p++)
     {
         if (!((wg_lv >> p) & 1u))
             continue; // (workgroup-uniform) no strip of this workgroup has a tile in panel p: X_p = 0 for all of them
         __syncthreads(); // everyone is done with the previous panel's image
+        TRSM_STAMP(2)
         TRSM_STAGE(p)
+        TRSM_STAMP(3)
         __syncthreads();
+        TRSM_STAMP(4)
         {
             // the next panel any strip needs goes in flight now
             const unsigned later = (p + 1 < NP) ? (wg_lv >> (p + 1)) : 0u;
@@ -265,6 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
                 part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xs[q][kq], part[kq], 0, 0, 0);
             }
         }
+        TRSM_STAMP(5)
         v4f64 acc = (part[0] + part[1]) + (part[2] + part[3]);
         // multiply by the inverted diagonal tile (upper part: inv(U_pp); strictly lower part: inv(L_pp), unit diagonal)
         v4f64 x = {0.0, 0.0, 0.0, 0.0};
@@ -280,17 +294,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[kq], x, 0, 0, 0);
         }
         xs[p] = x;
+        TRSM_STAMP(6)
+    }
+    // The solution tiles are written only now.  A store per panel sits in the same vmcnt counter as the next panel's
+    // prefetch loads; with loads and stores mixed the counter cannot be waited on partially, so every staging step
+    // would also wait for the previous panel's stores to come back.
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+    {
+        if (!((my_lv >> p) & 1u))
+            continue;
 #pragma unroll
         for (int g = 0; g < 4; g++)
         {
             if (tstrf)
-                Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] = x[g];
+                Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] = xs[p][g];
             else
-                Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g] = x[g];
+                Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g] = xs[p][g];
         }
     }
+    TRSM_STAMP(7)
 #undef TRSM_PREFETCH
 #undef TRSM_STAGE
+#undef TRSM_STAMP
 }
 
 // structural flops of the solves that ran on the dense path (src/pangulu_kernel_interface.c:84-159): one workgroup
