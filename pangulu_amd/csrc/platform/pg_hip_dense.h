@@ -400,8 +400,17 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
             // dense solves touch live 16 x 16 tiles only, sparsify reads pattern entries), so only live tiles are
             // cleared -- for fill of a few percent that is a fraction of the nb*nb image.  (Dead tiles keep whatever
             // the memory held; the sparse-update kernel carries such values through its column pass unchanged.)
-            for (u32 p = e0 + threadIdx.x; p < e1; p += blockDim.x)
-                atomicOr(&occ[(c0 + mirror_column_of(sp, ncols, p)) >> 4], 1u << (J.lo.idx[p] >> 4));
+            for (u32 p0 = e0 + threadIdx.x; p0 < e1; p0 += 4 * blockDim.x)
+            {
+                u32 r4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    r4[u] = p0 + u * blockDim.x < e1 ? J.lo.idx[p0 + u * blockDim.x] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (p0 + u * blockDim.x < e1)
+                        atomicOr(&occ[(c0 + mirror_column_of(sp, ncols, p0 + u * blockDim.x)) >> 4], 1u << (r4[u] >> 4));
+            }
             __syncthreads();
             const int tpc = nb / 2; // 16-byte pieces per column; eight of them per 16-row slab
             for (int i = threadIdx.x; i < ncols * tpc; i += blockDim.x)
@@ -426,13 +435,32 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
                     base[i] = 0.0;
         }
         __syncthreads();
-        for (u32 p = e0 + threadIdx.x; p < e1; p += blockDim.x)
+        // four entries per thread and pass: their index and value loads go out together, then the four stores (one
+        // entry at a time, every iteration's loads wait for the previous iteration's store as well: loads and stores
+        // share one counter)
+        for (u32 p0 = e0 + threadIdx.x; p0 < e1; p0 += 4 * blockDim.x)
         {
-            const int c = c0 + mirror_column_of(sp, ncols, p);
-            const u32 r = J.lo.idx[p];
-            J.dense[(size_t)c * nb + r] = J.lo.val[p];
-            if (mapped && !by_tiles)
-                atomicOr(&occ[c >> 4], 1u << (r >> 4));
+            u32 r4[4];
+            double v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const u32 p = p0 + u * blockDim.x;
+                r4[u] = p < e1 ? J.lo.idx[p] : 0u;
+                v4[u] = p < e1 ? J.lo.val[p] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const u32 p = p0 + u * blockDim.x;
+                if (p < e1)
+                {
+                    const int c = c0 + mirror_column_of(sp, ncols, p);
+                    J.dense[(size_t)c * nb + r4[u]] = v4[u];
+                    if (mapped && !by_tiles)
+                        atomicOr(&occ[c >> 4], 1u << (r4[u] >> 4));
+                }
+            }
         }
         for (u32 p = f0 + threadIdx.x; p < f1; p += blockDim.x) // upper half of a diagonal block
         {
@@ -470,12 +498,27 @@ __global__ __launch_bounds__(256) void sparsify_kernel(const MirrorJobD *__restr
         }
         __syncthreads();
         const u32 e0 = sp[0], e1 = sp[ncols], f0 = su[0], f1 = su[ncols];
-        for (u32 p = e0 + threadIdx.x; p < e1; p += blockDim.x)
+        for (u32 p0 = e0 + threadIdx.x; p0 < e1; p0 += 4 * blockDim.x) // (four entries per pass, see densify_kernel)
         {
-            const int c = c0 + mirror_column_of(sp, ncols, p);
-            const u32 r = J.lo.idx[p];
-            J.lo.val[p] = (J.diag_tiles && (r >> 4) == (u32)(c >> 4)) ? J.diag_tiles[((c >> 4) << 8) + ((c & 15) << 4) + (r & 15)]
-                                                                   : J.dense[(size_t)c * nb + r];
+            u32 r4[4];
+            double v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                r4[u] = p0 + u * blockDim.x < e1 ? J.lo.idx[p0 + u * blockDim.x] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const u32 p = p0 + u * blockDim.x;
+                const int c = c0 + mirror_column_of(sp, ncols, p < e1 ? p : e0);
+                const u32 r = r4[u];
+                v4[u] = p >= e1 ? 0.0
+                                : (J.diag_tiles && (r >> 4) == (u32)(c >> 4)) ? J.diag_tiles[((c >> 4) << 8) + ((c & 15) << 4) + (r & 15)]
+                                                                            : J.dense[(size_t)c * nb + r];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (p0 + u * blockDim.x < e1)
+                    J.lo.val[p0 + u * blockDim.x] = v4[u];
         }
         for (u32 p = f0 + threadIdx.x; p < f1; p += blockDim.x)
         {
