@@ -219,6 +219,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         return; // nothing of these updates reaches this tile
     }
     DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb)
+    // A group that owns its destination and whose whole queue fits the bookkeeping window knows from the maps which
+    // 16 x 16 pieces of C it is going to touch: their values go into the accumulators now (negated: acc = -C + sum A B,
+    // C = -acc at the end), in flight together with the first slab, and the epilogue is stores only -- read-modify-write
+    // at the end costs memory round trips that nothing hides.
+    unsigned pre = 0;
+    double *__restrict__ C = G.cdense;
+    if (mapped && ntask <= DG_WINDOW && !G.atomic)
+    {
+        unsigned m = 0;
+        for (int e = lane; e < (int)ntask * 16; e += 64)
+        {
+            const unsigned v = s_abbb[e];
+            const unsigned a4 = ((v & 0xFFu) >> (wm / 16)) & 0xFu, b4 = ((v >> 8) >> (wn / 16)) & 0xFu;
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+                if ((b4 >> ni) & 1u)
+                    m |= a4 << (4 * ni);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            m |= (unsigned)__shfl_xor((int)m, off, 64);
+        pre = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                if ((pre >> (4 * ni + mi)) & 1u)
+                {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        acc[ni][mi][r] = -C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)];
+                }
+    }
     while (nxt_step >= 0)
     {
         cur_ab = nxt_ab;
@@ -285,7 +318,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     if (product_counter && lane == 0 && nprod)
         atomicAdd(product_counter, (unsigned long long)nprod); // 16 x 16 x 16 products issued to the matrix cores
 
-    double *__restrict__ C = G.cdense;
+    if (pre)
+    {
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                if ((pre >> (4 * ni + mi)) & 1u)
+                {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)] = -acc[ni][mi][r];
+                }
+        touched = 0; // (= pre: everything has been written)
+    }
     // Read-modify-write of the touched 16 x 16 pieces, a column of four pieces (16 values per lane) at a time: all its
     // loads go out together, then all its stores.  Piece by piece (load 4, store 4, load 4 ...) every load waits for the
     // stores before it as well -- loads and stores share one counter and cannot be waited on separately -- which made this
