@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+PANGULU_HIP_DEBUG_GETRF=1 SWEEP_REPS=10 timeout 300 python tools/sweep_env.py PANGULU_AMD_PANEL_LOOKAHEAD 1 0 2>&1 | grep -v amdgpu.ids | sed 's/ms \[.*\] min/min/'
