@@ -136,7 +136,7 @@ struct Sched
     bool panel_lookahead_on = true;   // PANGULU_AMD_PANEL_LOOKAHEAD (0 disables)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
-    double gather_max_s = 2000e-6, gather_quiet_s = 300e-6, t_gather = 0;
+    double gather_max_s = 600e-6, gather_quiet_s = 60e-6, t_gather = 0;
     // ... but only while blocks ARE arriving: the receive thread counts arrivals and pulls in flight; a drain that
     // follows a dispatch with neither (the subtree phase of the factorisation exchanges nothing) goes out at once
     std::atomic<u64> arrivals{0};
