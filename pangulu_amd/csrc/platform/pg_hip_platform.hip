@@ -2419,8 +2419,8 @@ extern "C"
             fprintf(stderr, "[ssssm_dense stamps, every 64th workgroup, shader clocks] bookkeeping+first step %llu | barrier A %llu | LDS stage (waits for the slab) %llu | barrier B %llu | next step + loads issued %llu | mfma %llu | C update %llu | slab steps %llu, empty workgroups %llu\n",
                     f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15] & 0xFFFFFFFFull, f[15] >> 32);
         if (getenv("PANGULU_HIP_DEBUG_TRSM"))
-            fprintf(stderr, "[trsm stamps, workgroup 0, shader clocks] setup+x loads %llu | prefetch issue %llu | barrier A %llu | stage %llu | barrier B %llu | mfma loop %llu | tail chain %llu | stores %llu\n",
-                    f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15]);
+            fprintf(stderr, "[trsm stamps, every 64th workgroup, shader clocks] setup+x loads %llu | prefetch issue %llu | barrier A %llu | stage %llu | barrier B %llu | mfma loop %llu | tail chain %llu | stores %llu, empty workgroups %llu\n",
+                    f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15] & ((1ull << 40) - 1), f[15] >> 40);
         if (getenv("PANGULU_HIP_DEBUG_GETRF"))
             fprintf(stderr, "[getrf stamps, block 0, 100 MHz ticks] scatter %llu | panel-load %llu | pivots %llu | panel-store %llu | strip %llu | gemm %llu | gather %llu\n",
                     f[8], f[9], f[10], f[11], f[12], f[13], f[14]);

@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
 {
     unsigned long long stamp_ = dbg ? __builtin_amdgcn_s_memtime() : 0;
 #define TRSM_STAMP(slot)                                                   \
-    if (dbg && threadIdx.x == 0 && blockIdx.x == 0)                        \
+    if (dbg && threadIdx.x == 0 && (blockIdx.x & 63) == 0)                 \
     {                                                                      \
         unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
-        dbg[slot] += now_ - stamp_;                                        \
+        atomicAdd(&dbg[slot], now_ - stamp_);                              \
         stamp_ = now_;                                                     \
     }
     constexpr int nb = NP * 16;
@@ -224,7 +224,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
     const unsigned my_lv = swave == 0 ? lv[0] : swave == 1 ? lv[1] : swave == 2 ? lv[2] : lv[3];
     const unsigned wg_lv = lv[0] | lv[1] | lv[2] | lv[3];
     if (wg_lv == 0)
+    {
+        if (dbg && threadIdx.x == 0 && (blockIdx.x & 63) == 0)
+            atomicAdd(&dbg[7], 1ull << 40); // (empty workgroups counted in the high bits of the last slot)
         return;
+    }
     const int wg_first = __builtin_ctz(wg_lv);
 
     // tile p, register g of lane l  <->  TSTRF: X(o0 + l15, 16p + l4 + 4g)    GESSM: X(16p + l4 + 4g, o0 + l15)
