@@ -1769,8 +1769,14 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 if (ds != B.stream)
                     HIP_CHECK(hipStreamWaitEvent(ds, B.ev_fork, 0));
                 static const bool debug_trsm = getenv("PANGULU_HIP_DEBUG_TRSM") != nullptr; // (stamps share the GETRF debug slots)
+                // barrier-free kernel by default (PANGULU_HIP_TRSM_DIRECT=0: the LDS-staged one)
+                static const bool direct = getenv("PANGULU_HIP_TRSM_DIRECT") ? atoi(getenv("PANGULU_HIP_TRSM_DIRECT")) != 0 : true;
                 unsigned long long *dbg = debug_trsm ? B.d_flops + 8 : nullptr;
-                if (nb == 256)
+                if (direct && nb == 256)
+                    hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks);
+                else if (direct)
+                    hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks);
+                else if (nb == 256)
                     hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks, dbg);
                 else
                     hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks, dbg);

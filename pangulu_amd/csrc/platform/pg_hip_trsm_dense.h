@@ -323,6 +323,139 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
 #undef TRSM_STAMP
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Barrier-free variant.  In-kernel stamps of the LDS-staged kernel above on the bench matrix: 19 % of a workgroup's time
+// is spent at the start-of-panel barrier (its four strips have different live tiles), 11 + 2 % staging the factor's
+// panel, 39 % of the workgroups have nothing to do at all.  Here every wavefront solves its strip on its own: the
+// factor tiles it needs -- only those that meet a live solution tile -- come straight from the LU image (L2-resident:
+// all solves of a level read the same few images) into MFMA operand registers, two tiles ahead of the matrix cores;
+// no LDS, no barriers, a wavefront without live tiles leaves at once.
+//   TSTRF  A'[i = c][k] = U(16q + k, 16p + c)  = LU[(16p + c) nb + 16q + k]
+//   GESSM  A [i = r][k] = L(16p + r, 16q + k)  = LU[(16q + k) nb + 16p + r]
+// -----------------------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_direct_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks)
+{
+    constexpr int nb = NP * 16;
+    const int slabs = nb / 64;
+    const unsigned bid = logical_block_id((unsigned)slabs);
+    const TrsmDenseTaskD T = tasks[bid / slabs];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int o0 = (bid % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
+    double *__restrict__ Bm = T.b;
+    const double *__restrict__ LU = T.lu;
+    const bool tstrf = T.is_tstrf != 0;
+    const unsigned short *map = mirror_map(Bm, nb);
+    unsigned my_lv = 0;
+    {
+        const int strip = o0 >> 4;
+        if (tstrf)
+        {
+            for (int c = 0; c < NP; c++)
+                my_lv |= (((unsigned)map[c] >> strip) & 1u) << c;
+        }
+        else
+            my_lv = map[strip];
+        my_lv = (unsigned)__builtin_amdgcn_readfirstlane((int)my_lv);
+    }
+    if (my_lv == 0)
+        return;
+    // factor tile (q, p): the four k-quarters of this lane's A operand
+    const size_t a_lane = tstrf ? (size_t)l15 * nb + l4 : (size_t)l4 * nb + l15;
+#define TRSM_A_PTR(q_, p_) (LU + a_lane + (tstrf ? (size_t)(16 * (p_)) * nb + 16 * (q_) : (size_t)(16 * (q_)) * nb + 16 * (p_)))
+#define TRSM_A_LOAD(dst_, q_, p_)                                                  \
+    {                                                                              \
+        const double *ap_ = TRSM_A_PTR(q_, p_);                                    \
+        _Pragma("unroll") for (int kq_ = 0; kq_ < 4; kq_++)                        \
+            (dst_)[kq_] = tstrf ? ap_[4 * kq_] : ap_[(size_t)(4 * kq_) * nb];      \
+    }
+    v4f64 xs[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            xs[p][g] = !((my_lv >> p) & 1u) ? 0.0
+                                             : (tstrf ? Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] : Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g]);
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+    {
+        if (!((my_lv >> p) & 1u))
+            continue; // (wavefront-uniform)
+        // the inverted diagonal tile goes in flight first, it is needed last
+        double ad[4];
+        TRSM_A_LOAD(ad, p, p)
+        v4f64 part[4];
+        part[0] = xs[p];
+        part[1] = part[2] = part[3] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        // products with the live tiles q < p, two steps of q per stage, the next stage's tiles in flight meanwhile
+        double a0[4], a1[4], n0[4], n1[4];
+        if (p > 0)
+        {
+            if ((my_lv >> 0) & 1u)
+                TRSM_A_LOAD(n0, 0, p)
+            if (p > 1 && ((my_lv >> 1) & 1u))
+                TRSM_A_LOAD(n1, 1, p)
+        }
+#pragma unroll
+        for (int q = 0; q < p; q += 2)
+        {
+#pragma unroll
+            for (int kq = 0; kq < 4; kq++)
+            {
+                a0[kq] = n0[kq];
+                a1[kq] = n1[kq];
+            }
+            if (q + 2 < p && ((my_lv >> (q + 2)) & 1u))
+                TRSM_A_LOAD(n0, q + 2, p)
+            if (q + 3 < p && ((my_lv >> (q + 3)) & 1u))
+                TRSM_A_LOAD(n1, q + 3, p)
+            if ((my_lv >> q) & 1u)
+            {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++)
+                    part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[kq], xs[q][kq], part[kq], 0, 0, 0);
+            }
+            if (q + 1 < p && ((my_lv >> (q + 1)) & 1u))
+            {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++)
+                    part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[kq], xs[q + 1][kq], part[kq], 0, 0, 0);
+            }
+        }
+        v4f64 acc = (part[0] + part[1]) + (part[2] + part[3]);
+        // multiply by the inverted diagonal tile (upper part: inv(U_pp); strictly lower part: inv(L_pp), unit diagonal)
+        v4f64 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++)
+        {
+            const int k = kq * 4 + l4; // TSTRF: A''[i = c'][k = c] = invU(c, c');  GESSM: A[i = r'][k = r] = invL(r', r)
+            double a;
+            if (tstrf)
+                a = (k <= l15) ? ad[kq] : 0.0;
+            else
+                a = (l15 > k) ? ad[kq] : ((l15 == k) ? 1.0 : 0.0);
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[kq], x, 0, 0, 0);
+        }
+        xs[p] = x;
+    }
+#undef TRSM_A_LOAD
+#undef TRSM_A_PTR
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+    {
+        if (!((my_lv >> p) & 1u))
+            continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            if (tstrf)
+                Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] = xs[p][g];
+            else
+                Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g] = xs[p][g];
+        }
+    }
+}
+
 // structural flops of the solves that ran on the dense path (src/pangulu_kernel_interface.c:84-159): one workgroup
 // per task.  T carries the CSC view of the solved block in vptr/vidx and the factor's pointer array in tptr.
 //   TSTRF: every entry (r, c) costs 1 division + 2 per entry of U's row c right of the diagonal

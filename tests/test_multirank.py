@@ -11,6 +11,7 @@ import sys
 import numpy as np
 import pytest
 import scipy.sparse as sp
+import torch.distributed  # noqa: F401  (pages the library in once, here, instead of in every rank under a timeout)
 
 from pangulu_amd import matrices as M
 
@@ -36,7 +37,7 @@ def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transpo
     outs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=180)
+            o, _ = p.communicate(timeout=420)  # (the first `import torch` on a fresh box can take minutes)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
