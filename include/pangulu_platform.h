@@ -250,6 +250,10 @@ extern "C"
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an
      * allocation and three small copies inside the factorisation).  `diag` may be either half. */
     void pangulu_platform_0201001_prepare_diag(pangulu_inblock_idx nb, pangulu_storage_slot_t *diag);
+    /* Once per owned off-diagonal block at preprocessing (host pattern arrays valid): the back-end summarises which
+     * 16 x 16 tiles of the symbolic pattern hold entries, so that its launches can leave out workgroups (128 x 128
+     * update tiles, 64-wide solve slabs) that would find nothing to do.  Optional; without it every workgroup is launched. */
+    void pangulu_platform_0201001_prepare_blocks(pangulu_inblock_idx nb, pangulu_uint64_t nslot, pangulu_storage_slot_t **slots);
     /* Optional: a waitable handle for "everything queued on the back-end so far" (a hipEvent_t on the back-end's
      * stream, owned by the back-end).  The native multi-rank scheduler uses it to announce finished blocks and to
      * recycle receive slots without draining the device after every batch. */

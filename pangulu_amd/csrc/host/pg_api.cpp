@@ -67,6 +67,7 @@ void bind_builtin_hip(Platform &p)
     p.sptrsv = pangulu_platform_0201001_sptrsv;
     p.set_option = pangulu_platform_0201001_set_option;
     p.prepare_diag = pangulu_platform_0201001_prepare_diag;
+    p.prepare_blocks = pangulu_platform_0201001_prepare_blocks;
     p.marker_record = pangulu_platform_0201001_marker_record;
     p.marker_done = pangulu_platform_0201001_marker_done;
     p.marker_wait = pangulu_platform_0201001_marker_wait;

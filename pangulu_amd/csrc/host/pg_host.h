@@ -68,6 +68,7 @@ struct Platform
     // extension of the HIP back-end (nullptr elsewhere)
     int (*set_option)(int, long long) = nullptr;
     void (*prepare_diag)(pangulu_inblock_idx, slot_t *) = nullptr;
+    void (*prepare_blocks)(pangulu_inblock_idx, pangulu_uint64_t, slot_t **) = nullptr;
     void *(*marker_record)() = nullptr;
     int (*marker_done)(void *) = nullptr;
     void (*marker_wait)(void *) = nullptr;

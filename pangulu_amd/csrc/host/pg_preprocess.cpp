@@ -723,6 +723,13 @@ void preprocess(Solver &S, const CscMatrix &A)
         if (plat.prepare_diag)
             for (u32 k : owned_diag)
                 plat.prepare_diag((pangulu_inblock_idx)nb, S.diag_lower[k]);
+        if (plat.prepare_blocks && st.n_owned_nondiag)
+        {
+            std::vector<slot_t *> offdiag(st.n_owned_nondiag);
+            for (size_t i = 0; i < st.n_owned_nondiag; i++)
+                offdiag[i] = &st.owned[i];
+            plat.prepare_blocks((pangulu_inblock_idx)nb, offdiag.size(), offdiag.data());
+        }
     }
     if (world()->size > 1)
         world()->register_arena(st.dchunks.data(), plat.host_memory ? 0 : st.dchunks.size(), st.dchunk_bytes, st.arena_bytes); // (collective)

@@ -43,7 +43,7 @@ __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PER_EU, DG_WAVES_PER_EU))) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
                                                                const SsssmTaskD *__restrict__ tasks, int nb,
                                                                unsigned long long *__restrict__ product_counter,
-                                                               unsigned long long *dbg)
+                                                               unsigned long long *dbg, const u32 *__restrict__ work)
 {
     // (debug stamps: every 64th workgroup adds its phase times; PANGULU_HIP_DEBUG_SSSSM)
     const bool stamping = dbg && threadIdx.x == 0 && (blockIdx.x & 63) == 0;
@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     __shared__ __align__(16) double sB[DG_K * DG_LD];
     const int tiles = nb / DG_TILE;
     const unsigned bid = logical_block_id((unsigned)(tiles * tiles)); // the tiles of one destination share operand halves: same XCD, same L2
-    const int g = bid / (tiles * tiles);
-    const int tile = bid % (tiles * tiles);
+    // (group, tile) of this workgroup: from the launch's work list (tiles no update of the group can reach are left out)
+    const u32 item = work[bid];
+    const int g = (int)(item >> 2);
+    const int tile = (int)(item & 3u);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (scalar: the skip tests below must be scalar branches)
     const int M0 = (tile % tiles) * DG_TILE, N0 = (tile / tiles) * DG_TILE; // workgroup tile origin

@@ -12,6 +12,14 @@ struct BlockState
     bool lu_image = false;       // diagonal block: the mirror holds L\\U with inverted diagonal tiles (pg_hip_trsm_dense.h)
     unsigned char image_halves = 0; // ... of which triangles: 1 = strictly lower (L), 2 = upper (U)
     u32 brow = 0, bcol = 0, nnz = 0;
+    // Host-side occupancy summary of an OWNED off-diagonal block's pattern (pangulu_platform_0201001_prepare_blocks, once
+    // per block at preprocessing; the pattern is symbolic and never changes; survives reset_block_states):
+    //   occ_a[t] bit s: column slab s (16 wide) has entries in the rows of 128-row half t   (the block as left operand)
+    //   occ_b[t] bit s: row slab s has entries in the columns of 128-column half t          (the block as right operand)
+    //   occ_rows bit r / occ_cols bit c: row slab r / column slab c has entries at all          (the block in a dense solve)
+    // The launch code uses it to leave out workgroups that would find nothing to do.
+    bool occ_valid = false;
+    unsigned short occ_a[2] = {0, 0}, occ_b[2] = {0, 0}, occ_rows = 0, occ_cols = 0;
 };
 
 // Open-addressing table block key -> BlockState.  Looked up three times per update task (destination and both operands)
@@ -128,6 +136,7 @@ BlockState &block_state(slot_t *s, int nb)
     if (st.brow != s->brow_pos || st.bcol != s->bcol_pos || st.nnz != nnz)
     {
         // first sight, or a receive slot that now holds another block: forget everything but the memory
+        // (the occupancy summary goes too: it described the previous block)
         double *keep = st.mirror;
         st = BlockState();
         st.mirror = keep;
@@ -351,7 +360,21 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify, bool
 
 void reset_block_states()
 {
-    MP.blocks.clear();
+    // everything about values and mirrors is forgotten; the identity of owned blocks and their occupancy summaries stay
+    MP.blocks.for_each([](BlockState &st)
+                       {
+                           BlockState fresh;
+                           fresh.brow = st.brow;
+                           fresh.bcol = st.bcol;
+                           fresh.nnz = st.nnz;
+                           fresh.occ_valid = st.occ_valid;
+                           fresh.occ_a[0] = st.occ_a[0];
+                           fresh.occ_a[1] = st.occ_a[1];
+                           fresh.occ_b[0] = st.occ_b[0];
+                           fresh.occ_b[1] = st.occ_b[1];
+                           fresh.occ_rows = st.occ_rows;
+                           fresh.occ_cols = st.occ_cols;
+                           st = fresh; });
     MP.cursor = 0;
     MP.to_densify.clear();
     MP.to_sparsify.clear();

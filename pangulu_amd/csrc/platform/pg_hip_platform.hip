@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <thread>
 #include <mutex>
 #include <unordered_map>
 #include <unordered_set>
@@ -157,6 +158,10 @@ struct SsssmGroupD
     // with a handful of updates (the diagonal block's update near the root of the tree, on the critical path of
     // every level) is cut four ways along K so that 16 CUs instead of 4 share a 256 x 256 x 256 product.
     u32 slab_mask;
+    // host side only: which of the destination's 128 x 128 tiles some update of this group can reach (bit = tile index);
+    // the launch leaves the others out (pangulu_platform_0201001_prepare_blocks)
+    u32 live_tiles;
+    u32 pad_;
 };
 
 struct TrsmTaskD
@@ -1405,7 +1410,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
     {
         Segment seg = acquire_segment();
         // worst case per task: one group + one task descriptor in each class; fill until the segment is full
-        size_t max_tasks = seg.cap / (sizeof(SsssmGroupD) + sizeof(SsssmTaskD) + 32) / 2;
+        size_t max_tasks = seg.cap / (sizeof(SsssmGroupD) + sizeof(SsssmTaskD) + 32 + 4 * sizeof(u32)) / 2;
         size_t take = std::min(n - i, max_tasks);
         SsssmTaskD *d_tasks_s, *d_tasks_d;
         SsssmGroupD *d_groups_s, *d_groups_d;
@@ -1415,7 +1420,11 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         const unsigned ksplit = (nb <= 256 && nb % 64 == 0 && take * (size_t)(tiles_per_dim * tiles_per_dim) <= 64) ? 4u : 1u;
         SsssmGroupD *groups_s = seg.alloc<SsssmGroupD>(take, &d_groups_s);
         SsssmGroupD *groups_d = seg.alloc<SsssmGroupD>(take * ksplit, &d_groups_d);
-        if (!tasks_s || !tasks_d || !groups_s || !groups_d)
+        static std::vector<unsigned short> live_k; // per dense task and tile: K-slabs in which both operands have entries
+        live_k.assign(take * 4, 0);
+        u32 *d_work;
+        u32 *work = seg.alloc<u32>(take * ksplit * 4, &d_work); // (group, tile) of every workgroup of the MFMA launch
+        if (!tasks_s || !tasks_d || !groups_s || !groups_d || !work)
         {
             fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
             exit(EXIT_FAILURE);
@@ -1500,6 +1509,14 @@ void launch_ssssm(int nb, task_t **list, size_t n)
 #endif
                 if (on_mfma)
                 {
+#if defined(CALCULATE_TYPE_R64)
+                    // tiles of the destination this update can reach (tile = tm + tiles * tn), per K-slab
+                    const BlockState *sa = MP.blocks.find(block_key(a)), *sb = MP.blocks.find(block_key(b));
+                    for (int tl = 0; tl < tiles_per_dim * tiles_per_dim; tl++)
+                        live_k[nd * 4 + tl] = (sa && sb && sa->occ_valid && sb->occ_valid)
+                                                  ? (unsigned short)(sa->occ_a[tl % tiles_per_dim] & sb->occ_b[tl / tiles_per_dim])
+                                                  : (unsigned short)0xFFFF;
+#endif
                     tasks_d[nd++] = T;
                     bytes_d += by;
                 }
@@ -1533,10 +1550,17 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 for (unsigned q = 0; q < ksplit; q++)
                 {
                     G.slab_mask = ksplit > 1 ? (((1u << per) - 1u) << (q * per)) : 0u;
+                    const unsigned kmask = G.slab_mask ? G.slab_mask : 0xFFFFu;
+                    G.live_tiles = 0;
+                    for (u32 t = G.task_begin; t < G.task_end; t++)
+                        for (int tl = 0; tl < tiles_per_dim * tiles_per_dim; tl++)
+                            if (live_k[(size_t)t * 4 + tl] & kmask)
+                                G.live_tiles |= 1u << tl;
                     groups_d[gd++] = G;
                 }
             }
             G.slab_mask = 0;
+            G.live_tiles = 0;
             i = j;
         }
 #if defined(CALCULATE_TYPE_R64)
@@ -1589,11 +1613,18 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 HIP_CHECK(hipStreamWaitEvent(ds, B.ev_fork, 0));
             }
             {
-                LaunchTimer lt(5, ds);
+                // one workgroup per (group, tile) some update of the group can reach
                 int tiles = nb / DG_TILE;
+                size_t nw = 0;
+                for (size_t gi = 0; gi < gd; gi++)
+                    for (int tl = 0; tl < tiles * tiles; tl++)
+                        if ((groups_d[gi].live_tiles >> tl) & 1u)
+                            work[nw++] = (u32)(gi << 2) | (u32)tl;
+                LaunchTimer lt(5, ds);
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
-                hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)(gd * tiles * tiles)), dim3(256), 0, ds, d_groups_d, d_tasks_d, nb,
-                                   B.opt_count_flops ? B.d_flops + 6 : nullptr, debug_ssssm ? B.d_flops + 8 : nullptr);
+                if (nw)
+                    hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(256), 0, ds, d_groups_d, d_tasks_d, nb,
+                                       B.opt_count_flops ? B.d_flops + 6 : nullptr, debug_ssssm ? B.d_flops + 8 : nullptr, d_work);
             }
             if (B.opt_count_flops)
                 hipLaunchKernelGGL(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, ds, d_tasks_d, nb, B.d_flops + 5);
@@ -1620,7 +1651,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
     while (i < n)
     {
         Segment seg = acquire_segment();
-        size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64 + 80)); // (+80: a remote-diagonal image job per task at worst)
+        size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64 + 80 + 4 * sizeof(u32))); // (+80: a remote-diagonal image job per task at worst)
         TrsmTaskD *d_tasks, *d_ftasks;
         TrsmTaskD *tasks = seg.alloc<TrsmTaskD>(take, &d_tasks);
         TrsmTaskD *ftasks = seg.alloc<TrsmTaskD>(take, &d_ftasks); // sparse views of the dense-path tasks (flop counting)
@@ -1629,6 +1660,10 @@ void launch_trsm(int nb, task_t **list, size_t n)
 #if defined(CALCULATE_TYPE_R64)
         TrsmDenseTaskD *d_dtasks;
         TrsmDenseTaskD *dtasks = seg.alloc<TrsmDenseTaskD>(take, &d_dtasks);
+        u32 *d_dwork;
+        u32 *dwork = seg.alloc<u32>(take * 4, &d_dwork); // (task, 64-wide slab) of every workgroup of the dense-solve launch
+        static std::vector<unsigned short> dlive;        // per dense task: which 16-wide strips of the block hold entries
+        dlive.assign(take, 0);
         std::vector<slot_t *> solved_dense;
         const bool dense_ok = dense_mode_available(nb);
 #endif
@@ -1696,6 +1731,11 @@ void launch_trsm(int nb, task_t **list, size_t n)
                         D.lu = lu;
                         D.is_tstrf = T.is_tstrf;
                         D.pad_ = 0;
+                        {
+                            // strips of the solve = row slabs (TSTRF) / column slabs (GESSM) of the block
+                            const BlockState *sd = MP.blocks.find(block_key(dst));
+                            dlive[ndense] = (sd && sd->occ_valid) ? (T.is_tstrf ? sd->occ_rows : sd->occ_cols) : (unsigned short)0xFFFF;
+                        }
                         dtasks[ndense] = D;
                         // the flop counter wants the CSC view of the block in both cases
                         T.vptr = dst->d_columnpointer;
@@ -1772,14 +1812,22 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 // barrier-free kernel by default (PANGULU_HIP_TRSM_DIRECT=0: the LDS-staged one)
                 static const bool direct = getenv("PANGULU_HIP_TRSM_DIRECT") ? atoi(getenv("PANGULU_HIP_TRSM_DIRECT")) != 0 : true;
                 unsigned long long *dbg = debug_trsm ? B.d_flops + 8 : nullptr;
-                if (direct && nb == 256)
-                    hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks);
+                // one workgroup per (task, 64-wide slab) that holds pattern entries
+                size_t nw = 0;
+                for (size_t t = 0; t < ndense; t++)
+                    for (int w = 0; w < nb / 64; w++)
+                        if ((dlive[t] >> (4 * w)) & 0xFu)
+                            dwork[nw++] = (u32)(t << 2) | (u32)w;
+                if (!nw)
+                    ;
+                else if (direct && nb == 256)
+                    hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<16>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, d_dwork);
                 else if (direct)
-                    hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks);
+                    hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<8>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, d_dwork);
                 else if (nb == 256)
-                    hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks, dbg);
+                    hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, dbg, d_dwork);
                 else
-                    hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)(ndense * (nb / 64))), dim3(256), 0, ds, d_dtasks, dbg);
+                    hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, dbg, d_dwork);
                 if (ds != B.stream)
                 {
                     HIP_CHECK(hipEventRecord(B.ev_join, ds));
@@ -2344,6 +2392,74 @@ extern "C"
         slot_t *up, *lo;
         diag_halves(diag, &up, &lo);
         (void)get_diag_aux(up, nb);
+    }
+
+    void pangulu_platform_0201001_prepare_blocks(pangulu_inblock_idx nb, pangulu_uint64_t nslot, pangulu_storage_slot_t **slots)
+    {
+#if defined(CALCULATE_TYPE_R64)
+        if (nb > 256 || nb % 16 != 0 || nslot == 0)
+            return;
+        static const bool enabled = !(getenv("PANGULU_HIP_OCCUPANCY_SUMMARIES") && atoi(getenv("PANGULU_HIP_OCCUPANCY_SUMMARIES")) == 0);
+        if (!enabled)
+            return;
+        ensure_ready();
+        std::lock_guard<std::mutex> g(B.mutex);
+        struct Occ
+        {
+            unsigned short a[2], b[2], rows, cols;
+        };
+        std::vector<Occ> occ((size_t)nslot);
+        // the patterns are walked by a few threads (half a billion entries for the bench matrix), the table is filled by one
+        const unsigned nthr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthr; t++)
+            pool.emplace_back([&, t]()
+                              {
+                                  for (size_t i = t; i < (size_t)nslot; i += nthr)
+                                  {
+                                      const slot_t *s = slots[i];
+                                      unsigned short m[16] = {0};
+                                      const u32 *cp = s->columnpointer;
+                                      const u16 *ri = s->rowindex;
+                                      for (int c = 0; c < (int)nb; c++)
+                                      {
+                                          unsigned short bits = 0;
+                                          for (u32 p = c == 0 ? 0u : cp[c]; p < cp[c + 1]; p++)
+                                              bits |= (unsigned short)(1u << (ri[p] >> 4));
+                                          m[c >> 4] |= bits;
+                                      }
+                                      Occ o = {{0, 0}, {0, 0}, 0, 0};
+                                      for (int sl = 0; sl < (int)nb / 16; sl++)
+                                      {
+                                          if (m[sl] & 0x00FF)
+                                              o.a[0] |= (unsigned short)(1u << sl);
+                                          if (m[sl] & 0xFF00)
+                                              o.a[1] |= (unsigned short)(1u << sl);
+                                          o.b[sl >> 3] |= m[sl];
+                                          o.rows |= m[sl];
+                                          if (m[sl])
+                                              o.cols |= (unsigned short)(1u << sl);
+                                      }
+                                      occ[i] = o;
+                                  } });
+        for (auto &th : pool)
+            th.join();
+        for (size_t i = 0; i < (size_t)nslot; i++)
+        {
+            BlockState &st = block_state(slots[i], (int)nb);
+            st.occ_valid = true;
+            st.occ_a[0] = occ[i].a[0];
+            st.occ_a[1] = occ[i].a[1];
+            st.occ_b[0] = occ[i].b[0];
+            st.occ_b[1] = occ[i].b[1];
+            st.occ_rows = occ[i].rows;
+            st.occ_cols = occ[i].cols;
+        }
+#else
+        (void)nb;
+        (void)nslot;
+        (void)slots;
+#endif
     }
 
     int pangulu_platform_0201001_set_option(int option, long long value)

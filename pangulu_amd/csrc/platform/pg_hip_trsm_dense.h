@@ -132,7 +132,7 @@ __global__ __launch_bounds__(1024) void half_image_kernel(const HalfImageJobD *_
 // current one is consumed), laid out so that the MFMA A-operand reads are conflict-free:
 //     TSTRF  sT[c * 258 + row]   (c = column within the panel)     GESSM  sT[k * 16 + r]   (r = row within the panel)
 template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks, unsigned long long *dbg)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks, unsigned long long *dbg, const u32 *__restrict__ work)
 {
     unsigned long long stamp_ = dbg ? __builtin_amdgcn_s_memtime() : 0;
 #define TRSM_STAMP(slot)                                                   \
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
     constexpr int LDT = nb + 2;
     __shared__ __align__(16) double sT[16 * LDT];
     const int slabs = nb / 64;
-    const unsigned bid = logical_block_id((unsigned)slabs); // the strips of one solve read the same factor image: same XCD
+    // (task, slab) from the launch's work list: slabs without pattern entries are left out
+    const u32 item = work[logical_block_id((unsigned)slabs)]; // neighbours in the list read the same factor image: same XCD
+    const unsigned bid = (item >> 2) * (unsigned)slabs + (item & 3u);
     const TrsmDenseTaskD T = tasks[bid / slabs];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int o0 = (bid % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
@@ -334,11 +336,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
 //   GESSM  A [i = r][k] = L(16p + r, 16q + k)  = LU[(16q + k) nb + 16p + r]
 // -----------------------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_direct_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_direct_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks, const u32 *__restrict__ work)
 {
     constexpr int nb = NP * 16;
     const int slabs = nb / 64;
-    const unsigned bid = logical_block_id((unsigned)slabs);
+    // (task, slab) from the launch's work list: slabs without pattern entries are left out
+    const u32 item = work[logical_block_id((unsigned)slabs)];
+    const unsigned bid = (item >> 2) * (unsigned)slabs + (item & 3u);
     const TrsmDenseTaskD T = tasks[bid / slabs];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int o0 = (bid % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
