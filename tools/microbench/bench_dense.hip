@@ -9,7 +9,7 @@ typedef unsigned int u32;
 typedef unsigned short u16;
 struct BlkView { const u32 *ptr; const u16 *idx; val_t *val; };
 struct SsssmTaskD { BlkView a, b; };
-struct SsssmGroupD { BlkView c; const u32 *ucp; const u16 *uri; const u32 *uvi; val_t *uval; val_t *cdense; u32 task_begin, task_end; u32 atomic; u32 pad_; };
+struct SsssmGroupD { BlkView c; const u32 *ucp; const u16 *uri; const u32 *uvi; val_t *uval; val_t *cdense; u32 task_begin, task_end; u32 atomic; u32 slab_mask; u32 live_tiles; u32 pad_; }; // = pg_hip_platform.hip
 __device__ inline u32 ptr0(const u32 *p, int i) { return i == 0 ? 0u : p[i]; }
 __device__ inline unsigned long long wave_sum(unsigned long long v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; }
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -28,7 +28,7 @@ __device__ inline unsigned logical_block_id(unsigned per_unit)
 int main(int argc, char **argv)
 {
     int nb = 256, ngroups = argc > 1 ? atoi(argv[1]) : 1024, tpg = argc > 2 ? atoi(argv[2]) : 8, nmir = 4096, atomic = argc > 3 ? atoi(argv[3]) : 0, livebits = argc > 4 ? atoi(argv[4]) : 16, ndst = argc > 5 ? atoi(argv[5]) : 1024, nops = argc > 6 ? atoi(argv[6]) : 1500;
-    size_t mb = (size_t)nb * nb + 8; // values + occupancy map
+    size_t mb = (size_t)nb * nb + 8 + 16 * (size_t)nb; // values + occupancy map + saved diagonal tiles (pg_hip_dense_host.h)
     double *pool;
     CK(hipMalloc(&pool, sizeof(double) * mb * nmir));
     std::vector<double> h(mb * 64);
@@ -59,10 +59,13 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dT, T.data(), sizeof(SsssmTaskD) * T.size(), hipMemcpyHostToDevice));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     int tiles = nb / DG_TILE;
+    std::vector<u32> W((size_t)ngroups * tiles * tiles); // work list: every (group, tile)
+    for (size_t i = 0; i < W.size(); i++) W[i] = (u32)((i / (tiles * tiles)) << 2) | (u32)(i % (tiles * tiles));
+    u32 *dW; CK(hipMalloc(&dW, sizeof(u32) * W.size())); CK(hipMemcpy(dW, W.data(), sizeof(u32) * W.size(), hipMemcpyHostToDevice));
     for (int rep = 0; rep < 3; rep++)
     {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3(ngroups * tiles * tiles), dim3(256), 0, 0, dG, dT, nb, nullptr);
+        hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3(ngroups * tiles * tiles), dim3(256), 0, 0, dG, dT, nb, nullptr, nullptr, dW);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         double flop = 2.0 * nb * nb * nb * (double)ngroups * tpg;
