@@ -235,7 +235,7 @@ def main():
             # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process, so the value
             # is the one the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes measured for this exact workload
             # (profiles/r01x_final_shell398.md; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
-            rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_blocked_f64_kernel",
+            rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_lookahead_f64_kernel",
                             "tstrf": "void trsm_dense_direct_f64_kernel<16>", "gessm": "void trsm_dense_direct_f64_kernel<16>",
                             "ssssm_sparse": "void ssssm_sparse_kernel<false>"}.get(dom)
             traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01x_hbm_traffic_shell398.json")

@@ -2382,7 +2382,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 // (measured: 64.2 ms per factorisation of the bench matrix with the 512-thread variant from 129 blocks against 64.6 ms
                 // without -- both kernels slow down when they share CUs; off by default)
                 static const long narrow_from = getenv("PANGULU_HIP_GETRF_NARROW_FROM") ? atol(getenv("PANGULU_HIP_GETRF_NARROW_FROM")) : 1 << 30;
-                static const bool lookahead_kernel = getenv("PANGULU_HIP_GETRF_LOOKAHEAD") && atoi(getenv("PANGULU_HIP_GETRF_LOOKAHEAD")) != 0;
+                static const bool lookahead_kernel = !(getenv("PANGULU_HIP_GETRF_LOOKAHEAD") && atoi(getenv("PANGULU_HIP_GETRF_LOOKAHEAD")) == 0);
                 if (lookahead_kernel)
                 {
                     const size_t lds_la = sizeof(double) * (4 * GETRF_PANEL * (size_t)(nb + 2) + GETRF_PANEL * GETRF_PANEL) + sizeof(u32) * (2 * (size_t)(nb + 1) + 4);
