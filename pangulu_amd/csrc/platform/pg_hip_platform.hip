@@ -1042,40 +1042,74 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     };
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // ---- panel j0 into image `buf`: thread t < nb - j0 owns row j0 + t of the 16 panel columns in registers; per pivot
-    // the owner of the pivot row publishes it through LDS (one barrier: `sync`), every row below scales its own L entry
-    // and updates its own 15 registers
+    // ---- panel j0 into image `buf`: thread t < nb - j0 owns row j0 + t of the 16 panel columns in registers.  The 16 pivot
+    // rows are rows of wavefront 0: it eliminates its 64 rows on its own, pivot row by pivot row, broadcasting each from its
+    // lane with v_readlane (no LDS, no barrier) and publishing it for the others; after ONE barrier (`sync`) the other row
+    // wavefronts run the same 16 steps on their rows from the published rows.  Same operations in the same order per
+    // row as a barrier per pivot, a sixteenth of the barriers -- which matters here, where a barrier is an LDS counter.
     auto panel = [&](int j0, int buf, auto sync)
     {
         double *P = Pb + (size_t)buf * GETRF_PANEL * ldp;
         const int myrow = j0 + tid;
         const bool row_thread = tid < GETRF_BLOCKED_ROWS && myrow < nb;
         double x[GETRF_PANEL];
-        if (row_thread)
+#pragma unroll
+        for (int c = 0; c < GETRF_PANEL; c++)
+            x[c] = row_thread ? D[(size_t)(j0 + c) * nb + myrow] : 0.0;
+        if (wave == 0)
         {
 #pragma unroll
-            for (int c = 0; c < GETRF_PANEL; c++)
-                x[c] = D[(size_t)(j0 + c) * nb + myrow];
-        }
-#pragma unroll
-        for (int kk = 0; kk < GETRF_PANEL; kk++)
-        {
-            if (tid == kk)
+            for (int kk = 0; kk < GETRF_PANEL; kk++)
             {
+                double u[GETRF_PANEL]; // pivot row kk (wavefront-uniform)
 #pragma unroll
                 for (int c = 0; c < GETRF_PANEL; c++)
-                    Rb[kk * GETRF_PANEL + c] = x[c];
+                    if (c >= kk)
+                    {
+                        union
+                        {
+                            double d;
+                            int w[2];
+                        } v;
+                        v.d = x[c];
+                        v.w[0] = __builtin_amdgcn_readlane(v.w[0], kk);
+                        v.w[1] = __builtin_amdgcn_readlane(v.w[1], kk);
+                        u[c] = v.d;
+                    }
+                if (lane == kk)
+                {
+#pragma unroll
+                    for (int c = 0; c < GETRF_PANEL; c++)
+                        Rb[kk * GETRF_PANEL + c] = x[c];
+                }
+                const int k = j0 + kk;
+                if (sLcp[k] != sLcp[k + 1] && row_thread && myrow > k && x[kk] != 0.0)
+                {
+                    const double l = x[kk] / clamp_pivot(u[kk]);
+                    x[kk] = l;
+#pragma unroll
+                    for (int c = 0; c < GETRF_PANEL; c++)
+                        if (c > kk)
+                            x[c] = x[c] - l * u[c];
+                }
             }
-            sync();
-            const int k = j0 + kk;
-            if (sLcp[k] != sLcp[k + 1] && row_thread && myrow > k && x[kk] != 0.0)
-            {
-                const double l = x[kk] / clamp_pivot(Rb[kk * GETRF_PANEL + kk]);
-                x[kk] = l;
+        }
+        sync();
+        if (wave != 0 && row_thread)
+        {
 #pragma unroll
-                for (int c = 0; c < GETRF_PANEL; c++)
-                    if (c > kk)
-                        x[c] = x[c] - l * Rb[kk * GETRF_PANEL + c];
+            for (int kk = 0; kk < GETRF_PANEL; kk++)
+            {
+                const int k = j0 + kk;
+                if (sLcp[k] != sLcp[k + 1] && x[kk] != 0.0) // (myrow > k: these rows are at least 64 below the panel's first)
+                {
+                    const double l = x[kk] / clamp_pivot(Rb[kk * GETRF_PANEL + kk]);
+                    x[kk] = l;
+#pragma unroll
+                    for (int c = 0; c < GETRF_PANEL; c++)
+                        if (c > kk)
+                            x[c] = x[c] - l * Rb[kk * GETRF_PANEL + c];
+                }
             }
         }
         if (row_thread)
