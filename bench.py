@@ -234,16 +234,16 @@ def main():
                             "frac": ach / HBM_PEAK_GBS, "traffic": None}
             # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process, so the value
             # is the one the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes measured for this exact workload
-            # (profiles/r01x_final_shell398.md; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+            # (profiles/r01y_final_shell398.md; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
             rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_lookahead_f64_kernel",
                             "tstrf": "void trsm_dense_direct_f64_kernel<16>", "gessm": "void trsm_dense_direct_f64_kernel<16>",
                             "ssssm_sparse": "void ssssm_sparse_kernel<false>"}.get(dom)
-            traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01x_hbm_traffic_shell398.json")
+            traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01y_hbm_traffic_shell398.json")
             if world == 1 and default_workload and rocprof_name and os.path.exists(traffic_file):
                 t = json.load(open(traffic_file)).get(rocprof_name)
                 if t:
                     roofline["traffic"] = t["hbm_bytes_per_launch"]
-                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass, profiles/r01x_final_shell398.md)"
+                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass, profiles/r01y_final_shell398.md)"
             roofline["avg_launch_us"] = kernels[dom]["avg_launch_us"]
             roofline["share_of_kernel_time"] = kernels[dom]["ms"] / sum(k["ms"] for k in kernels.values())
 
