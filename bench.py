@@ -150,6 +150,8 @@ def main():
     if world > 1:
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         base_port = int(os.environ.get("MASTER_PORT", "29500")) + 23
+        if base_port + world >= 32768:  # keep the solver's listeners (base_port + rank) out of the ephemeral port range
+            base_port = 20000 + (base_port * 7) % 8000
         transport = {"host": _lib.TRANSPORT_HOST, "rccl": _lib.TRANSPORT_RCCL, "ipc": _lib.TRANSPORT_IPC}[args.transport]
         rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port, transport, None)
         assert rc == 0

@@ -109,7 +109,30 @@ struct SocketComm : Comm
         if (::bind(ls, (sockaddr *)&sa, sizeof(sa)) != 0)
             fatal("rank %d: bind to %s:%d failed: %s", rank, addr, base_port + rank, strerror(errno));
         ::listen(ls, size);
-        // connect to every lower rank, accept from every higher rank
+        // connect to every lower rank, accept from every higher rank.  Both sides check a magic word: base_port + rank may
+        // lie in the ephemeral range, where some other socket of the job (the launcher's rendezvous, gloo pairs) can hold
+        // the number -- a connection that reached the wrong listener is dropped and retried instead of waited on forever.
+        const unsigned magic = 0x50474c55u; // "PGLU"
+        auto set_timeout = [](int s, int seconds)
+        {
+            timeval tv;
+            tv.tv_sec = seconds;
+            tv.tv_usec = 0;
+            setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+        };
+        auto read_some = [](int s, void *buf, size_t n) -> bool
+        {
+            char *p = (char *)buf;
+            while (n)
+            {
+                ssize_t r = ::recv(s, p, n, 0);
+                if (r <= 0)
+                    return false;
+                p += r;
+                n -= (size_t)r;
+            }
+            return true;
+        };
         for (int peer = 0; peer < rank; peer++)
         {
             int s = -1;
@@ -119,26 +142,45 @@ struct SocketComm : Comm
                 sockaddr_in pa = sa;
                 pa.sin_port = htons((uint16_t)(base_port + peer));
                 if (::connect(s, (sockaddr *)&pa, sizeof(pa)) == 0)
-                    break;
+                {
+                    unsigned hello[2] = {magic, (unsigned)rank}, ack = 0;
+                    set_timeout(s, 3);
+                    if (::send(s, hello, sizeof(hello), MSG_NOSIGNAL) == (ssize_t)sizeof(hello) && read_some(s, &ack, sizeof(ack)) && ack == (magic ^ (unsigned)peer))
+                    {
+                        set_timeout(s, 0);
+                        break;
+                    }
+                }
                 ::close(s);
                 if (attempt > 6000)
                     fatal("rank %d: cannot reach rank %d at %s:%d", rank, peer, addr, base_port + peer);
                 usleep(10000);
             }
             setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-            int me = rank;
-            write_all(s, &me, sizeof(me));
             fd[(size_t)peer] = s;
         }
-        for (int k = rank + 1; k < size; k++)
+        for (int got = 0; got < size - rank - 1;)
         {
             int s = ::accept(ls, nullptr, nullptr);
             if (s < 0)
                 fatal("accept failed: %s", strerror(errno));
+            unsigned hello[2] = {0, 0};
+            set_timeout(s, 3);
+            if (!read_some(s, hello, sizeof(hello)) || hello[0] != magic || hello[1] >= (unsigned)size || (int)hello[1] <= rank || fd[hello[1]] >= 0)
+            {
+                ::close(s); // not one of ours
+                continue;
+            }
+            const unsigned ack = magic ^ (unsigned)rank;
+            if (::send(s, &ack, sizeof(ack), MSG_NOSIGNAL) != (ssize_t)sizeof(ack))
+            {
+                ::close(s);
+                continue;
+            }
+            set_timeout(s, 0);
             setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-            int who = -1;
-            read_all(s, &who, sizeof(who));
-            fd[(size_t)who] = s;
+            fd[hello[1]] = s;
+            got++;
         }
         ::close(ls);
         sender = std::thread([this]()

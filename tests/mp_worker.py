@@ -30,7 +30,9 @@ def main():
         assert lib.pangulu_amd_use_platform_library(oracle_library(vtype).encode(), _lib.PLATFORM_CPU_NAIVE) == 0
     else:
         lib.pangulu_amd_use_builtin_platform()  # every rank on the one GPU of the test box (LOCAL_RANK % device count)
-    base_port = int(os.environ["MASTER_PORT"]) + 40
+    # the solver's own listeners (base_port + rank): a block below the ephemeral range, where the rendezvous port and
+    # gloo's pair sockets live (a number taken by one of those would be dialled by mistake)
+    base_port = 20000 + (int(os.environ["MASTER_PORT"]) * 7) % 8000
     transport = {"host": _lib.TRANSPORT_HOST, "ipc": _lib.TRANSPORT_IPC, "rccl": _lib.TRANSPORT_RCCL}[os.environ.get("PANGULU_TEST_TRANSPORT", "host")]
     assert lib.pangulu_amd_comm_init(rank, world, b"127.0.0.1", base_port, transport, None) == 0
     dtype = _lib.VALUE_TYPES[vtype][0]

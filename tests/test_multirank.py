@@ -37,7 +37,7 @@ def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transpo
     outs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=420)  # (the first `import torch` on a fresh box can take minutes)
+            o, _ = p.communicate(timeout=int(os.environ.get("PANGULU_TEST_RANK_TIMEOUT", "420")))  # (the first `import torch` on a fresh box can take minutes)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
