@@ -39,14 +39,26 @@ def main():
     gen = {"fem27_6": lambda: M.fem27(6, dtype=dtype), "poisson8": lambda: M.poisson3d(8, dtype=dtype),
            "shell_8x7": lambda: M.shell(8, 7, dtype=dtype), "trefethen": lambda: M.trefethen(dtype=dtype),
            "random200": lambda: M.random_pattern(200, 0.03, 5, dtype=dtype), "fem27_9": lambda: M.fem27(9, dtype=dtype),
-           "shell_20x16": lambda: M.shell(20, 16, dtype=dtype)}[spec]
+           "shell_20x16": lambda: M.shell(20, 16, dtype=dtype),
+           "poisson12c": lambda: M.poisson3d(12, dtype=dtype, shift=0.5j if np.issubdtype(dtype, np.complexfloating) else 0.0),
+           "kkt6": lambda: M.kkt(6, dtype=dtype), "shell_40x40": lambda: M.shell(40, 40, dtype=dtype)}[spec]
     n, cp, ri, va, co = gen()
     ordering = "identity" if spec == "trefethen" else "nd"
     if rank == 0:
         h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=co if ordering == "nd" else None)
     else:
         h = pa.pangulu_init(0, 0, None, None, None, nb=nb, vtype=vtype, ordering=ordering)  # rank 0 broadcasts the matrix
+    repeat = os.environ.get("PANGULU_TEST_REPEAT") == "1"
+    if repeat:  # bench.py's sequence: snapshot, gstrf, reset_numeric, gstrf again
+        assert lib.pangulu_amd_snapshot(h.ref) == 0
     pa.pangulu_gstrf(h)
+    if repeat:
+        L1, U1 = pa.factors_as_scipy(h)
+        assert lib.pangulu_amd_reset_numeric(h.ref) == 0
+        pa.pangulu_gstrf(h)
+        L2, U2 = pa.factors_as_scipy(h)
+        scale = max(abs(L1).max(), abs(U1).max())
+        assert abs(L1 - L2).max() <= 1e-12 * scale and abs(U1 - U2).max() <= 1e-12 * scale, "second factorisation differs"
     info = h.info()
     L, U = pa.factors_as_scipy(h)  # this rank's blocks only
     b = M.rhs_of_ones(n, cp, ri, va) if rank == 0 else None

@@ -26,12 +26,13 @@ def free_port():
     return p
 
 
-def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transport="host"):
+def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transport="host", repeat=False):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", PANGULU_TEST_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", PANGULU_TEST_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   PANGULU_TEST_REPEAT="1" if repeat else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), spec, str(nb), out_path, vtype, platform],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -49,7 +50,7 @@ def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transpo
 
 GENS = {"fem27_6": lambda: M.fem27(6), "poisson8": lambda: M.poisson3d(8), "shell_8x7": lambda: M.shell(8, 7),
         "trefethen": lambda: M.trefethen(), "random200": lambda: M.random_pattern(200, 0.03, 5), "fem27_9": lambda: M.fem27(9),
-        "shell_20x16": lambda: M.shell(20, 16)}
+        "shell_20x16": lambda: M.shell(20, 16), "kkt6": lambda: M.kkt(6), "shell_40x40": lambda: M.shell(40, 40)}
 
 
 @pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (2, "trefethen", 4), (4, "poisson8", 32), (4, "trefethen", 4),
@@ -125,4 +126,50 @@ def test_ipc_transport_falls_back_on_a_host_memory_platform(tmp_path):
     run_ranks(2, "fem27_6", 32, out, transport="ipc")
     z = np.load(out)
     assert int(z["transport"]) == _lib.TRANSPORT_HOST
+    assert float(z["residual"]) < 1e-13
+
+
+@pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (4, "shell_20x16", 24), (2, "kkt6", 16)])
+def test_multirank_snapshot_reset_and_second_factorisation(tmp_path, world, spec, nb):
+    """bench.py's multi-rank sequence (snapshot, gstrf, reset_numeric, gstrf) gives the same factors twice."""
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, repeat=True)
+    z = np.load(out)
+    ref = factorize(GENS[spec](), nb, oracle_library("r64"), ordering="nd")
+    n = len(z["L_ptr"]) - 1
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
+    assert float(z["residual"]) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,spec,nb,transport", [(2, "fem27_9", 128, "ipc"), (4, "shell_40x40", 256, "ipc"), (2, "kkt6", 64, "host")])
+def test_multirank_on_the_gpu_snapshot_reset_and_second_factorisation(tmp_path, world, spec, nb, transport):
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, platform="hip", transport=transport, repeat=True)
+    z = np.load(out)
+    ref = factorize(GENS[spec](), nb, oracle_library("r64"), ordering="nd")
+    n = len(z["L_ptr"]) - 1
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
+    assert float(z["residual"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_multirank_cr64_on_the_gpu_peer_copies(tmp_path):
+    """BASELINE config 5 class (complex Poisson, CR64) on 2 ranks with the one-node transport."""
+    from pangulu_amd import _lib
+
+    out = str(tmp_path / "out.npz")
+    run_ranks(2, "poisson12c", 128, out, vtype="cr64", platform="hip", transport="ipc")
+    z = np.load(out)
+    assert int(z["transport"]) == _lib.TRANSPORT_IPC
+    mat = M.poisson3d(12, dtype=np.complex128, shift=0.5j)
+    ref = factorize(mat, 128, oracle_library("cr64"), vtype="cr64", ordering="nd")
+    n = len(z["L_ptr"]) - 1
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
     assert float(z["residual"]) < 1e-13
