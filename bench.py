@@ -99,7 +99,7 @@ def find_openblas():
 def cpu_baseline(args, pa, M, lib):
     """Oracle (CPU restatement of the reference's CPU platform) timed on one host core on a bounded sample of the
     same workload class.  Reported beside the GPU number; not a target."""
-    from tests.helpers import oracle_library, select_platform
+    from tests.helpers import library_for, oracle_library
 
     blas = find_openblas()
     if blas:
@@ -107,14 +107,13 @@ def cpu_baseline(args, pa, M, lib):
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
     nx, ny = args.cpu_sample
     n, cp, ri, va, co = M.shell(nx, ny)
-    select_platform(lib, oracle_library("r64"))
-    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=args.nb, ordering=args.ordering, coords=co, nthread=max(1, os.cpu_count() or 1))
+    tlib = library_for(oracle_library("r64"))  # the checker's build of the host, routed to the CPU restatement
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=args.nb, ordering=args.ordering, coords=co, nthread=max(1, os.cpu_count() or 1), lib=tlib)
     t0 = time.time()
     pa.pangulu_gstrf(h)
     dt = time.time() - t0
     info = h.info()
     pa.pangulu_finalize(h)
-    select_platform(lib, "hip")
     return {
         "value": info["flop"] / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
         "sample": "shell(%d,%d) n=%d F=%.3e nb=%d, 1 rank x 1 compute thread, SSSSM GEMM: %s, %.1f s" % (

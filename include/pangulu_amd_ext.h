@@ -36,12 +36,10 @@ extern "C"
     int pangulu_amd_comm_size(void);
 
     /* ---- back-end selection ------------------------------------------------------------------------- */
-    /* The product always runs on the built-in HIP platform (PANGULU_PLATFORM_GPU_HIP) and aborts when no
-     * device is present.  TEST HOOK: route the 21 platform operators to another shared object exporting
-     * pangulu_platform_<7-digit id>_<name> (the tests pass oracle/_build/libpangulu_oracle_*.so with id
-     * 0x0100000 to run the scheduler on the CPU restatement).  Returns 0 on success. */
-    int pangulu_amd_use_platform_library(const char *so_path, unsigned int platform_id);
-    /* back to the built-in HIP platform (tests compare both in one process) */
+    /* The product always runs on the built-in HIP platform (PANGULU_PLATFORM_GPU_HIP), bound statically, and aborts
+     * when no device is present; this library has no platform loader.  (The checker's test build,
+     * oracle/_build/libpangulu_amd_test_*.so, adds one: oracle/pangulu_amd_test_hooks.h.) */
+    /* (re)binds the built-in HIP platform; a no-op in this library, kept for callers written against the test build */
     void pangulu_amd_use_builtin_platform(void);
     unsigned int pangulu_amd_active_platform(void);
 
@@ -53,7 +51,8 @@ extern "C"
     /* perm[new] = old, length n; copied */
     void pangulu_amd_set_user_perm(const sparse_index_t *perm, sparse_index_t n);
     /* optional vertex coordinates (dim = 2 or 3, n*dim doubles, vertex-major) turn ORDER_ND into a geometric
-     * dissection; copied; cleared after the next pangulu_init */
+     * dissection; copied.  All analysis options are one-shot: the next pangulu_init consumes them and the defaults
+     * (ORDER_ND, no permutation, no coordinates, device-resident numeric phase) apply again afterwards */
     void pangulu_amd_set_coordinates(const double *xyz, sparse_index_t n, int dim);
     /* 0 (default): device-resident numeric phase, factors downloaded once when gstrs / block export needs
      * them.  1: reference behaviour, every finished panel block is copied back to the host at once. */

@@ -1,0 +1,21 @@
+/*
+ * TEST INFRASTRUCTURE, NOT PRODUCT API.
+ *
+ * oracle/_build/libpangulu_amd_test_<type>.so is the native host (scheduler, preprocessing, transports) compiled from the
+ * same sources as the product with -DPANGULU_AMD_TEST_HOOKS, which adds exactly one entry point: a loader that routes
+ * the 21 platform operators to another shared object.  tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * use it to run the scheduler on the CPU restatement of the reference's CPU platform (libpangulu_oracle_*.so, id
+ * 0x0100000).  The shipped libpangulu_amd_<type>.so does not export it.
+ */
+#ifndef PANGULU_AMD_TEST_HOOKS_H
+#define PANGULU_AMD_TEST_HOOKS_H
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+    /* so_path must export pangulu_platform_<7-digit id>_<name> for the 21 names of build_helper.py:8-32.  0 on success. */
+    int pangulu_amd_use_platform_library(const char *so_path, unsigned int platform_id);
+#ifdef __cplusplus
+}
+#endif
+#endif

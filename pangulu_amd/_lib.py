@@ -104,12 +104,21 @@ def library_path(vtype="r64"):
     return os.path.join(LIB_DIR, "libpangulu_amd_%s.so" % vtype)
 
 
-def load(vtype="r64"):
-    """Load (once) the shared object for a value type and declare the signatures used from Python."""
+def test_library_path(vtype="r64"):
+    """The checker's build of the host (oracle/pangulu_amd_test_hooks.h): same sources + a platform loader.
+    Test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it."""
+    return os.path.join(REPO_ROOT, "oracle", "_build", "libpangulu_amd_test_%s.so" % vtype)
+
+
+def load(vtype="r64", test_hooks=False):
+    """Load (once) the shared object for a value type and declare the signatures used from Python.
+
+    test_hooks=True loads the checker's variant instead (it can run the scheduler on the oracle's CPU operators)."""
     vtype = vtype.lower()
-    if vtype in _cache:
-        return _cache[vtype]
-    path = library_path(vtype)
+    key = (vtype, bool(test_hooks))
+    if key in _cache:
+        return _cache[key]
+    path = test_library_path(vtype) if test_hooks else library_path(vtype)
     if not os.path.exists(path):
         raise RuntimeError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -137,8 +146,9 @@ def load(vtype="r64"):
     lib.pangulu_amd_comm_transport.restype = ctypes.c_int
     lib.pangulu_amd_comm_rank.restype = ctypes.c_int
     lib.pangulu_amd_comm_size.restype = ctypes.c_int
-    lib.pangulu_amd_use_platform_library.argtypes = [ctypes.c_char_p, ctypes.c_uint]
-    lib.pangulu_amd_use_platform_library.restype = ctypes.c_int
+    if test_hooks:
+        lib.pangulu_amd_use_platform_library.argtypes = [ctypes.c_char_p, ctypes.c_uint]
+        lib.pangulu_amd_use_platform_library.restype = ctypes.c_int
     lib.pangulu_amd_active_platform.restype = ctypes.c_uint
     lib.pangulu_amd_use_builtin_platform.restype = None
     lib.pangulu_amd_set_ordering.argtypes = [ctypes.c_int]
@@ -174,7 +184,7 @@ def load(vtype="r64"):
     lib.pangulu_platform_0201001_get_stats.argtypes = [ctypes.POINTER(HipStats), ctypes.c_int]
     lib.pangulu_platform_0201001_get_stats.restype = None
     lib.pangulu_platform_0201001_get_stream.restype = ctypes.c_void_p
-    _cache[vtype] = lib
+    _cache[key] = lib
     return lib
 
 

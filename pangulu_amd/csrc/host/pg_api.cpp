@@ -96,6 +96,9 @@ using namespace pg;
 extern "C"
 {
 
+#ifdef PANGULU_AMD_TEST_HOOKS
+    // TEST BUILD ONLY (oracle/_build/libpangulu_amd_test_*.so, oracle/pangulu_amd_test_hooks.h): the shipped library
+    // binds platform 0201001 statically and has no way to route the operators anywhere else.
     int pangulu_amd_use_platform_library(const char *so_path, unsigned int platform_id)
     {
         void *h = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
@@ -155,6 +158,7 @@ extern "C"
         g_platform_builtin = false;
         return 0;
     }
+#endif
 
     void pangulu_amd_use_builtin_platform(void)
     {
@@ -340,8 +344,13 @@ extern "C"
         comm->bcast(&np, sizeof(np), 0);
         S->perm.resize(np);
         comm->bcast(S->perm.data(), sizeof(u32) * np, 0);
+        // one-shot analysis options: the next pangulu_init starts from the defaults again (a stale user permutation of
+        // the same length would otherwise be applied silently)
         opt.coords.clear();
         opt.coord_dim = 0;
+        opt.user_perm.clear();
+        opt.ordering = PANGULU_AMD_ORDER_ND;
+        opt.eager_host_mirror = false;
         S->n = (u32)np;
         S->nbk = (S->n + S->nb - 1) / S->nb;
         S->info.n_padded = S->n;

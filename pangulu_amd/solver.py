@@ -42,14 +42,14 @@ def _as(arr, dtype):
 
 
 def pangulu_init(n, nnz, csc_colptr, csc_rowidx, csc_value, nb=256, nthread=1, vtype="r64",
-                 ordering=None, coords=None, user_perm=None, recv_buffer_level=0.5, eager_host_mirror=False):
+                 ordering=None, coords=None, user_perm=None, recv_buffer_level=0.5, eager_host_mirror=False, lib=None):
     """CSC input with 64-bit column pointers and 32-bit row indices, as the reference (src/pangulu_common.h:67-70).
 
     ordering: None/"nd" (built-in nested dissection, geometric when ``coords`` is given), "identity" (what the
     reference does when built without METIS/MC64) or "user" with ``user_perm`` (perm[new] = old).
     On ranks other than 0 the matrix arguments may be None (rank 0 broadcasts them, as examples/example.c does).
     """
-    lib = _lib.load(vtype)
+    lib = lib or _lib.load(vtype)  # (tests pass the checker's build of the library, _lib.load(vtype, test_hooks=True))
     h = Handle(lib, vtype)
     dtype, sizeof_value, is_complex = _lib.VALUE_TYPES[vtype]
     if ordering in (None, "nd"):

@@ -18,12 +18,17 @@ def oracle_library(vtype="r64", fma=False):
     return os.path.join(ROOT, "oracle", "_build", "libpangulu_oracle_%s%s.so" % (vtype, "_fma" if fma else ""))
 
 
-def select_platform(lib, platform):
+def library_for(platform, vtype="r64"):
+    """The PRODUCT library for "hip"; the checker's build of the host (with the platform loader) routed to the oracle's CPU
+    operators otherwise."""
     if platform == "hip":
+        lib = _lib.load(vtype)
         lib.pangulu_amd_use_builtin_platform()
-    else:
-        rc = lib.pangulu_amd_use_platform_library(platform.encode(), _lib.PLATFORM_CPU_NAIVE)
-        assert rc == 0, "cannot load %s" % platform
+        return lib
+    lib = _lib.load(vtype, test_hooks=True)
+    rc = lib.pangulu_amd_use_platform_library(platform.encode(), _lib.PLATFORM_CPU_NAIVE)
+    assert rc == 0, "cannot load %s" % platform
+    return lib
 
 
 def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_factors=True, user_perm=None, nthread=4,
@@ -31,8 +36,7 @@ def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_fa
     """Runs pangulu_init + gstrf (+ gstrs with b = A*1) and returns info, factors (scipy CSC, permuted ordering),
     the permutation, x and ||Ax-b||/||b||."""
     n, cp, ri, va, coords = mat
-    lib = _lib.load(vtype)
-    select_platform(lib, platform)
+    lib = library_for(platform, vtype)
     if platform == "hip":
         pa.hip_stats(lib, reset=True)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_GETRF_STRICT_ORDER, 0)
@@ -46,7 +50,7 @@ def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_fa
     if ordering is None:
         ordering = "nd"
     h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering,
-                        coords=coords if ordering == "nd" else None, user_perm=user_perm, nthread=nthread)
+                        coords=coords if ordering == "nd" else None, user_perm=user_perm, nthread=nthread, lib=lib)
     out = {"info": h.info()}
     pa.pangulu_gstrf(h)
     out["info"] = h.info()

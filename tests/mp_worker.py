@@ -25,11 +25,11 @@ def main():
     vtype = sys.argv[4] if len(sys.argv) > 4 else "r64"
     platform = sys.argv[5] if len(sys.argv) > 5 else "oracle"
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lib = _lib.load(vtype)
     if platform == "oracle":
+        lib = _lib.load(vtype, test_hooks=True)  # the checker's build of the host, operators routed to the CPU restatement
         assert lib.pangulu_amd_use_platform_library(oracle_library(vtype).encode(), _lib.PLATFORM_CPU_NAIVE) == 0
     else:
-        lib.pangulu_amd_use_builtin_platform()  # every rank on the one GPU of the test box (LOCAL_RANK % device count)
+        lib = _lib.load(vtype)  # the product; every rank on the one GPU of the test box (LOCAL_RANK % device count)
     # the solver's own listeners (base_port + rank): a block below the ephemeral range, where the rendezvous port and
     # gloo's pair sockets live (a number taken by one of those would be dialled by mistake)
     base_port = 20000 + (int(os.environ["MASTER_PORT"]) * 7) % 8000
@@ -45,9 +45,9 @@ def main():
     n, cp, ri, va, co = gen()
     ordering = "identity" if spec == "trefethen" else "nd"
     if rank == 0:
-        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=co if ordering == "nd" else None)
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=co if ordering == "nd" else None, lib=lib)
     else:
-        h = pa.pangulu_init(0, 0, None, None, None, nb=nb, vtype=vtype, ordering=ordering)  # rank 0 broadcasts the matrix
+        h = pa.pangulu_init(0, 0, None, None, None, nb=nb, vtype=vtype, ordering=ordering, lib=lib)  # rank 0 broadcasts the matrix
     repeat = os.environ.get("PANGULU_TEST_REPEAT") == "1"
     if repeat:  # bench.py's sequence: snapshot, gstrf, reset_numeric, gstrf again
         assert lib.pangulu_amd_snapshot(h.ref) == 0

@@ -222,12 +222,11 @@ def exported_records(mat, nb, vtype="r64", ordering="nd"):
     """Block records (patterns closed under fill, values = A on its pattern, 0 on fill) as the host builds them."""
     import pangulu_amd as pa
 
-    from .helpers import oracle_library, select_platform
+    from .helpers import library_for, oracle_library
 
     n, cp, ri, va, coords = mat
-    lib = _lib.load(vtype)
-    select_platform(lib, oracle_library(vtype))
-    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=coords if ordering == "nd" else None)
+    lib = library_for(oracle_library(vtype), vtype)
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=coords if ordering == "nd" else None, lib=lib)
     recs = list(pa.owned_blocks(h))
     pa.pangulu_finalize(h)
     return recs

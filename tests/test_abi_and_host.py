@@ -14,7 +14,7 @@ import pangulu_amd as pa
 from pangulu_amd import _lib
 from pangulu_amd import matrices as M
 
-from .helpers import ROOT, factorize, oracle_library
+from .helpers import ROOT, factorize, library_for, oracle_library
 
 
 def declared_functions(header):
@@ -34,6 +34,9 @@ def test_library_exports_every_declared_symbol(vtype):
         assert hasattr(lib, n), "%s is declared in include/ but not exported by %s" % (n, _lib.library_path(vtype))
     for op in _lib.PLATFORM_SYMBOLS:
         assert hasattr(lib, "pangulu_platform_0201001_" + op)
+    # the shipped library has no platform loader: nothing can route the product to the CPU checker
+    assert not hasattr(lib, "pangulu_amd_use_platform_library")
+    assert hasattr(ctypes.CDLL(_lib.test_library_path(vtype)), "pangulu_amd_use_platform_library")
 
 
 @pytest.mark.parametrize("vtype", ["r64", "r32", "cr64", "cr32"])
@@ -112,10 +115,9 @@ def test_block_records_follow_the_reference_layout():
     first in every upper row, values = A on its pattern and 0 on fill before gstrf."""
     mat = M.fem27(5)
     n, cp, ri, va, co = mat
-    lib = _lib.load("r64")
-    lib.pangulu_amd_use_platform_library(oracle_library("r64").encode(), _lib.PLATFORM_CPU_NAIVE)
+    lib = library_for(oracle_library("r64"))
     nb = 32
-    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, coords=co)
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, coords=co, lib=lib)
     from .helpers import permuted_matrix
 
     Ap = permuted_matrix(mat, pa.permutation(h)).toarray()
@@ -147,9 +149,8 @@ def test_block_records_follow_the_reference_layout():
 def test_gstrf_twice_after_reset_gives_identical_factors():
     mat = M.fem27(5)
     n, cp, ri, va, co = mat
-    lib = _lib.load("r64")
-    lib.pangulu_amd_use_platform_library(oracle_library("r64").encode(), _lib.PLATFORM_CPU_NAIVE)
-    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=32, coords=co)
+    lib = library_for(oracle_library("r64"))
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=32, coords=co, lib=lib)
     assert lib.pangulu_amd_snapshot(h.ref) == 0
     pa.pangulu_gstrf(h)
     L1, U1 = pa.factors_as_scipy(h)

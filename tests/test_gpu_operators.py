@@ -83,7 +83,6 @@ def test_single_task_operators(name, vtype):
     hip, fh, fo = _platforms(vtype)
     dt = _lib.VALUE_TYPES[vtype][0]
     recs = S.exported_records(gen(), nb, vtype)
-    hip.pangulu_amd_use_builtin_platform()
     g = S.BlockMatrix(recs, nb, dt, hip)
     r = S.BlockMatrix(recs, nb, dt, None)
     try:
@@ -116,7 +115,6 @@ def test_hybrid_batched_dependent_array_with_hazard_scan(name):
     gen, nb = _case(name, vtype)
     hip, fh, fo = _platforms(vtype)
     recs = S.exported_records(gen(), nb, vtype)
-    hip.pangulu_amd_use_builtin_platform()
     g = S.BlockMatrix(recs, nb, np.float64, hip)
     r = S.BlockMatrix(recs, nb, np.float64, None)
     try:
@@ -137,7 +135,6 @@ def test_ssssm_batched_per_level(name):
     gen, nb = _case(name, vtype)
     hip, fh, fo = _platforms(vtype)
     recs = S.exported_records(gen(), nb, vtype)
-    hip.pangulu_amd_use_builtin_platform()
     g = S.BlockMatrix(recs, nb, np.float64, hip)
     r = S.BlockMatrix(recs, nb, np.float64, None)
     try:
@@ -166,7 +163,6 @@ def test_spmv_vecadd_sptrsv_operators(vtype):
     nb = 64
     rng = np.random.default_rng(3)
     recs = S.exported_records(M.fem27(6, dtype=dt), nb, vtype)
-    hip.pangulu_amd_use_builtin_platform()
     g = S.BlockMatrix(recs, nb, dt, hip)
     r = S.BlockMatrix(recs, nb, dt, None)
     sv = np.dtype(dt).itemsize

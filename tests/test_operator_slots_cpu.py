@@ -10,7 +10,7 @@ from pangulu_amd import _lib
 from pangulu_amd import matrices as M
 
 from . import slots as S
-from .helpers import oracle_library, select_platform
+from .helpers import library_for, oracle_library
 
 
 @pytest.mark.parametrize("vtype", ["r64", "cr64"])
@@ -28,9 +28,8 @@ def test_hand_built_slots_reproduce_the_scheduler_result(name, gen, nb, vtype):
     fo("hybrid_batched")(nb, len(tasks), arr)
     # the same matrix through the scheduler
     n, cp, ri, va, co = mat
-    lib = _lib.load(vtype)
-    select_platform(lib, oracle_library(vtype))
-    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, coords=co)
+    lib = library_for(oracle_library(vtype), vtype)
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, coords=co, lib=lib)
     pa.pangulu_gstrf(h)
     done = {(br, bc, up): v for br, bc, up, _, _, v in pa.owned_blocks(h)}
     pa.pangulu_finalize(h)
