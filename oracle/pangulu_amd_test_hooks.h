@@ -15,6 +15,11 @@ extern "C"
 #endif
     /* so_path must export pangulu_platform_<7-digit id>_<name> for the 21 names of build_helper.py:8-32.  0 on success. */
     int pangulu_amd_use_platform_library(const char *so_path, unsigned int platform_id);
+    /* the host's priority heap driven by a push/pop script, and its symbolic phase on a bare pattern: compared with the
+     * reference's own src/pangulu_task.c / src/pangulu_symbolic.c (oracle/ref/ref_pin.c) in tests/test_reference_pin.py */
+    long long pangulu_amd_test_heap_script(long long nscript, const long long *script, const void *tasks, void *out);
+    int pangulu_amd_test_symbolic(unsigned int n, const unsigned long long *colptr, const unsigned int *rowidx,
+                                  unsigned long long **out_ptr, unsigned int **out_idx, unsigned long long *out_symbolic_nnz, long long *out_flop);
 #ifdef __cplusplus
 }
 #endif

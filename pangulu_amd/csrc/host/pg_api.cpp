@@ -158,6 +158,43 @@ extern "C"
         g_platform_builtin = false;
         return 0;
     }
+
+    // The host's own priority heap driven by a script (script[i] >= 0: push tasks[script[i]], -1: pop); the popped tasks
+    // go to `out`.  tests/test_reference_pin.py runs the same script through the reference's src/pangulu_task.c.
+    long long pangulu_amd_test_heap_script(long long nscript, const long long *script, const pangulu_task_t *tasks, pangulu_task_t *out)
+    {
+        TaskHeap heap;
+        long long npop = 0;
+        for (long long i = 0; i < nscript; i++)
+        {
+            if (script[i] >= 0)
+                heap.push(tasks[script[i]]);
+            else if (!heap.pop(out[npop++]))
+                return -2;
+        }
+        return npop;
+    }
+
+    // The host's symbolic phase on a CSC pattern (already ordered): lower fill pattern incl. diagonal per column, the
+    // reference's symbolic_nnz and the structural flop count.  Arrays are malloc'ed; free with free().
+    int pangulu_amd_test_symbolic(sparse_index_t n, const sparse_pointer_t *colptr, const sparse_index_t *rowidx,
+                                  sparse_pointer_t **out_ptr, sparse_index_t **out_idx, unsigned long long *out_symbolic_nnz, long long *out_flop)
+    {
+        CscMatrix A;
+        A.n = n;
+        A.colptr.assign(colptr, colptr + n + 1);
+        A.rowidx.assign(rowidx, rowidx + colptr[n]);
+        A.value.assign((size_t)colptr[n], val_t());
+        Symbolic sym;
+        symbolic_factorize(A, sym);
+        *out_ptr = (sparse_pointer_t *)malloc(sizeof(sparse_pointer_t) * ((size_t)n + 1));
+        *out_idx = (sparse_index_t *)malloc(sizeof(sparse_index_t) * std::max<size_t>(1, sym.idx.size()));
+        std::copy(sym.ptr.begin(), sym.ptr.end(), *out_ptr);
+        std::copy(sym.idx.begin(), sym.idx.end(), *out_idx);
+        *out_symbolic_nnz = sym.symbolic_nnz;
+        *out_flop = sym.flop;
+        return 0;
+    }
 #endif
 
     void pangulu_amd_use_builtin_platform(void)
