@@ -159,8 +159,10 @@ struct Sched
     // Single-rank runs on a device: the platform calls (descriptor building and launches) cost about as much host time
     // as the scheduling itself, and nothing the scheduler does next depends on their return -- the back-end's streams
     // keep program order.  A launcher thread makes the calls in batch order while this thread releases successors and
-    // drains the next batch.  Opt-in (PANGULU_AMD_ASYNC_LAUNCH=1): on the bench host the one-thread loop already stays
-    // ahead of the device (it spends 27 of its 66 ms waiting for descriptor segments), so the thread buys nothing there.
+    // drains the next batch.  On by default (PANGULU_AMD_ASYNC_LAUNCH=0 turns it off): in round 1 the one-thread loop still
+    // stayed ahead of the device; with the faster GETRF the leaf levels of the bench matrix became host-bound (the
+    // device sat empty 10-19 ms of a 57 ms factorisation, mostly before the densify launch that follows a level's
+    // GETRF) and the launcher thread brought 59.7-70.7 ms down to 52.0-52.4 ms on the same box.
     bool async_launch = false;
     std::thread launcher;
     std::mutex lq_mutex;
@@ -185,7 +187,7 @@ struct Sched
             stall_limit_s = atof(e);
         use_markers = multi && !plat.host_memory && plat.marker_record && plat.marker_done && plat.marker_wait && !getenv("PANGULU_AMD_SYNC_EVERY_BATCH");
         const char *al = getenv("PANGULU_AMD_ASYNC_LAUNCH");
-        async_launch = !multi && !plat.host_memory && al && atoi(al) != 0;
+        async_launch = !multi && !plat.host_memory && !(al && atoi(al) == 0);
         if (async_launch)
             launcher = std::thread([this]()
                                    { launcher_loop(); });

@@ -1388,6 +1388,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (lane == 0 && ops)
         atomicAdd(flop_counter, ops);
 }
+#include "pg_hip_getrf_tiled.h"
 #endif
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -2417,7 +2418,21 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 // without -- both kernels slow down when they share CUs; off by default)
                 static const long narrow_from = getenv("PANGULU_HIP_GETRF_NARROW_FROM") ? atol(getenv("PANGULU_HIP_GETRF_NARROW_FROM")) : 1 << 30;
                 static const bool lookahead_kernel = !(getenv("PANGULU_HIP_GETRF_LOOKAHEAD") && atoi(getenv("PANGULU_HIP_GETRF_LOOKAHEAD")) == 0);
-                if (lookahead_kernel)
+                static const bool tiled_kernel = !(getenv("PANGULU_HIP_GETRF_TILED") && atoi(getenv("PANGULU_HIP_GETRF_TILED")) == 0);
+                if (tiled_kernel)
+                {
+                    // static tile ownership + a dedicated factorisation wavefront (pg_hip_getrf_tiled.h)
+                    const size_t lds_t = gt_lds_bytes(nb);
+                    static size_t t_allowed = 0;
+                    if (lds_t > t_allowed)
+                    {
+                        HIP_CHECK(hipFuncSetAttribute((const void *)getrf_tiled_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+                        t_allowed = lds_t;
+                    }
+                    hipLaunchKernelGGL(getrf_tiled_f64_kernel, dim3((unsigned)take), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, B.d_flops + 1,
+                                       debug_stamps ? B.d_flops + 8 : nullptr);
+                }
+                else if (lookahead_kernel)
                 {
                     const size_t lds_la = sizeof(double) * (4 * GETRF_PANEL * (size_t)(nb + 2) + GETRF_PANEL * GETRF_PANEL) + sizeof(u32) * (2 * (size_t)(nb + 1) + 4);
                     static size_t la_allowed = 0;
@@ -2982,8 +2997,8 @@ extern "C"
             fprintf(stderr, "[trsm stamps, every 64th workgroup, shader clocks] setup+x loads %llu | prefetch issue %llu | barrier A %llu | stage %llu | barrier B %llu | mfma loop %llu | tail chain %llu | stores %llu, empty workgroups %llu\n",
                     f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15] & ((1ull << 40) - 1), f[15] >> 40);
         if (getenv("PANGULU_HIP_DEBUG_GETRF"))
-            fprintf(stderr, "[getrf stamps, block 0, 100 MHz ticks] scatter %llu | panel-load %llu | pivots %llu | panel-store %llu | strip %llu | gemm %llu | gather %llu\n",
-                    f[8], f[9], f[10], f[11], f[12], f[13], f[14]);
+            fprintf(stderr, "[getrf stamps, block 0, shader clocks; tiled kernel: 1 = diag+priority tiles, 2 = trailing passes, 3 = wait for LU, 4 = substitution (wavefront 0), lu = tile LU (wavefront 7)] prologue %llu | 1 %llu | 2 %llu | 3 %llu | 4 %llu | loop %llu | gather %llu | lu %llu\n",
+                    f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15]);
         for (int c = 1; c <= 5; c++)
             B.stats.flops[c] = (double)f[c];
         B.stats.mfma_flops_executed = 8192.0 * (double)f[6]; // 16 x 16 x 16 products counted by the MFMA update kernel
