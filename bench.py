@@ -46,11 +46,12 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, nargs=2, default=[200, 200], help="shell nx ny of the CPU-baseline sample (about 15 s of one core)")
-    ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "ipc"), choices=["host", "rccl", "ipc"],
-                    help="block exchange for --gpus > 1: ipc = the consumer pulls each record out of the owner's HBM arena with "
-                         "one peer copy over xGMI (default), rccl = ncclSend/ncclRecv per ordered pair; both are verified by a "
-                         "self-test at start-up and fall back to host-staged TCP on all ranks together on failure")
+    ap.add_argument("--cpu-sample-stride", type=int, default=6,
+                    help="CPU baseline: execute every k-th task of each kernel class of the SAME factorisation (about 15 s of one core at 6)")
+    ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "auto"), choices=["auto", "host", "rccl", "ipc"],
+                    help="block exchange for --gpus > 1: auto = rccl (ncclSend/ncclRecv per ordered pair over xGMI), else ipc (the "
+                         "consumer pulls each record out of the owner's HBM arena with one peer copy), else host-staged TCP: each is "
+                         "verified by a self-test at start-up and all ranks fall back together; the line says what ran")
     return ap.parse_args()
 
 
@@ -71,6 +72,18 @@ def make_matrix(args, M):
         return M.poisson3d(*s), "poisson3d(%s)" % ",".join(map(str, s))
     s = size or [40]
     return M.kkt(s[0]), "nlpkkt-class stand-in: kkt(%d)" % s[0]
+
+
+def kernel_source_hash():
+    """sha256 over the HIP kernel sources: a committed PMC pass is only quoted for the build it profiled."""
+    import hashlib
+
+    d = os.path.join(ROOT, "pangulu_amd", "csrc", "platform")
+    hsh = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def grid(world):
@@ -96,28 +109,40 @@ def find_openblas():
     return None
 
 
-def cpu_baseline(args, pa, M, lib):
-    """Oracle (CPU restatement of the reference's CPU platform) timed on one host core on a bounded sample of the
-    same workload class.  Reported beside the GPU number; not a target."""
+def cpu_baseline(args, pa, M, mat, workload):
+    """Oracle (CPU restatement of the reference's CPU platform, OpenBLAS dgemm inside SSSSM like the reference) timed on one
+    host core on a bounded sample of the SAME factorisation: same matrix, ordering and nb; every k-th task of each kernel
+    class is executed (in the scheduler's order), the others are only released.  A kernel's time depends on the patterns
+    of its operands, not on their values, so the sample is a 1/k cut through all levels of the elimination tree.
+    value = structural flops of the executed tasks / their time.  Reported beside the GPU number; not a target."""
     from tests.helpers import library_for, oracle_library
 
     blas = find_openblas()
     if blas:
         os.environ["PANGULU_ORACLE_BLAS"] = blas
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-    nx, ny = args.cpu_sample
-    n, cp, ri, va, co = M.shell(nx, ny)
+    n, cp, ri, va, co = mat
     tlib = library_for(oracle_library("r64"))  # the checker's build of the host, routed to the CPU restatement
-    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=args.nb, ordering=args.ordering, coords=co, nthread=max(1, os.cpu_count() or 1), lib=tlib)
+    tlib.pangulu_amd_test_set_task_sampling.argtypes = [ctypes.c_int]
+    stride = max(1, args.cpu_sample_stride)
+    tlib.pangulu_amd_test_set_task_sampling(stride)
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=args.nb, ordering=args.ordering, coords=co if args.ordering == "nd" else None,
+                        nthread=max(1, os.cpu_count() or 1), lib=tlib)
     t0 = time.time()
     pa.pangulu_gstrf(h)
     dt = time.time() - t0
     info = h.info()
     pa.pangulu_finalize(h)
+    tlib.pangulu_amd_test_set_task_sampling(1)
+    ntask = info["ntask_getrf"] + info["ntask_tstrf"] + info["ntask_gessm"] + info["ntask_ssssm"]
+    fsample = info["sampled_flop"] if stride > 1 else float(info["flop"])
     return {
-        "value": info["flop"] / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
-        "sample": "shell(%d,%d) n=%d F=%.3e nb=%d, 1 rank x 1 compute thread, SSSSM GEMM: %s, %.1f s" % (
-            nx, ny, n, info["flop"], args.nb, "OpenBLAS (scipy bundle)" if blas else "oracle triple loop", dt),
+        "value": fsample / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+        "sample": "same matrix, ordering and nb as the GPU line (%s): every %d%s task of each kernel class, %d of %d tasks, "
+                  "%.3e of %.3e structural flops, %.1f s; 1 rank x 1 compute thread (= R x 1 at R = 1 GPU), SSSSM GEMM: %s" % (
+                      workload, stride, "th" if stride > 3 else ("st", "nd", "rd")[stride - 1] if stride <= 3 else "th",
+                      info["sampled_tasks"] if stride > 1 else ntask, ntask, fsample, float(info["flop"]), dt,
+                      "OpenBLAS (scipy bundle)" if blas else "oracle triple loop"),
     }
 
 
@@ -151,10 +176,24 @@ def main():
         base_port = int(os.environ.get("MASTER_PORT", "29500")) + 23
         if base_port + world >= 32768:  # keep the solver's listeners (base_port + rank) out of the ephemeral port range
             base_port = 20000 + (base_port * 7) % 8000
-        transport = {"host": _lib.TRANSPORT_HOST, "rccl": _lib.TRANSPORT_RCCL, "ipc": _lib.TRANSPORT_IPC}[args.transport]
-        rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port, transport, None)
-        assert rc == 0
+        # auto: rccl first (north star: MPI point-to-point -> RCCL send/recv over xGMI); it self-tests on every pair and all
+        # ranks agree on the outcome; if it is not there the same ranks try peer copies, then host staging
+        order = {"auto": ["rccl", "ipc", "host"], "rccl": ["rccl"], "ipc": ["ipc"], "host": ["host"]}[args.transport]
+        codes = {"host": _lib.TRANSPORT_HOST, "rccl": _lib.TRANSPORT_RCCL, "ipc": _lib.TRANSPORT_IPC}
+        t_comm = time.time()
+        tried = []
+        for k, name in enumerate(order):
+            rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port + 64 * k, codes[name], None)
+            assert rc == 0
+            got = {0: "host", 1: "rccl", 2: "ipc"}[lib.pangulu_amd_comm_transport()]
+            tried.append("%s->%s" % (name, got))
+            if got == name or k + 1 == len(order):
+                break
+            lib.pangulu_amd_comm_finalize()  # (all ranks saw the same fall-back: they all move on to the next one)
+        comm_init_s = time.time() - t_comm
 
+    if world == 1:
+        tried, comm_init_s = [], 0.0
     if rank == 0:
         mat, workload = make_matrix(args, M)
         n, cp, ri, va, coords = mat
@@ -218,8 +257,11 @@ def main():
                 }
                 if name == "ssssm_dense_mfma":
                     kernels[name]["GFLOP_executed"] = round(v["mfma_flops_executed"] / 1e9, 2)
+        task_classes = ("getrf", "tstrf", "gessm", "ssssm_sparse", "ssssm_dense_mfma")
         if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["ms"])
+            # the dominant kernel among the task classes (mirror maintenance -- densify, sparsify, remote LU images -- is listed
+            # in `kernels` and counted in the denominator of share_of_kernel_time, but has no algorithmic bytes or flops)
+            dom = max((k for k in kernels if k in task_classes), key=lambda k: kernels[k]["ms"])
             v = st[dom]
             sec = v["elapsed_ms"] / 1e3
             if dom == "ssssm_dense_mfma":
@@ -233,20 +275,33 @@ def main():
                 ach = v["alg_bytes"] / sec / 1e9
                 roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": None}
-            # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process, so the value
-            # is the one the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes measured for this exact workload
-            # (profiles/r01y_final_shell398.md; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
-            rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_lookahead_f64_kernel",
+            # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process, so the value comes
+            # from a committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass (tools/profile_recipe.sh; FETCH_SIZE doubled as
+            # MI355X_MICROARCH.md prescribes for gfx950) -- but ONLY if that pass profiled this build's kernels: the file
+            # records a hash of the kernel sources, anything else leaves `traffic` null
+            rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_tiled_f64_kernel",
                             "tstrf": "void trsm_dense_direct_f64_kernel<16>", "gessm": "void trsm_dense_direct_f64_kernel<16>",
                             "ssssm_sparse": "void ssssm_sparse_kernel<false>"}.get(dom)
-            traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01y_hbm_traffic_shell398.json")
-            if world == 1 and default_workload and rocprof_name and os.path.exists(traffic_file):
-                t = json.load(open(traffic_file)).get(rocprof_name)
-                if t:
-                    roofline["traffic"] = t["hbm_bytes_per_launch"]
-                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass, profiles/r01y_final_shell398.md)"
+            tfile = os.path.join(ROOT, "profiles", "hbm_traffic_default_workload.json")
+            if world == 1 and default_workload and rocprof_name and os.path.exists(tfile):
+                tj = json.load(open(tfile))
+                if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get(rocprof_name):
+                    roofline["traffic"] = tj[rocprof_name]["hbm_bytes_per_launch"]
+                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass of this build, %s)" % tj.get("profile", "profiles/")
+                else:
+                    roofline["traffic_note"] = "no PMC pass of this build committed (kernel sources changed since %s)" % tj.get("profile", "the last one")
             roofline["avg_launch_us"] = kernels[dom]["avg_launch_us"]
             roofline["share_of_kernel_time"] = kernels[dom]["ms"] / sum(k["ms"] for k in kernels.values())
+            # whole-factorisation bound of SURVEY.md §8d: T* = sum over tasks of max(bytes_t / 8 TB/s, flop_t / 78.6 TF), from the
+            # task list's structure alone (pg_model.cpp); single-rank handles
+            if world == 1:
+                lib.pangulu_amd_model_roofline(h.ref, HBM_PEAK_GBS, FP64_PEAK_TFLOPS)
+                mi = h.info()
+                t_star = mi["model_tmin_hbm_bound"] + mi["model_tmin_fp_bound"]
+                roofline["model_T_star_ms"] = 1e3 * t_star
+                roofline["model_T_star_over_t_gstrf"] = 1e3 * t_star / ms_per_step
+                roofline["model_split_ms"] = {"hbm_bound_tasks": 1e3 * mi["model_tmin_hbm_bound"], "mfma_bound_tasks": 1e3 * mi["model_tmin_fp_bound"]}
+                roofline["model_alg_GB"] = mi["model_bytes_total"] / 1e9
 
     # end-to-end check of the last factorisation: ||Ax-b||/||b|| with b = A*1 (examples/example.c:252-264,304-364)
     residual = None
@@ -265,7 +320,7 @@ def main():
     # after ten seconds of host-only work with the device idle, whatever the warm-up count; cause not isolated)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, pa, M, lib)
+        cpu = cpu_baseline(args, pa, M, mat, workload)
 
     if rank == 0:
         value = flop / (ms_per_step / 1e3) / 1e9
@@ -281,6 +336,7 @@ def main():
                 "parallelism": "2D block-cyclic %dx%d" % grid(world) + (" above subtrees of the block elimination tree mapped to single ranks" if world > 1 else ""),
                 # what is really in use: ipc / rccl fall back to host staging on all ranks when their self-test fails
                 "transport": effective_transport,
+                "transport_tried": tried, "comm_nranks": world if world > 1 else 0, "comm_init_s": round(comm_init_s, 2),
                 "blocks": int(info["nblocks_nondiag"]),
                 "tasks": {"getrf": int(info["ntask_getrf"]), "tstrf": int(info["ntask_tstrf"]), "gessm": int(info["ntask_gessm"]),
                           "ssssm": int(info["ntask_ssssm"])},

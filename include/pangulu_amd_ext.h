@@ -78,6 +78,9 @@ extern "C"
         double model_bytes_total, model_flop_total;
         double model_tmin_hbm_bound, model_tmin_fp_bound; /* seconds */
         unsigned long long batches;           /* platform hybrid_batched calls issued by the scheduler                */
+        /* checker's build with task sampling on (oracle/pangulu_amd_test_hooks.h); 0 in the product */
+        double sampled_flop;                  /* structural flops of the tasks that were executed                      */
+        unsigned long long sampled_tasks;
     } pangulu_amd_info_t;
     void pangulu_amd_get_info(void **pangulu_handle, pangulu_amd_info_t *out);
     /* evaluate T* = sum_t max(bytes_t / BW, flop_t / P) over this rank's task list (structure only) */

@@ -264,18 +264,23 @@ extern "C"
     void *pangulu_platform_0201001_get_stream(void);
     /* Cumulative per-kernel-class counters since the last reset.  Classes: 1 GETRF, 2 TSTRF, 3 GESSM,
      * 4 SSSSM (sparse LDS-accumulator kernel), 5 SSSSM (dense MFMA kernel); index 0 unused.
+     * Classes 6..8 are the MIRROR MAINTENANCE of the dense-mode blocks -- no task of the reference's model, so no
+     * algorithmic bytes or flops, but real device time and HBM traffic: 6 densify (record -> dense mirror), 7 sparsify
+     * (mirror -> record), 8 LU images of remote diagonal blocks (half_image + tile inversion).  For them `tasks` counts
+     * blocks and `alg_bytes` the bytes the jobs move by construction (record read + image written, or the reverse).
      *   alg_bytes : algorithmic HBM bytes of the launched tasks (SURVEY.md §8d formulas, from nnz only)
      *   flops     : structural flops the kernels executed (counted on the device for the sparse kernels,
      *               2*nb^3 per task for the dense kernel)
      *   elapsed_ms: sum of launch durations from hipEvents on the back-end stream; only collected while
      *               PANGULU_HIP_OPT_PROFILE is 1 (it adds two event records per launch)                  */
+#define PANGULU_HIP_STAT_CLASSES 9
     typedef struct pangulu_hip_stats_t
     {
-        unsigned long long launches[6];
-        unsigned long long tasks[6];
-        double alg_bytes[6];
-        double flops[6];
-        double elapsed_ms[6];
+        unsigned long long launches[PANGULU_HIP_STAT_CLASSES];
+        unsigned long long tasks[PANGULU_HIP_STAT_CLASSES];
+        double alg_bytes[PANGULU_HIP_STAT_CLASSES];
+        double flops[PANGULU_HIP_STAT_CLASSES];
+        double elapsed_ms[PANGULU_HIP_STAT_CLASSES];
         double mfma_flops_executed; /* class 5: flops the matrix cores actually executed (16x16x16 products issued x 8192;
                                      *  structurally empty tiles are skipped); counted while COUNT_FLOPS is on */
         unsigned long long trsm_dense_tasks; /* TSTRF/GESSM tasks that took the dense MFMA path */

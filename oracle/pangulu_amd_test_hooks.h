@@ -15,6 +15,10 @@ extern "C"
 #endif
     /* so_path must export pangulu_platform_<7-digit id>_<name> for the 21 names of build_helper.py:8-32.  0 on success. */
     int pangulu_amd_use_platform_library(const char *so_path, unsigned int platform_id);
+    /* bench.py's cpu_baseline leg: execute every stride-th task of each kernel class of a factorisation and only release
+     * the others (a bounded sample of the same matrix / ordering / nb); pangulu_amd_info_t.sampled_flop / sampled_tasks
+     * say what ran.  1 = everything (default). */
+    void pangulu_amd_test_set_task_sampling(int stride);
     /* the host's priority heap driven by a push/pop script, and its symbolic phase on a bare pattern: compared with the
      * reference's own src/pangulu_task.c / src/pangulu_symbolic.c (oracle/ref/ref_pin.c) in tests/test_reference_pin.py */
     long long pangulu_amd_test_heap_script(long long nscript, const long long *script, const void *tasks, void *out);

@@ -75,6 +75,8 @@ class Info(ctypes.Structure):
         ("model_tmin_hbm_bound", ctypes.c_double),
         ("model_tmin_fp_bound", ctypes.c_double),
         ("batches", ctypes.c_ulonglong),
+        ("sampled_flop", ctypes.c_double),
+        ("sampled_tasks", ctypes.c_ulonglong),
     ]
 
     def as_dict(self):
@@ -82,20 +84,22 @@ class Info(ctypes.Structure):
 
 
 class HipStats(ctypes.Structure):
-    """pangulu_hip_stats_t (include/pangulu_platform.h); class index 1 GETRF, 2 TSTRF, 3 GESSM, 4 SSSSM sparse, 5 SSSSM dense."""
+    """pangulu_hip_stats_t (include/pangulu_platform.h); class index 1 GETRF, 2 TSTRF, 3 GESSM, 4 SSSSM sparse, 5 SSSSM dense,
+    6 densify, 7 sparsify, 8 LU images of remote diagonal blocks."""
 
     _fields_ = [
-        ("launches", ctypes.c_ulonglong * 6),
-        ("tasks", ctypes.c_ulonglong * 6),
-        ("alg_bytes", ctypes.c_double * 6),
-        ("flops", ctypes.c_double * 6),
-        ("elapsed_ms", ctypes.c_double * 6),
+        ("launches", ctypes.c_ulonglong * 9),
+        ("tasks", ctypes.c_ulonglong * 9),
+        ("alg_bytes", ctypes.c_double * 9),
+        ("flops", ctypes.c_double * 9),
+        ("elapsed_ms", ctypes.c_double * 9),
         ("mfma_flops_executed", ctypes.c_double),
         ("trsm_dense_tasks", ctypes.c_ulonglong),
     ]
 
 
-KERNEL_CLASSES = {1: "getrf", 2: "tstrf", 3: "gessm", 4: "ssssm_sparse", 5: "ssssm_dense_mfma"}
+KERNEL_CLASSES = {1: "getrf", 2: "tstrf", 3: "gessm", 4: "ssssm_sparse", 5: "ssssm_dense_mfma",
+                  6: "densify", 7: "sparsify", 8: "remote_lu_image"}  # 6..8: mirror maintenance, no task of the reference's model
 
 _cache = {}
 

@@ -159,6 +159,9 @@ extern "C"
         return 0;
     }
 
+    // bench.py's cpu_baseline leg: run every stride-th task of each kernel class only (pg_numeric.cpp)
+    void pangulu_amd_test_set_task_sampling(int stride) { g_task_sample_stride = stride < 1 ? 1 : stride; }
+
     // The host's own priority heap driven by a script (script[i] >= 0: push tasks[script[i]], -1: pop); the popped tasks
     // go to `out`.  tests/test_reference_pin.py runs the same script through the reference's src/pangulu_task.c.
     long long pangulu_amd_test_heap_script(long long nscript, const long long *script, const pangulu_task_t *tasks, pangulu_task_t *out)
@@ -636,9 +639,6 @@ extern "C"
     void pangulu_amd_model_roofline(void **pangulu_handle, double hbm_gbytes_per_s, double fp_tflops)
     {
         Solver *S = (Solver *)*pangulu_handle;
-        compute_task_model(*S);
-        // the split by bound needs per-task maxima; compute_task_model stored per-task sums in info
-        (void)hbm_gbytes_per_s;
-        (void)fp_tflops;
+        compute_task_model(*S, hbm_gbytes_per_s * 1e9, fp_tflops * 1e12);
     }
 }

@@ -312,6 +312,10 @@ void preprocess(Solver &S, const CscMatrix &Aperm);       // records, counters, 
 void numeric_factorize(Solver &S);                        // the hot path
 void download_factors(Solver &S);                         // device -> host mirror of owned values
 void triangular_solve(Solver &S, val_t *rhs_permuted);    // forward + backward block sweeps (host kernels)
-void compute_task_model(Solver &S);
+void compute_task_model(Solver &S, double hbm_bytes_per_s, double fp_flops_per_s); // pg_model.cpp: T* of SURVEY.md §8d
+double task_structural_flop(u32 nb, const task_t &t);
+// Checker's build only (oracle/pangulu_amd_test_hooks.h): execute every stride-th task of each kernel class and skip the
+// rest -- a bounded, representative sample of the SAME factorisation for bench.py's cpu_baseline leg.  1 = everything.
+extern int g_task_sample_stride;
 
 } // namespace pg

@@ -396,6 +396,7 @@ struct MirrorJobD
     double *dense;  // nb x nb column-major
     const double *diag_tiles; // sparsify of a fresh LU image: its nb/16 diagonal tiles as GETRF left them (16 x 16 column-major
                               // each; the image's own have been inverted in place since), or nullptr
+    unsigned long long move_bytes; // host side only (statistics): record entries read + image entries written, or the reverse
 };
 
 // Entries ptr[c0] .. ptr[c1] of a CSC block are one contiguous run: the workgroup walks it flat (coalesced, no

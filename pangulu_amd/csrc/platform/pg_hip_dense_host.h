@@ -211,6 +211,20 @@ MirrorJobD mirror_job(slot_t *s, double *dense, int nb)
         J.lo = BlkView{s->d_columnpointer, s->d_rowindex, s->d_value};
     }
     J.dense = dense;
+    {
+        // what the job moves by construction: every pattern entry once as (index, value) in the record and once as a
+        // value in the image, plus the record's pointer array(s)
+        double nnz = host_nnz(canon_dst(s), nb);
+        double ptrs = 4.0 * (nb + 1);
+        if (s->brow_pos == s->bcol_pos)
+        {
+            slot_t *up, *lo;
+            diag_halves(s, &up, &lo);
+            nnz = (double)host_nnz(lo, nb) + host_nnz(up, nb);
+            ptrs *= 2;
+        }
+        J.move_bytes = (unsigned long long)(nnz * (sizeof(double) + 2.0 + sizeof(double)) + ptrs);
+    }
     return J;
 }
 
@@ -342,11 +356,18 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify, bool
         while (slices > 1 && (size_t)slices * take > (size_t)target_env)
             slices >>= 1;
         slices = std::min<unsigned>(slices, (unsigned)std::max(1, nb / 16)); // whole 16-column slabs per workgroup
-        if (densify)
-            hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
-        else
-            hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
+        {
+            LaunchTimer lt(densify ? 6 : 7, st);
+            if (densify)
+                hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
+            else
+                hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
+        }
         HIP_CHECK(hipGetLastError());
+        B.stats.launches[densify ? 6 : 7]++;
+        B.stats.tasks[densify ? 6 : 7] += take;
+        for (size_t k = 0; k < take; k++)
+            B.stats.alg_bytes[densify ? 6 : 7] += jobs[i + k].move_bytes;
         release_pending_segments(st); // (callers commit their own segment only after this returns)
         i += take;
     }

@@ -2207,8 +2207,14 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 imgs[q] = g_half_image_jobs[q].dense;
             }
             g_half_image_jobs.clear();
-            hipLaunchKernelGGL(half_image_kernel, dim3((unsigned)nj), dim3(1024), sizeof(u32) * (size_t)(nb + 1), B.stream, d_jobs, nb);
-            hipLaunchKernelGGL(diag_tile_inverse_kernel, dim3((unsigned)(nj * (nb / 16))), dim3(64), 0, B.stream, d_imgs, nb);
+            {
+                LaunchTimer lt(8);
+                hipLaunchKernelGGL(half_image_kernel, dim3((unsigned)nj), dim3(1024), sizeof(u32) * (size_t)(nb + 1), B.stream, d_jobs, nb);
+                hipLaunchKernelGGL(diag_tile_inverse_kernel, dim3((unsigned)(nj * (nb / 16))), dim3(64), 0, B.stream, d_imgs, nb);
+            }
+            B.stats.launches[8]++;
+            B.stats.tasks[8] += nj;
+            B.stats.alg_bytes[8] += (double)nj * sizeof(double) * nb * nb;
             HIP_CHECK(hipGetLastError());
         }
 #endif

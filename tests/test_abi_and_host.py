@@ -169,3 +169,41 @@ def test_matrix_generators_are_diagonally_dominant():
         off = np.asarray(abs(A).sum(axis=1)).ravel() - d
         assert (d > off - 1e-12).all() or (d >= 0.99 * off).all()
         assert sp.issparse(A)
+
+
+@pytest.mark.parametrize("gen,nb", [(lambda: M.fem27(7), 32), (lambda: M.shell(12, 10), 48), (lambda: M.kkt(4), 16), (lambda: M.trefethen(), 4)])
+def test_task_model_counts_every_task_and_every_flop(gen, nb):
+    """pg_model.cpp (T* of SURVEY.md §8d): the per-task structural flops summed over the whole task list equal the closed
+    form F = sum_k (c_k + 2 c_k^2), the task counts equal the scheduler's, and T* = max-sum is consistent with its parts."""
+    n, cp, ri, va, co = gen()
+    lib = library_for(oracle_library("r64"))
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, coords=co, lib=lib, ordering="nd" if co is not None else "identity")
+    lib.pangulu_amd_model_roofline(h.ref, 8000.0, 78.6)
+    info = h.info()
+    assert info["model_flop_total"] == float(info["flop"])
+    assert info["model_bytes_total"] > 0
+    t_star = info["model_tmin_hbm_bound"] + info["model_tmin_fp_bound"]
+    assert t_star >= max(info["model_bytes_total"] / 8e12, info["model_flop_total"] / 78.6e12) * (1 - 1e-12)
+    assert t_star <= info["model_bytes_total"] / 8e12 + info["model_flop_total"] / 78.6e12
+    pa.pangulu_finalize(h)
+
+
+def test_task_sampling_hook_runs_a_stated_fraction():
+    """bench.py's cpu_baseline leg: with sampling stride k the checker's build executes every k-th task of each class and
+    reports exactly their structural flops; stride 1 reports the whole factorisation (= the closed form)."""
+    n, cp, ri, va, co = M.shell(14, 12)
+    lib = library_for(oracle_library("r64"))
+    lib.pangulu_amd_test_set_task_sampling.argtypes = [ctypes.c_int]
+    out = {}
+    for stride in (1, 4):
+        lib.pangulu_amd_test_set_task_sampling(stride)
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=32, coords=co, lib=lib)
+        pa.pangulu_gstrf(h)
+        out[stride] = h.info()
+        pa.pangulu_finalize(h)
+    lib.pangulu_amd_test_set_task_sampling(1)
+    full, part = out[1], out[4]
+    ntask = full["ntask_getrf"] + full["ntask_tstrf"] + full["ntask_gessm"] + full["ntask_ssssm"]
+    assert full["sampled_tasks"] == 0 and full["sampled_flop"] == 0  # sampling off: nothing special is recorded
+    assert abs(part["sampled_tasks"] - ntask / 4) <= 4
+    assert 0.1 * full["flop"] < part["sampled_flop"] < 0.5 * full["flop"]

@@ -17,5 +17,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d ${O}_write -o r
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d ${O}_sq -o runc -- $B 2>&1 | grep metric | cut -c1-120
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d ${O}_mfma -o runc -- $B 2>&1 | grep -i metric | cut -c1-120
 cd $R
-python tools/summarize_rocprof.py $O ${O}_fetch ${O}_write ${O}_sq ${O}_mfma --json gpurun_out/${TAG}_hbm_traffic.json > gpurun_out/${TAG}_table.md
+PROFILE_NAME=profiles/${TAG}.md python tools/summarize_rocprof.py $O ${O}_fetch ${O}_write ${O}_sq ${O}_mfma --json gpurun_out/${TAG}_hbm_traffic.json > gpurun_out/${TAG}_table.md
+python tools/critical_path.py $(find $O -name "*kernel_trace.csv" | head -1) > gpurun_out/${TAG}_critical_path.md
 find gpurun_out/prof_${TAG}* -name "*kernel_trace.csv" -delete
+# for the default workload: cp gpurun_out/${TAG}_hbm_traffic.json profiles/hbm_traffic_default_workload.json (bench.py reads it)

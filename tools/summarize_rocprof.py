@@ -56,6 +56,12 @@ def main():
         summary[name] = {"calls": calls, "avg_us": float(r["AverageNs"]) / 1e3, "hbm_bytes_per_launch": fetch + write,
                          "fetch_bytes_per_launch_x2": fetch, "write_bytes_per_launch": write}
     if out_json:
+        # bench.py quotes these per-launch HBM bytes only for the build they were measured on
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+
+        summary["kernel_source_hash"] = bench.kernel_source_hash()
+        summary["profile"] = os.environ.get("PROFILE_NAME", os.path.basename(out_json))
         json.dump(summary, open(out_json, "w"), indent=1)
 
 
