@@ -40,7 +40,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="shell", choices=["shell", "fem27", "poisson", "kkt"])
     ap.add_argument("--size", type=int, nargs="*", default=None, help="generator size arguments (shell: nx ny)")
-    ap.add_argument("--mtx", default=None, help="MatrixMarket file to factorise instead of the synthetic stand-in")
+    ap.add_argument("--mtx", default=None, help="matrix file to factorise instead of the synthetic stand-in: MatrixMarket (.mtx) or the "
+                                                "reference's binary .lid (examples/example.c:112-163)")
+    ap.add_argument("--rhs", default=None, help="right-hand side file (examples/example.c:167-243); default b = A*1")
     ap.add_argument("--nb", type=int, default=256)
     ap.add_argument("--ordering", default="nd", choices=["nd", "identity"])
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
@@ -57,8 +59,8 @@ def parse_args():
 
 def make_matrix(args, M):
     if args.mtx:
-        n, cp, ri, va, co = M.read_mtx(args.mtx)
-        return (n, cp, ri, va, co), "mtx:%s" % os.path.basename(args.mtx)
+        n, cp, ri, va, co = M.read_matrix(args.mtx)
+        return (n, cp, ri, va, co), "file:%s" % os.path.basename(args.mtx)
     size = args.size
     if args.workload == "shell":
         nx, ny = (size + [None, None])[:2] if size else (398, 398)
@@ -306,7 +308,7 @@ def main():
     # end-to-end check of the last factorisation: ||Ax-b||/||b|| with b = A*1 (examples/example.c:252-264,304-364)
     residual = None
     if rank == 0:
-        b = M.rhs_of_ones(n, cp, ri, va)
+        b = M.read_rhs(args.rhs, n) if args.rhs else M.rhs_of_ones(n, cp, ri, va)
     else:
         b = None
     x = pa.pangulu_gstrs(h, b)

@@ -12,9 +12,11 @@
 //     which a single 8-rank communicator with one send and one receive stream per rank would (a cycle of
 //     head-of-line-blocked sends).
 // librccl.so is loaded lazily so the library (and every CPU test) works where RCCL is absent.
-// Before first use every pair exchanges a test pattern in both directions; if initialisation or that self test
-// does not finish within PANGULU_AMD_RCCL_TIMEOUT_S (default 180 s) on any rank, ALL ranks fall back to the
-// host-staged path together and say so.
+// Start-up: the unique ids of all ordered pairs are exchanged over TCP by the calling thread; a helper thread then creates
+// the communicators round by round of a round-robin tournament (disjoint pairs per round: 2 (N - 1) creations per rank,
+// not N (N - 1) in sequence) and sends a test pattern over every directed pair.  If that does not finish within
+// PANGULU_AMD_RCCL_TIMEOUT_S (default 90 s) on any rank, ALL ranks fall back together and say so; the abandoned
+// helper only ever touches RCCL, never the control-plane sockets.
 #include <dlfcn.h>
 
 #define __HIP_PLATFORM_AMD__ 1
@@ -98,106 +100,154 @@ struct RcclComm : SocketComm
     std::vector<ncclComm_t> send_comm, recv_comm; // per peer: (me -> peer) and (peer -> me)
     std::vector<hipStream_t> send_stream, recv_stream;
 
+    std::vector<NcclUniqueId> id_out, id_in; // per peer: id of (me -> peer), made here; id of (peer -> me), made there
+    double init_seconds = 0;
+
     RcclComm(int rank_, int size_, const char *addr, int base_port) : SocketComm(rank_, size_, addr, base_port)
     {
         transport = PANGULU_AMD_TRANSPORT_RCCL;
-        HIPC(hipGetDevice(&device));
+        const bool have_device = hipGetDevice(&device) == hipSuccess; // (a host-memory platform has none: fall back, do not fail)
         send_comm.assign((size_t)size, nullptr);
         recv_comm.assign((size_t)size, nullptr);
         send_stream.assign((size_t)size, nullptr);
         recv_stream.assign((size_t)size, nullptr);
+        id_out.resize((size_t)size);
+        id_in.resize((size_t)size);
         const char *to = getenv("PANGULU_AMD_RCCL_TIMEOUT_S");
-        int timeout_s = to ? atoi(to) : 180;
-        // initialise + self-test on a helper thread so a hang cannot take the run down with it
-        auto fut = std::async(std::launch::async, [this]()
-                              { return init_and_selftest(); });
-        bool ok = false;
-        if (fut.wait_for(std::chrono::seconds(timeout_s)) == std::future_status::ready)
-            ok = fut.get();
-        else
+        int timeout_s = to ? atoi(to) : 90;
+        const double t0 = wall_seconds();
+        // Everything that touches the TCP control plane happens HERE, on the calling thread, before the helper thread
+        // exists: library check, agreement, the unique ids of all my ordered pairs.  The helper thread below only makes
+        // RCCL calls, so abandoning it on a timeout cannot disturb the sockets or the mailbox the scheduler uses later.
+        i64 missing = (have_device && R.load()) ? 0 : 1;
+        if (missing)
+            fprintf(stderr, "[PanguLU-AMD] rank %d: %s\n", rank, have_device ? "librccl.so not found" : "no HIP device for the RCCL transport");
+        for (int p = 0; p < size && !missing; p++)
+            if (p != rank && R.GetUniqueId(&id_out[(size_t)p]) != 0)
+                missing = 1;
+        allreduce_sum_i64(&missing, 1);
+        bool ok = missing == 0;
+        if (ok)
         {
-            fprintf(stderr, "[PanguLU-AMD] rank %d: RCCL initialisation did not finish within %d s\n", rank, timeout_s);
-            // the helper thread is abandoned; leak the future so its destructor does not join
-            new std::future<bool>(std::move(fut));
+            // (128-byte messages: they fit the socket buffers, so everybody can send first and receive afterwards)
+            for (int p = 0; p < size; p++)
+                if (p != rank)
+                    send_bytes(p, TAG_NCCL_ID, &id_out[(size_t)p], sizeof(NcclUniqueId));
+            for (int p = 0; p < size; p++)
+                if (p != rank)
+                    recv_bytes(p, TAG_NCCL_ID, &id_in[(size_t)p], sizeof(NcclUniqueId));
+            // communicators + self-test on a helper thread so that a hang inside RCCL cannot take the run down with it
+            auto fut = std::async(std::launch::async, [this]()
+                                  { return init_and_selftest(); });
+            if (fut.wait_for(std::chrono::seconds(timeout_s)) == std::future_status::ready)
+                ok = fut.get();
+            else
+            {
+                ok = false;
+                fprintf(stderr, "[PanguLU-AMD] rank %d: RCCL initialisation did not finish within %d s\n", rank, timeout_s);
+                // the helper thread is abandoned inside RCCL; leak the future so its destructor does not join
+                new std::future<bool>(std::move(fut));
+            }
         }
         // all ranks must agree (over TCP, which works regardless)
         i64 flag = ok ? 0 : 1;
         allreduce_sum_i64(&flag, 1);
         rccl_ok = flag == 0;
+        init_seconds = wall_seconds() - t0;
         if (!rccl_ok)
         {
             transport = PANGULU_AMD_TRANSPORT_HOST;
             if (rank == 0)
                 fprintf(stderr, "[PanguLU-AMD] RCCL transport unavailable on %lld rank(s): falling back to host-staged block exchange\n", (long long)flag);
         }
+        else if (rank == 0)
+            fprintf(stderr, "[PanguLU-AMD] RCCL transport: %d ranks, %d two-rank communicators per rank, self-test passed, %.1f s\n", size,
+                    2 * (size - 1), init_seconds);
     }
 
+    // partner of `r` in round `round` of a round-robin tournament over m = size rounded up to even (circle method);
+    // returns -1 when r sits the round out.  Every rank meets every other exactly once, and in one round all pairs are
+    // disjoint -- so the communicators of a round are created concurrently and nobody waits for a rank that is busy
+    // with somebody else.
+    int partner_in_round(int r, int round) const
+    {
+        const int m = size + (size & 1);
+        int p;
+        if (r == m - 1)
+            p = round;
+        else if (r == round)
+            p = m - 1;
+        else
+            p = ((2 * round - r) % (m - 1) + (m - 1)) % (m - 1);
+        return (p >= size || p == r) ? -1 : p;
+    }
+
+    // RCCL calls only (see the constructor)
     bool init_and_selftest()
     {
-        if (!R.load())
-        {
-            fprintf(stderr, "[PanguLU-AMD] rank %d: librccl.so not found\n", rank);
-            return false;
-        }
         if (hipSetDevice(device) != hipSuccess)
             return false;
-        // communicators in one global order over ordered pairs (i, j): no rank can wait on a pair another rank
-        // has not reached yet
-        for (int i = 0; i < size; i++)
-            for (int j = 0; j < size; j++)
+        const int m = size + (size & 1);
+        for (int round = 0; round < m - 1; round++)
+        {
+            const int p = partner_in_round(rank, round);
+            if (p < 0)
+                continue;
+            // both sides create (low -> high) first, then (high -> low): sender is rank 0 of the two-rank communicator
+            for (int dir = 0; dir < 2; dir++)
             {
-                if (i == j || (rank != i && rank != j))
-                    continue;
-                NcclUniqueId id;
-                if (rank == i)
+                const bool i_send = (dir == 0) == (rank < p);
+                if (i_send)
                 {
-                    if (R.GetUniqueId(&id) != 0)
+                    if (R.CommInitRank(&send_comm[(size_t)p], 2, id_out[(size_t)p], 0) != 0)
                         return false;
-                    send_bytes(j, TAG_NCCL_ID, &id, sizeof(id));
-                    if (R.CommInitRank(&send_comm[(size_t)j], 2, id, 0) != 0)
-                        return false;
-                    if (hipStreamCreateWithFlags(&send_stream[(size_t)j], hipStreamNonBlocking) != hipSuccess)
+                    if (hipStreamCreateWithFlags(&send_stream[(size_t)p], hipStreamNonBlocking) != hipSuccess)
                         return false;
                 }
                 else
                 {
-                    recv_bytes(i, TAG_NCCL_ID, &id, sizeof(id));
-                    if (R.CommInitRank(&recv_comm[(size_t)i], 2, id, 1) != 0)
+                    if (R.CommInitRank(&recv_comm[(size_t)p], 2, id_in[(size_t)p], 1) != 0)
                         return false;
-                    if (hipStreamCreateWithFlags(&recv_stream[(size_t)i], hipStreamNonBlocking) != hipSuccess)
+                    if (hipStreamCreateWithFlags(&recv_stream[(size_t)p], hipStreamNonBlocking) != hipSuccess)
                         return false;
                 }
             }
-        // self test: 1 MiB pattern over every directed pair, same global order
+        }
+        // self test: a 1 MiB pattern over every directed pair, in the same tournament order
         const size_t N = 1 << 20;
         unsigned char *dbuf = nullptr;
         if (hipMalloc((void **)&dbuf, N) != hipSuccess)
             return false;
         std::vector<unsigned char> host(N);
         bool good = true;
-        for (int i = 0; i < size && good; i++)
-            for (int j = 0; j < size && good; j++)
+        for (int round = 0; round < m - 1 && good; round++)
+        {
+            const int p = partner_in_round(rank, round);
+            if (p < 0)
+                continue;
+            for (int dir = 0; dir < 2 && good; dir++)
             {
-                if (i == j || (rank != i && rank != j))
-                    continue;
-                if (rank == i)
+                const bool i_send = (dir == 0) == (rank < p);
+                const int i = i_send ? rank : p, j = i_send ? p : rank;
+                if (i_send)
                 {
                     for (size_t k = 0; k < N; k++)
                         host[k] = (unsigned char)((k * 131 + (size_t)i * 7 + (size_t)j) & 0xff);
                     good = hipMemcpy(dbuf, host.data(), N, hipMemcpyHostToDevice) == hipSuccess &&
-                           R.Send(dbuf, N, NCCL_CHAR, 1, send_comm[(size_t)j], send_stream[(size_t)j]) == 0 &&
-                           hipStreamSynchronize(send_stream[(size_t)j]) == hipSuccess;
+                           R.Send(dbuf, N, NCCL_CHAR, 1, send_comm[(size_t)p], send_stream[(size_t)p]) == 0 &&
+                           hipStreamSynchronize(send_stream[(size_t)p]) == hipSuccess;
                 }
                 else
                 {
                     good = hipMemset(dbuf, 0, N) == hipSuccess &&
-                           R.Recv(dbuf, N, NCCL_CHAR, 0, recv_comm[(size_t)i], recv_stream[(size_t)i]) == 0 &&
-                           hipStreamSynchronize(recv_stream[(size_t)i]) == hipSuccess &&
+                           R.Recv(dbuf, N, NCCL_CHAR, 0, recv_comm[(size_t)p], recv_stream[(size_t)p]) == 0 &&
+                           hipStreamSynchronize(recv_stream[(size_t)p]) == hipSuccess &&
                            hipMemcpy(host.data(), dbuf, N, hipMemcpyDeviceToHost) == hipSuccess;
                     for (size_t k = 0; k < N && good; k++)
                         good = host[k] == (unsigned char)((k * 131 + (size_t)i * 7 + (size_t)j) & 0xff);
                 }
             }
+        }
         (void)hipFree(dbuf);
         return good;
     }

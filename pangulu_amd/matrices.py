@@ -140,6 +140,65 @@ def read_mtx(path, dtype=np.float64):
     return _finish(sp.csc_matrix(A), dtype, None)
 
 
+def read_lid(path, dtype=np.float64):
+    """The reference's binary matrix format (examples/example.c:112-163): `m, n` as u32, `nnz` as u64, then a CSR
+    matrix -- row pointer u64 x (n+1), column index u32 x nnz, values x nnz in the library's value type."""
+    import os
+
+    dtype = np.dtype(dtype)
+    with open(path, "rb") as f:
+        m, n = np.fromfile(f, dtype=np.uint32, count=2)
+        nnz = int(np.fromfile(f, dtype=np.uint64, count=1)[0])
+        rowptr = np.fromfile(f, dtype=np.uint64, count=int(n) + 1)
+        colidx = np.fromfile(f, dtype=np.uint32, count=nnz)
+        values = np.fromfile(f, dtype=dtype, count=nnz)
+    expected = 16 + 8 * (int(n) + 1) + (4 + dtype.itemsize) * nnz  # (the format does not name its value type: the size must)
+    if len(rowptr) != int(n) + 1 or len(colidx) != nnz or len(values) != nnz or int(rowptr[-1]) != nnz or os.path.getsize(path) != expected:
+        raise ValueError("%s is not a .lid file for value type %s (truncated, or written for another type)" % (path, dtype))
+    A = sp.csr_matrix((values, colidx.astype(np.int64), rowptr.astype(np.int64)), shape=(int(m), int(n)))
+    return _finish(A.tocsc(), dtype, None)
+
+
+def write_lid(path, n, colptr, rowidx, values):
+    """Writes a CSC matrix in the reference's .lid layout (CSR on disk)."""
+    A = to_scipy(n, colptr, rowidx, values).tocsr()
+    A.sort_indices()
+    with open(path, "wb") as f:
+        np.array([n, n], dtype=np.uint32).tofile(f)
+        np.array([A.nnz], dtype=np.uint64).tofile(f)
+        A.indptr.astype(np.uint64).tofile(f)
+        A.indices.astype(np.uint32).tofile(f)
+        A.data.astype(values.dtype).tofile(f)
+
+
+def read_matrix(path, dtype=np.float64):
+    """By the last letter of the name, as examples/example.c:100-163 does: ...x -> MatrixMarket, ...d -> .lid."""
+    if path.endswith("d"):
+        return read_lid(path, dtype)
+    return read_mtx(path, dtype)
+
+
+def read_rhs(path, n, dtype=np.float64):
+    """Right-hand side file of examples/example.c:167-243: '%' comment lines, the length, then one value per line
+    (two numbers, real and imaginary part, for complex types)."""
+    dtype = np.dtype(dtype)
+    with open(path) as f:
+        lines = [ln for ln in f if ln.strip() and not ln.lstrip().startswith("%")]
+    if not lines:
+        raise ValueError("%s contains only comments or is empty" % path)
+    length = int(lines[0].split()[0])
+    if length != n:
+        raise ValueError("vector dimension mismatch - expected %d, got %d" % (n, length))
+    tok = " ".join(lines[1:]).split()
+    per = 2 if np.issubdtype(dtype, np.complexfloating) else 1
+    if len(tok) < per * n:
+        raise ValueError("failed to read vector element %d from %s" % (len(tok) // per, path))
+    v = np.array(tok[:per * n], dtype=np.float64)
+    if per == 2:
+        v = v[0::2] + 1j * v[1::2]
+    return v.astype(dtype)
+
+
 def rhs_of_ones(n, colptr, rowidx, values):
     """b = A * 1, the right-hand side examples/example.c:252-264 builds."""
     return np.asarray(to_scipy(n, colptr, rowidx, values).sum(axis=1)).ravel().astype(values.dtype)

@@ -207,3 +207,40 @@ def test_task_sampling_hook_runs_a_stated_fraction():
     assert full["sampled_tasks"] == 0 and full["sampled_flop"] == 0  # sampling off: nothing special is recorded
     assert abs(part["sampled_tasks"] - ntask / 4) <= 4
     assert 0.1 * full["flop"] < part["sampled_flop"] < 0.5 * full["flop"]
+
+
+@pytest.mark.parametrize("vtype", ["r64", "cr64", "r32"])
+def test_lid_and_rhs_files_round_trip(tmp_path, vtype):
+    """The reference's on-disk inputs (examples/example.c:112-163 binary .lid, :167-243 rhs text): written, read back,
+    solved -- and the reader refuses a file written for another value type."""
+    dt = _lib.VALUE_TYPES[vtype][0]
+    n, cp, ri, va, _ = M.random_pattern(120, 0.05, 5, dtype=dt)
+    path = str(tmp_path / "a.lid")
+    M.write_lid(path, n, cp, ri, va)
+    n2, cp2, ri2, va2, _ = M.read_matrix(path, dt)
+    assert n2 == n and (cp2 == cp).all() and (ri2 == ri).all() and (va2 == va).all()
+    # header as the reference reads it: u32 m, u32 n, u64 nnz
+    raw = open(path, "rb").read(16)
+    assert np.frombuffer(raw, np.uint32, 2).tolist() == [n, n] and int(np.frombuffer(raw, np.uint64, 1, 8)[0]) == len(va)
+    other = np.float32 if np.dtype(dt).itemsize != 4 else np.float64
+    with pytest.raises(ValueError):
+        M.read_lid(path, other)
+    rng = np.random.default_rng(1)
+    b = rng.uniform(-1, 1, n).astype(dt)
+    if np.issubdtype(dt, np.complexfloating):
+        b = b + 1j * rng.uniform(-1, 1, n).astype(dt)
+    rhs = str(tmp_path / "b.rhs")
+    with open(rhs, "w") as f:
+        f.write("%% a comment line\n%d\n" % n)
+        for v in b:
+            f.write(("%.17e %.17e\n" % (v.real, v.imag)) if np.issubdtype(dt, np.complexfloating) else ("%.17e\n" % v))
+    b2 = M.read_rhs(rhs, n, dt)
+    assert np.abs(b2 - b).max() <= (1e-15 if vtype in ("r64", "cr64") else 1e-7)
+    with pytest.raises(ValueError):
+        M.read_rhs(rhs, n + 1, dt)
+    lib = library_for(oracle_library(vtype), vtype)
+    h = pa.pangulu_init(n2, len(va2), cp2, ri2, va2, nb=32, vtype=vtype, ordering="identity", lib=lib)
+    pa.pangulu_gstrf(h)
+    x = pa.pangulu_gstrs(h, b2)
+    pa.pangulu_finalize(h)
+    assert M.relative_residual(n, cp, ri, va, x, b2) < (1e-12 if vtype in ("r64", "cr64") else 1e-4)

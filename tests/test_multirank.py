@@ -173,3 +173,36 @@ def test_multirank_cr64_on_the_gpu_peer_copies(tmp_path):
     U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
     assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
     assert float(z["residual"]) < 1e-13
+
+
+def test_rccl_transport_falls_back_on_a_host_memory_platform(tmp_path):
+    """Requesting RCCL where there is no device (the CPU oracle platform): all ranks agree over the control plane and
+    degrade to host staging together."""
+    from pangulu_amd import _lib
+
+    out = str(tmp_path / "out.npz")
+    run_ranks(3, "fem27_6", 32, out, transport="rccl")
+    z = np.load(out)
+    assert int(z["transport"]) == _lib.TRANSPORT_HOST
+    assert float(z["residual"]) < 1e-13
+
+
+@pytest.mark.gpu
+def test_rccl_transport_on_a_shared_gpu_degrades_without_hanging(tmp_path):
+    """On the one-GPU test box two ranks share the device, which RCCL refuses ("Duplicate GPU detected"): the ids are
+    exchanged, the helper thread's communicator creation fails or times out, every rank falls back and the factorisation is
+    still right.  (The working RCCL path needs two devices: the driver's multi-GPU bench reports config.transport.)"""
+    from pangulu_amd import _lib
+
+    out = str(tmp_path / "out.npz")
+    os.environ["PANGULU_AMD_RCCL_TIMEOUT_S"] = "30"
+    try:
+        run_ranks(2, "fem27_6", 32, out, platform="hip", transport="rccl")
+    finally:
+        del os.environ["PANGULU_AMD_RCCL_TIMEOUT_S"]
+    z = np.load(out)
+    assert int(z["transport"]) in (_lib.TRANSPORT_HOST, _lib.TRANSPORT_RCCL)
+    ref = factorize(GENS["fem27_6"](), 32, oracle_library("r64"), ordering="nd")
+    n = len(z["L_ptr"]) - 1
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and float(z["residual"]) < 1e-13
