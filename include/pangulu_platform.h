@@ -260,6 +260,21 @@ extern "C"
     void *pangulu_platform_0201001_marker_record(void);
     int pangulu_platform_0201001_marker_done(void *marker);  /* 1 when everything before the marker has completed */
     void pangulu_platform_0201001_marker_wait(void *marker);
+    /* Optional: level-scheduled block triangular solve for pangulu_gstrs on one rank, on the device-resident factors (no
+     * download): the reference makes one spmv / sptrsv platform call per block, on its CPU platform
+     * (src/pangulu_sptrsv.c:62,94,126,159); this call sweeps all levels of the block dependency graph, one launch per
+     * level.  `x` is a HOST vector of `xlen` values, overwritten with the solution of the sweep (upper = 0: L, unit
+     * diagonal; 1: U).  rows[level_ptr[l] .. level_ptr[l+1]) are the block rows of level l, `diag` their diagonal half
+     * (lower / upper), blk_slots / blk_bcol[first .. first + nblk) their off-diagonal blocks on the sweep's side. */
+    typedef struct pangulu_hip_solve_row_t
+    {
+        pangulu_exblock_idx brow, nblk;
+        pangulu_uint64_t first;
+        pangulu_storage_slot_t *diag;
+    } pangulu_hip_solve_row_t;
+    void pangulu_platform_0201001_block_trsv(pangulu_inblock_idx nb, int upper, pangulu_uint64_t nlevel, const pangulu_uint64_t *level_ptr,
+                                             const pangulu_hip_solve_row_t *rows, pangulu_storage_slot_t *const *blk_slots,
+                                             const pangulu_exblock_idx *blk_bcol, calculate_type *x, pangulu_uint64_t xlen);
     /* stream all numeric kernels are launched on (a hipStream_t); for event timing in bench.py */
     void *pangulu_platform_0201001_get_stream(void);
     /* Cumulative per-kernel-class counters since the last reset.  Classes: 1 GETRF, 2 TSTRF, 3 GESSM,

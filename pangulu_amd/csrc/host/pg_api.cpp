@@ -71,6 +71,7 @@ void bind_builtin_hip(Platform &p)
     p.marker_record = pangulu_platform_0201001_marker_record;
     p.marker_done = pangulu_platform_0201001_marker_done;
     p.marker_wait = pangulu_platform_0201001_marker_wait;
+    p.block_trsv = pangulu_platform_0201001_block_trsv;
 }
 
 Platform &active_platform()

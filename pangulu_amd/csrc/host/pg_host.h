@@ -72,6 +72,8 @@ struct Platform
     void *(*marker_record)() = nullptr;
     int (*marker_done)(void *) = nullptr;
     void (*marker_wait)(void *) = nullptr;
+    void (*block_trsv)(pangulu_inblock_idx, int, pangulu_uint64_t, const pangulu_uint64_t *, const pangulu_hip_solve_row_t *, slot_t *const *,
+                       const pangulu_exblock_idx *, val_t *, pangulu_uint64_t) = nullptr;
 };
 Platform &active_platform();               // built-in HIP unless the test hook replaced it
 bool platform_is_builtin_hip();

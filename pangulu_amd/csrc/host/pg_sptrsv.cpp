@@ -73,8 +73,76 @@ void block_upper_solve(u32 nb, const slot_t *u, val_t *x)
 
 } // namespace
 
+// Single rank on a device: both sweeps on the device-resident factors (no download of the factors), level by level of the
+// block dependency graph -- pangulu_platform_0201001_block_trsv.  PANGULU_AMD_DEVICE_SOLVE=0 keeps the host sweep.
+static bool device_solve(Solver &S, val_t *rhs)
+{
+    Platform &plat = active_platform();
+    const char *e = getenv("PANGULU_AMD_DEVICE_SOLVE");
+    if (S.nproc != 1 || plat.host_memory || !plat.block_trsv || (e && atoi(e) == 0))
+        return false;
+    const BlockPattern &P = S.pat;
+    const u32 nb = S.nb, nbk = S.nbk;
+    std::vector<val_t> x((size_t)nbk * nb, vmake(0));
+    std::copy(rhs, rhs + S.n, x.begin());
+    for (int pass = 0; pass < 2; pass++)
+    {
+        const bool lower = pass == 0;
+        // level of a block row = 1 + the highest level among the rows its off-diagonal blocks (on the sweep's side) read
+        std::vector<u32> level(nbk, 0);
+        u32 nlevel = 0;
+        for (u32 step = 0; step < nbk; step++)
+        {
+            const u32 brow = lower ? step : nbk - 1 - step;
+            const u64 rb = lower ? P.rowptr[brow] : P.first_after_diag_csr[brow];
+            const u64 re = lower ? P.first_after_diag_csr[brow] : P.rowptr[brow + 1];
+            u32 lv = 0;
+            for (u64 r = rb; r < re; r++)
+                lv = std::max(lv, level[P.colidx[r]] + 1);
+            level[brow] = lv;
+            nlevel = std::max(nlevel, lv + 1);
+        }
+        std::vector<pangulu_uint64_t> level_ptr((size_t)nlevel + 1, 0);
+        for (u32 k = 0; k < nbk; k++)
+            level_ptr[level[k] + 1]++;
+        for (u32 l = 0; l < nlevel; l++)
+            level_ptr[l + 1] += level_ptr[l];
+        std::vector<pangulu_hip_solve_row_t> rows(nbk);
+        std::vector<slot_t *> blk_slots;
+        std::vector<pangulu_exblock_idx> blk_bcol;
+        std::vector<pangulu_uint64_t> cur(level_ptr.begin(), level_ptr.end() - 1);
+        for (u32 brow = 0; brow < nbk; brow++)
+        {
+            pangulu_hip_solve_row_t R;
+            R.brow = brow;
+            R.first = blk_slots.size();
+            R.diag = lower ? S.diag_lower[brow] : S.diag_upper[brow];
+            const u64 rb = lower ? P.rowptr[brow] : P.first_after_diag_csr[brow];
+            const u64 re = lower ? P.first_after_diag_csr[brow] : P.rowptr[brow + 1];
+            for (u64 r = rb; r < re; r++)
+            {
+                blk_slots.push_back(S.slot_of[P.csr_to_csc[r]]);
+                blk_bcol.push_back(P.colidx[r]);
+            }
+            R.nblk = (pangulu_exblock_idx)(blk_slots.size() - R.first);
+            rows[cur[level[brow]]++] = R;
+        }
+        if (blk_slots.empty())
+        {
+            blk_slots.push_back(nullptr);
+            blk_bcol.push_back(0);
+        }
+        plat.block_trsv((pangulu_inblock_idx)nb, lower ? 0 : 1, nlevel, level_ptr.data(), rows.data(), blk_slots.data(), blk_bcol.data(), x.data(),
+                        (pangulu_uint64_t)x.size());
+    }
+    std::copy(x.begin(), x.begin() + S.n, rhs);
+    return true;
+}
+
 void triangular_solve(Solver &S, val_t *rhs)
 {
+    if (device_solve(S, rhs))
+        return;
     download_factors(S);
     Comm *comm = world();
     const BlockPattern &P = S.pat;

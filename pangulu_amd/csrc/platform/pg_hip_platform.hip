@@ -1489,6 +1489,121 @@ __global__ void sptrsv_kernel(int nb, const u32 *ptr, const u16 *idx, const val_
 namespace
 {
 
+// -----------------------------------------------------------------------------------------------------------------
+// Level-scheduled block triangular solve for pangulu_gstrs on a single rank (pangulu_platform_0201001_block_trsv).
+// The reference sweeps block row by block row with one spmv / sptrsv platform call per block on the CPU platform
+// (src/pangulu_sptrsv.c:24-191); here block rows whose inputs are final form a LEVEL of the block dependency graph and one
+// launch handles a whole level: one workgroup per block row gathers  seg -= sum_j A(row, j) x_j  over the row's
+// off-diagonal blocks into LDS (floating-point LDS atomics), solves with the row's diagonal half there, and writes the
+// finished segment.  Same per-block arithmetic as ...0100000.c:435-506 (spmv, unit-lower column sweep, upper row sweep
+// with the PANGULU_SPTRSV_TOL clamp); sums across blocks arrive in a different order.
+// -----------------------------------------------------------------------------------------------------------------
+struct SolveBlkD
+{
+    const u32 *cp; // CSC
+    const u16 *ri;
+    const val_t *val;
+    u32 bcol;
+    u32 pad_;
+};
+struct SolveRowD
+{
+    u32 brow, nblk;
+    unsigned long long first; // into the SolveBlkD array
+    const u32 *dptr;          // diagonal half: lower = strictly-lower CSC column pointer, upper = CSR row pointer (diagonal first)
+    const u16 *didx;
+    const val_t *dval;
+};
+
+template <bool UPPER>
+__global__ __launch_bounds__(256) void block_trsv_level_kernel(const SolveRowD *__restrict__ rows, const SolveBlkD *__restrict__ blks, int nb,
+                                                               val_t *__restrict__ x)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    val_t *seg = reinterpret_cast<val_t *>(smem_raw);
+    const SolveRowD R = rows[blockIdx.x];
+    val_t *xr = x + (size_t)R.brow * nb;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
+        seg[i] = xr[i];
+    __syncthreads();
+    // seg -= A(row, j) x_j: a quarter wavefront per column of the block, entries of the column over its 16 lanes
+    const int sub = threadIdx.x >> 4, l16 = threadIdx.x & 15, nsub = blockDim.x >> 4;
+    for (u32 b = 0; b < R.nblk; b++)
+    {
+        const SolveBlkD B = blks[R.first + b];
+        const val_t *xj = x + (size_t)B.bcol * nb;
+        for (int c = sub; c < nb; c += nsub)
+        {
+            const u32 p0 = ptr0(B.cp, c), p1 = B.cp[c + 1];
+            if (p0 == p1)
+                continue;
+            const val_t xc = xj[c];
+            for (u32 p = p0 + l16; p < p1; p += 16)
+                lds_atomic_sub(&seg[B.ri[p]], v_mul(B.val[p], xc));
+        }
+    }
+    __syncthreads();
+    // the diagonal half, by one wavefront (LDS operations of a wavefront complete in order: no barriers in the sweep)
+    if (threadIdx.x < 64)
+    {
+        const int lane = threadIdx.x;
+        if (!UPPER)
+        {
+            for (int c = 0; c < nb; c++)
+            {
+                const u32 p0 = ptr0(R.dptr, c), p1 = R.dptr[c + 1];
+                if (p0 == p1)
+                    continue;
+                const val_t xc = seg[c];
+                for (u32 p = p0 + lane; p < p1; p += 64)
+                    seg[R.didx[p]] = v_submul(seg[R.didx[p]], R.dval[p], xc);
+                wave_lds_fence();
+            }
+        }
+        else
+        {
+            for (int r = nb - 1; r >= 0; r--)
+            {
+                const u32 b = R.dptr[r], e = R.dptr[r + 1];
+                if (b == e)
+                    continue;
+#ifdef PANGULU_COMPLEX
+                val_t part = v_make(0);
+                for (u32 p = b + 1 + lane; p < e; p += 64)
+                {
+                    const val_t m = v_mul(R.dval[p], seg[R.didx[p]]);
+                    part.re += m.re;
+                    part.im += m.im;
+                }
+                for (int off = 32; off > 0; off >>= 1)
+                {
+                    part.re += __shfl_down(part.re, off, 64);
+                    part.im += __shfl_down(part.im, off, 64);
+                }
+#else
+                val_t part = 0;
+                for (u32 p = b + 1 + lane; p < e; p += 64)
+                    part += R.dval[p] * seg[R.didx[p]];
+                for (int off = 32; off > 0; off >>= 1)
+                    part += __shfl_down(part, off, 64);
+#endif
+                if (lane == 0)
+                {
+                    val_t d = R.dval[b];
+                    const real_t dr = v_realpart(d);
+                    if (!((dr < 0 ? -dr : dr) > (real_t)PANGULU_SPTRSV_TOL))
+                        d = v_make((real_t)PANGULU_SPTRSV_TOL);
+                    seg[r] = v_div(v_sub(seg[r], part), d);
+                }
+                wave_lds_fence();
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
+        xr[i] = seg[i];
+}
+
 struct DiagAux // column view of a diagonal block's upper (CSR) half, built on first use
 {
     u32 *d_cp = nullptr;
@@ -2972,6 +3087,70 @@ extern "C"
         default:
             return 1;
         }
+    }
+
+    // Level-scheduled block triangular solve (see block_trsv_level_kernel).  `x` is a HOST vector of nbk*nb values: copied
+    // to the device, swept forward (L, unit diagonal) or backward (U), copied back.  rows[level_ptr[l] .. level_ptr[l+1]) are
+    // the block rows of level l; row r's off-diagonal blocks are blk_slots / blk_bcol[rows[r].first .. + rows[r].nblk).
+    void pangulu_platform_0201001_block_trsv(pangulu_inblock_idx nb, int upper, pangulu_uint64_t nlevel, const pangulu_uint64_t *level_ptr,
+                                             const pangulu_hip_solve_row_t *rows, pangulu_storage_slot_t *const *blk_slots,
+                                             const pangulu_exblock_idx *blk_bcol, calculate_type *x, pangulu_uint64_t xlen)
+    {
+        ensure_ready();
+        std::lock_guard<std::mutex> g(B.mutex);
+        HIP_CHECK(hipSetDevice(B.device));
+        join_records(B.stream); // the sparse records of finished blocks are written on the records stream
+        const size_t nrow = (size_t)level_ptr[nlevel];
+        size_t nblk = 0;
+        for (size_t r = 0; r < nrow; r++)
+            nblk = std::max(nblk, (size_t)(rows[r].first + rows[r].nblk));
+        std::vector<SolveRowD> hr(nrow);
+        std::vector<SolveBlkD> hb(std::max<size_t>(nblk, 1));
+        for (size_t r = 0; r < nrow; r++)
+        {
+            const slot_t *d = rows[r].diag;
+            hr[r].brow = rows[r].brow;
+            hr[r].nblk = rows[r].nblk;
+            hr[r].first = rows[r].first;
+            hr[r].dptr = upper ? d->d_rowpointer : d->d_columnpointer;
+            hr[r].didx = upper ? d->d_columnindex : d->d_rowindex;
+            hr[r].dval = d->d_value;
+        }
+        for (size_t b = 0; b < nblk; b++)
+        {
+            const slot_t *sb = blk_slots[b];
+            hb[b].cp = sb->d_columnpointer;
+            hb[b].ri = sb->d_rowindex;
+            hb[b].val = sb->d_value;
+            hb[b].bcol = blk_bcol[b];
+            hb[b].pad_ = 0;
+        }
+        SolveRowD *d_rows = nullptr;
+        SolveBlkD *d_blks = nullptr;
+        val_t *d_x = nullptr;
+        HIP_CHECK(hipMalloc((void **)&d_rows, sizeof(SolveRowD) * std::max<size_t>(nrow, 1)));
+        HIP_CHECK(hipMalloc((void **)&d_blks, sizeof(SolveBlkD) * hb.size()));
+        HIP_CHECK(hipMalloc((void **)&d_x, sizeof(val_t) * (size_t)xlen));
+        HIP_CHECK(hipMemcpyAsync(d_rows, hr.data(), sizeof(SolveRowD) * nrow, hipMemcpyHostToDevice, B.stream));
+        HIP_CHECK(hipMemcpyAsync(d_blks, hb.data(), sizeof(SolveBlkD) * hb.size(), hipMemcpyHostToDevice, B.stream));
+        HIP_CHECK(hipMemcpyAsync(d_x, x, sizeof(val_t) * (size_t)xlen, hipMemcpyHostToDevice, B.stream));
+        const size_t lds = sizeof(val_t) * (size_t)nb;
+        for (size_t l = 0; l < (size_t)nlevel; l++)
+        {
+            const size_t n = (size_t)(level_ptr[l + 1] - level_ptr[l]);
+            if (!n)
+                continue;
+            if (upper)
+                hipLaunchKernelGGL(block_trsv_level_kernel<true>, dim3((unsigned)n), dim3(256), lds, B.stream, d_rows + level_ptr[l], d_blks, (int)nb, d_x);
+            else
+                hipLaunchKernelGGL(block_trsv_level_kernel<false>, dim3((unsigned)n), dim3(256), lds, B.stream, d_rows + level_ptr[l], d_blks, (int)nb, d_x);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(x, d_x, sizeof(val_t) * (size_t)xlen, hipMemcpyDeviceToHost, B.stream));
+        HIP_CHECK(hipStreamSynchronize(B.stream));
+        HIP_CHECK(hipFree(d_rows));
+        HIP_CHECK(hipFree(d_blks));
+        HIP_CHECK(hipFree(d_x));
     }
 
     void *pangulu_platform_0201001_get_stream(void)

@@ -93,3 +93,27 @@ def test_other_value_types_nb128(vtype, gen, nb):
     assert gpu["residual"] <= (1e-12 if vtype == "cr64" else 5e-5)
     assert abs(gpu["residual"] - ref["residual"]) <= (1e-10 if vtype == "cr64" else 5e-5)
     assert lu_check(mat, gpu) <= (1e-12 if vtype == "cr64" else 5e-5)
+
+
+@pytest.mark.parametrize("vtype,gen,nb", [
+    ("r64", lambda dt: M.shell(40, 40, dtype=dt), 256),
+    ("r64", lambda dt: M.kkt(8, dtype=dt), 64),
+    ("cr64", lambda dt: M.poisson3d(12, dtype=dt, shift=0.5j), 128),
+    ("r32", lambda dt: M.fem27(10, dtype=dt), 64),
+], ids=["r64_shell40", "r64_kkt8", "cr64_poisson12", "r32_fem27_10"])
+def test_device_solve_matches_host_sweep(vtype, gen, nb, monkeypatch):
+    """pangulu_gstrs on one rank runs both sweeps on the device-resident factors, level by level
+    (pangulu_platform_0201001_block_trsv); the reference-style host sweep (src/pangulu_sptrsv.c:24-191) on downloaded
+    factors must give the same solution to rounding, and both the oracle's."""
+    dt = _lib.VALUE_TYPES[vtype][0]
+    mat = gen(dt)
+    monkeypatch.setenv("PANGULU_AMD_DEVICE_SOLVE", "1")
+    dev = factorize(mat, nb, "hip", vtype=vtype, keep_factors=False)
+    monkeypatch.setenv("PANGULU_AMD_DEVICE_SOLVE", "0")
+    host = factorize(mat, nb, "hip", vtype=vtype, keep_factors=False)
+    ref = factorize(mat, nb, oracle_library(vtype), vtype=vtype, keep_factors=False)
+    tol = 1e-11 if vtype in ("r64", "cr64") else 2e-4
+    scale = np.abs(ref["x"]).max()
+    assert np.abs(dev["x"] - host["x"]).max() <= tol * scale
+    assert np.abs(dev["x"] - ref["x"]).max() <= tol * scale
+    assert dev["residual"] <= (1e-12 if vtype in ("r64", "cr64") else 5e-5)
