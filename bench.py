@@ -238,6 +238,8 @@ def main():
         lib.pangulu_amd_comm_allreduce_max_f64(tsum.ctypes.data_as(ctypes.c_void_p), 1)
     ms_per_step = float(tsum[0]) / max(1, args.steps) * 1e3
     info = h.info()
+    used = ctypes.c_size_t(0)
+    lib.pangulu_platform_0201001_get_device_memory_usage(ctypes.byref(used))  # records + receive bins + mirror pool + snapshot
     stats_timed = pa.hip_stats(lib, reset=True)
 
     default_workload = (not args.mtx and args.workload == "shell" and not args.size and args.nb == 256 and args.ordering == "nd")
@@ -345,6 +347,7 @@ def main():
             },
             "residual": residual,
             "init_s": round(t_init, 2),
+            "hbm_used_GB": round(used.value / 1e9, 2), "owned_records_GB": round(info["owned_bytes"] / 1e9, 2),
             "host_sched_s_last_step": round(info["time_numeric_host_sched"], 4),
             "batches_per_step": int(info["batches"]),
             "roofline": roofline,

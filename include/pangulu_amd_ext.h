@@ -57,6 +57,13 @@ extern "C"
     /* 0 (default): device-resident numeric phase, factors downloaded once when gstrs / block export needs
      * them.  1: reference behaviour, every finished panel block is copied back to the host at once. */
     void pangulu_amd_set_eager_host_mirror(int on);
+    /* 1: before the fill-reducing ordering, permute columns and scale rows and columns so that the diagonal entries have
+     * modulus 1 and no entry is larger (maximum-product matching; what the reference does when built with its MC64 port,
+     * src/pangulu_reordering.c:1150-1173) -- for matrices with small or zero diagonal entries (KKT systems), which a
+     * factorisation without pivoting cannot take as they are.  pangulu_gstrs applies the scalings and the permutation
+     * to b and x.  Default 0 (the reference's default build has no MC64 either); environment PANGULU_AMD_SCALING
+     * overrides.  A structurally singular input leaves the matrix unscaled, with a warning. */
+    void pangulu_amd_set_scaling(int on);
 
     /* ---- introspection -------------------------------------------------------------------------------- */
     typedef struct pangulu_amd_info_t

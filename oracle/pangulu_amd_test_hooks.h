@@ -15,6 +15,9 @@ extern "C"
 #endif
     /* so_path must export pangulu_platform_<7-digit id>_<name> for the 21 names of build_helper.py:8-32.  0 on success. */
     int pangulu_amd_use_platform_library(const char *so_path, unsigned int platform_id);
+    /* the host's maximum-product matching + scaling (pg_scaling.cpp) on a bare CSC matrix: column matched to every row, Dr, Dc */
+    int pangulu_amd_test_matching(unsigned int n, const unsigned long long *colptr, const unsigned int *rowidx, const void *value,
+                                  unsigned int *col_of_row, double *dr, double *dc);
     /* bench.py's cpu_baseline leg: execute every stride-th task of each kernel class of a factorisation and only release
      * the others (a bounded sample of the same matrix / ordering / nb); pangulu_amd_info_t.sampled_flop / sampled_tasks
      * say what ran.  1 = everything (default). */

@@ -163,6 +163,8 @@ def load(vtype="r64", test_hooks=False):
     lib.pangulu_amd_set_coordinates.restype = None
     lib.pangulu_amd_set_eager_host_mirror.argtypes = [ctypes.c_int]
     lib.pangulu_amd_set_eager_host_mirror.restype = None
+    lib.pangulu_amd_set_scaling.argtypes = [ctypes.c_int]
+    lib.pangulu_amd_set_scaling.restype = None
     lib.pangulu_amd_get_info.argtypes = [vpp, ctypes.POINTER(Info)]
     lib.pangulu_amd_get_info.restype = None
     lib.pangulu_amd_model_roofline.argtypes = [vpp, ctypes.c_double, ctypes.c_double]

@@ -179,6 +179,25 @@ extern "C"
         return npop;
     }
 
+    // maximum-product matching + scaling on a bare CSC matrix (pg_scaling.cpp); returns 0 on success
+    int pangulu_amd_test_matching(sparse_index_t n, const sparse_pointer_t *colptr, const sparse_index_t *rowidx, const sparse_value_t *value,
+                                  sparse_index_t *col_of_row, double *dr, double *dc)
+    {
+        CscMatrix A;
+        A.n = n;
+        A.colptr.assign(colptr, colptr + n + 1);
+        A.rowidx.assign(rowidx, rowidx + colptr[n]);
+        A.value.assign((const val_t *)value, (const val_t *)value + colptr[n]);
+        std::vector<u32> q;
+        std::vector<double> r, c;
+        if (!max_product_matching(A, q, r, c))
+            return 1;
+        std::copy(q.begin(), q.end(), col_of_row);
+        std::copy(r.begin(), r.end(), dr);
+        std::copy(c.begin(), c.end(), dc);
+        return 0;
+    }
+
     // The host's symbolic phase on a CSC pattern (already ordered): lower fill pattern incl. diagonal per column, the
     // reference's symbolic_nnz and the structural flop count.  Arrays are malloc'ed; free with free().
     int pangulu_amd_test_symbolic(sparse_index_t n, const sparse_pointer_t *colptr, const sparse_index_t *rowidx,
@@ -254,6 +273,7 @@ extern "C"
         pending_options().coord_dim = dim;
     }
     void pangulu_amd_set_eager_host_mirror(int on) { pending_options().eager_host_mirror = on != 0; }
+    void pangulu_amd_set_scaling(int on) { pending_options().scaling = on != 0; }
 
     // ----------------------------------------------------------------------------------------------------
     void pangulu_init(sparse_index_t pangulu_n, sparse_pointer_t pangulu_nnz, sparse_pointer_t *csc_colptr,
@@ -359,6 +379,43 @@ extern "C"
         Options &opt = pending_options();
         S->eager_host_mirror = opt.eager_host_mirror;
         double t0 = wall_seconds();
+        // Optional first step, like the reference's when built with its MC64 port (src/pangulu_reordering.c:1150-1173): put
+        // large entries on the diagonal by a column permutation and scale rows and columns so that they are 1 and nothing
+        // is larger.  A failure (structurally singular input) leaves the matrix as it is, with a warning, as there.
+        {
+            const char *se = getenv("PANGULU_AMD_SCALING");
+            const bool want = se ? atoi(se) != 0 : opt.scaling;
+            u64 applied = 0;
+            if (want && rank == 0)
+            {
+                if (max_product_matching(A, S->match_col, S->scale_row, S->scale_col))
+                {
+                    CscMatrix A1;
+                    apply_matching(A, S->match_col, S->scale_row, S->scale_col, A1);
+                    // columns of A1 are not sorted by row any more only if A's were not; keep CSC order per column
+                    A = std::move(A1);
+                    applied = 1;
+                }
+                else
+                {
+                    printf("[PanguLU-AMD WARNING] maximum-product matching failed (structurally singular?): continuing without scaling\n");
+                    S->match_col.clear();
+                    S->scale_row.clear();
+                    S->scale_col.clear();
+                }
+            }
+            comm->bcast(&applied, sizeof(applied), 0);
+            if (applied && rank != 0)
+            {
+                // (only rank 0 applies b and x transformations in gstrs; the others need the scaled matrix only)
+            }
+            if (applied)
+            {
+                comm->bcast(A.colptr.data(), sizeof(u64) * A.colptr.size(), 0);
+                comm->bcast(A.rowidx.data(), sizeof(u32) * A.rowidx.size(), 0);
+                comm->bcast(A.value.data(), sizeof(val_t) * A.value.size(), 0);
+            }
+        }
         if (rank == 0)
         {
             if (opt.ordering == PANGULU_AMD_ORDER_USER)
@@ -390,6 +447,7 @@ extern "C"
         opt.coords.clear();
         opt.coord_dim = 0;
         opt.user_perm.clear();
+        opt.scaling = false;
         opt.ordering = PANGULU_AMD_ORDER_ND;
         opt.eager_host_mirror = false;
         S->n = (u32)np;
@@ -463,12 +521,21 @@ extern "C"
         Solver *S = (Solver *)*pangulu_handle;
         Comm *comm = world();
         std::vector<val_t> b(S->n);
+        const bool scaled = !S->scale_row.empty();
+        auto times = [](val_t v, double s) -> val_t
+        {
+#ifdef PANGULU_COMPLEX
+            return val_t{(calculate_real_type)(v.re * s), (calculate_real_type)(v.im * s)};
+#else
+            return (val_t)(v * s);
+#endif
+        };
         if (comm->rank == 0)
         {
             for (u32 i = 0; i < S->n; i++)
             {
                 if (S->perm[i] < S->n_user)
-                    b[i] = rhs[S->perm[i]];
+                    b[i] = scaled ? times(rhs[S->perm[i]], S->scale_row[S->perm[i]]) : rhs[S->perm[i]]; // A1 y = Dr b
                 else
                     memset(&b[i], 0, sizeof(val_t)); // padding row: 1 * x = 0
             }
@@ -480,9 +547,22 @@ extern "C"
         S->info.time_solve = wall_seconds() - t0;
         if (comm->rank == 0)
         {
-            for (u32 i = 0; i < S->n; i++)
-                if (S->perm[i] < S->n_user)
-                    rhs[S->perm[i]] = b[i];
+            if (!scaled)
+            {
+                for (u32 i = 0; i < S->n; i++)
+                    if (S->perm[i] < S->n_user)
+                        rhs[S->perm[i]] = b[i];
+            }
+            else
+            {
+                // y (in the scaled matrix's column order) -> x[q(i)] = dc[q(i)] y[i]
+                std::vector<val_t> y(S->n_user);
+                for (u32 i = 0; i < S->n; i++)
+                    if (S->perm[i] < S->n_user)
+                        y[S->perm[i]] = b[i];
+                for (u32 i = 0; i < S->n_user; i++)
+                    rhs[S->match_col[i]] = times(y[i], S->scale_col[S->match_col[i]]);
+            }
         }
     }
 

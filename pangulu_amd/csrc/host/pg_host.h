@@ -240,8 +240,13 @@ Comm *make_ipc_comm(int rank, int size, const char *addr, int base_port);
 // ---------------------------------------------------------------------------------------------------------
 // the solver instance behind the opaque handle
 // ---------------------------------------------------------------------------------------------------------
+// pg_scaling.cpp: maximum-product matching + scaling (the reference's MC64 step, src/pangulu_reordering.c:149-681)
+bool max_product_matching(const CscMatrix &A, std::vector<u32> &col_of_row, std::vector<double> &dr, std::vector<double> &dc);
+void apply_matching(const CscMatrix &A, const std::vector<u32> &col_of_row, const std::vector<double> &dr, const std::vector<double> &dc, CscMatrix &out);
+
 struct Options
 {
+    bool scaling = false; // PANGULU_AMD_SCALING / pangulu_amd_set_scaling
     int ordering = PANGULU_AMD_ORDER_ND;
     std::vector<u32> user_perm;
     std::vector<double> coords;
@@ -266,6 +271,8 @@ struct Solver
     float recv_buffer_level = 0.5f;
     bool eager_host_mirror = false;
     // analysis products
+    std::vector<u32> match_col;            // scaling on: column of the user's matrix that sits in column i of the scaled one
+    std::vector<double> scale_row, scale_col; // scaling on: Dr, Dc (user's index space); empty otherwise
     std::vector<u32> perm, iperm;
     Symbolic sym;
     BlockPattern pat;

@@ -42,7 +42,7 @@ def _as(arr, dtype):
 
 
 def pangulu_init(n, nnz, csc_colptr, csc_rowidx, csc_value, nb=256, nthread=1, vtype="r64",
-                 ordering=None, coords=None, user_perm=None, recv_buffer_level=0.5, eager_host_mirror=False, lib=None):
+                 ordering=None, coords=None, user_perm=None, recv_buffer_level=0.5, eager_host_mirror=False, lib=None, scaling=False):
     """CSC input with 64-bit column pointers and 32-bit row indices, as the reference (src/pangulu_common.h:67-70).
 
     ordering: None/"nd" (built-in nested dissection, geometric when ``coords`` is given), "identity" (what the
@@ -65,6 +65,7 @@ def pangulu_init(n, nnz, csc_colptr, csc_rowidx, csc_value, nb=256, nthread=1, v
         c = _as(coords, np.float64)
         lib.pangulu_amd_set_coordinates(c.ctypes.data_as(ctypes.c_void_p), c.shape[0], c.shape[1])
     lib.pangulu_amd_set_eager_host_mirror(1 if eager_host_mirror else 0)
+    lib.pangulu_amd_set_scaling(1 if scaling else 0)  # maximum-product matching + scaling before the ordering (MC64's job)
     opt = _lib.InitOptions()
     opt.nthread = nthread
     opt.nb = nb
