@@ -284,8 +284,8 @@ def main():
             # MI355X_MICROARCH.md prescribes for gfx950) -- but ONLY if that pass profiled this build's kernels: the file
             # records a hash of the kernel sources, anything else leaves `traffic` null
             rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_tiled_f64_kernel",
-                            "tstrf": "void trsm_dense_direct_f64_kernel<16>", "gessm": "void trsm_dense_direct_f64_kernel<16>",
-                            "ssssm_sparse": "void ssssm_sparse_kernel<false>"}.get(dom)
+                            "tstrf": "trsm_dense_direct_f64_kernel<16>", "gessm": "trsm_dense_direct_f64_kernel<16>",
+                            "ssssm_sparse": "ssssm_sparse_kernel<false>"}.get(dom)
             tfile = os.path.join(ROOT, "profiles", "hbm_traffic_default_workload.json")
             if world == 1 and default_workload and rocprof_name and os.path.exists(tfile):
                 tj = json.load(open(tfile))

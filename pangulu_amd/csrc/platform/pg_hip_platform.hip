@@ -1493,9 +1493,9 @@ namespace
 // Level-scheduled block triangular solve for pangulu_gstrs on a single rank (pangulu_platform_0201001_block_trsv).
 // The reference sweeps block row by block row with one spmv / sptrsv platform call per block on the CPU platform
 // (src/pangulu_sptrsv.c:24-191); here block rows whose inputs are final form a LEVEL of the block dependency graph and one
-// launch handles a whole level: one workgroup per block row gathers  seg -= sum_j A(row, j) x_j  over the row's
-// off-diagonal blocks into LDS (floating-point LDS atomics), solves with the row's diagonal half there, and writes the
-// finished segment.  Same per-block arithmetic as ...0100000.c:435-506 (spmv, unit-lower column sweep, upper row sweep
+// level is two launches: one workgroup per off-diagonal block subtracts  A(row, j) x_j  from the row's segment (floating-
+// point atomics), then one wavefront per block row solves with the row's diagonal half in LDS and writes the finished
+// segment.  Same per-block arithmetic as ...0100000.c:435-506 (spmv, unit-lower column sweep, upper row sweep
 // with the PANGULU_SPTRSV_TOL clamp); sums across blocks arrive in a different order.
 // -----------------------------------------------------------------------------------------------------------------
 struct SolveBlkD
@@ -1504,7 +1504,7 @@ struct SolveBlkD
     const u16 *ri;
     const val_t *val;
     u32 bcol;
-    u32 pad_;
+    u32 brow; // destination segment
 };
 struct SolveRowD
 {
@@ -1515,9 +1515,36 @@ struct SolveRowD
     const val_t *dval;
 };
 
+// x_row -= A(row, j) x_j for every off-diagonal block of the level: one workgroup per block (rows near the root of the
+// tree have hundreds of blocks: a workgroup per row would walk them one after the other), floating-point atomics on
+// the destination segment
+__global__ __launch_bounds__(256) void block_trsv_gather_kernel(const SolveBlkD *__restrict__ blks, int nb, val_t *__restrict__ x)
+{
+    const SolveBlkD B = blks[blockIdx.x];
+    const val_t *xj = x + (size_t)B.bcol * nb;
+    val_t *xr = x + (size_t)B.brow * nb;
+    const int sub = threadIdx.x >> 4, l16 = threadIdx.x & 15, nsub = blockDim.x >> 4;
+    for (int c = sub; c < nb; c += nsub)
+    {
+        const u32 p0 = ptr0(B.cp, c), p1 = B.cp[c + 1];
+        if (p0 == p1)
+            continue;
+        const val_t xc = xj[c];
+        for (u32 p = p0 + l16; p < p1; p += 16)
+        {
+            const val_t m = v_mul(B.val[p], xc);
+#ifdef PANGULU_COMPLEX
+            v_atomic_add(&xr[B.ri[p]], val_t{-m.re, -m.im});
+#else
+            v_atomic_add(&xr[B.ri[p]], -m);
+#endif
+        }
+    }
+}
+
+// the diagonal halves of the level's block rows: one wavefront per row, the segment in LDS
 template <bool UPPER>
-__global__ __launch_bounds__(256) void block_trsv_level_kernel(const SolveRowD *__restrict__ rows, const SolveBlkD *__restrict__ blks, int nb,
-                                                               val_t *__restrict__ x)
+__global__ __launch_bounds__(64) void block_trsv_level_kernel(const SolveRowD *__restrict__ rows, int nb, val_t *__restrict__ x)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     val_t *seg = reinterpret_cast<val_t *>(smem_raw);
@@ -1525,23 +1552,6 @@ __global__ __launch_bounds__(256) void block_trsv_level_kernel(const SolveRowD *
     val_t *xr = x + (size_t)R.brow * nb;
     for (int i = threadIdx.x; i < nb; i += blockDim.x)
         seg[i] = xr[i];
-    __syncthreads();
-    // seg -= A(row, j) x_j: a quarter wavefront per column of the block, entries of the column over its 16 lanes
-    const int sub = threadIdx.x >> 4, l16 = threadIdx.x & 15, nsub = blockDim.x >> 4;
-    for (u32 b = 0; b < R.nblk; b++)
-    {
-        const SolveBlkD B = blks[R.first + b];
-        const val_t *xj = x + (size_t)B.bcol * nb;
-        for (int c = sub; c < nb; c += nsub)
-        {
-            const u32 p0 = ptr0(B.cp, c), p1 = B.cp[c + 1];
-            if (p0 == p1)
-                continue;
-            const val_t xc = xj[c];
-            for (u32 p = p0 + l16; p < p1; p += 16)
-                lds_atomic_sub(&seg[B.ri[p]], v_mul(B.val[p], xc));
-        }
-    }
     __syncthreads();
     // the diagonal half, by one wavefront (LDS operations of a wavefront complete in order: no barriers in the sweep)
     if (threadIdx.x < 64)
@@ -3103,47 +3113,55 @@ extern "C"
         const size_t nrow = (size_t)level_ptr[nlevel];
         size_t nblk = 0;
         for (size_t r = 0; r < nrow; r++)
-            nblk = std::max(nblk, (size_t)(rows[r].first + rows[r].nblk));
-        std::vector<SolveRowD> hr(nrow);
+            nblk += rows[r].nblk;
+        std::vector<SolveRowD> hr(std::max<size_t>(nrow, 1));
         std::vector<SolveBlkD> hb(std::max<size_t>(nblk, 1));
-        for (size_t r = 0; r < nrow; r++)
+        std::vector<size_t> blk_level_ptr((size_t)nlevel + 1, 0);
+        size_t o = 0;
+        for (size_t l = 0; l < (size_t)nlevel; l++)
         {
-            const slot_t *d = rows[r].diag;
-            hr[r].brow = rows[r].brow;
-            hr[r].nblk = rows[r].nblk;
-            hr[r].first = rows[r].first;
-            hr[r].dptr = upper ? d->d_rowpointer : d->d_columnpointer;
-            hr[r].didx = upper ? d->d_columnindex : d->d_rowindex;
-            hr[r].dval = d->d_value;
-        }
-        for (size_t b = 0; b < nblk; b++)
-        {
-            const slot_t *sb = blk_slots[b];
-            hb[b].cp = sb->d_columnpointer;
-            hb[b].ri = sb->d_rowindex;
-            hb[b].val = sb->d_value;
-            hb[b].bcol = blk_bcol[b];
-            hb[b].pad_ = 0;
+            for (size_t r = (size_t)level_ptr[l]; r < (size_t)level_ptr[l + 1]; r++)
+            {
+                const slot_t *d = rows[r].diag;
+                hr[r].brow = rows[r].brow;
+                hr[r].nblk = rows[r].nblk;
+                hr[r].first = o;
+                hr[r].dptr = upper ? d->d_rowpointer : d->d_columnpointer;
+                hr[r].didx = upper ? d->d_columnindex : d->d_rowindex;
+                hr[r].dval = d->d_value;
+                for (size_t b = 0; b < rows[r].nblk; b++, o++)
+                {
+                    const slot_t *sb = blk_slots[rows[r].first + b];
+                    hb[o].cp = sb->d_columnpointer;
+                    hb[o].ri = sb->d_rowindex;
+                    hb[o].val = sb->d_value;
+                    hb[o].bcol = blk_bcol[rows[r].first + b];
+                    hb[o].brow = rows[r].brow;
+                }
+            }
+            blk_level_ptr[l + 1] = o;
         }
         SolveRowD *d_rows = nullptr;
         SolveBlkD *d_blks = nullptr;
         val_t *d_x = nullptr;
-        HIP_CHECK(hipMalloc((void **)&d_rows, sizeof(SolveRowD) * std::max<size_t>(nrow, 1)));
+        HIP_CHECK(hipMalloc((void **)&d_rows, sizeof(SolveRowD) * hr.size()));
         HIP_CHECK(hipMalloc((void **)&d_blks, sizeof(SolveBlkD) * hb.size()));
         HIP_CHECK(hipMalloc((void **)&d_x, sizeof(val_t) * (size_t)xlen));
-        HIP_CHECK(hipMemcpyAsync(d_rows, hr.data(), sizeof(SolveRowD) * nrow, hipMemcpyHostToDevice, B.stream));
+        HIP_CHECK(hipMemcpyAsync(d_rows, hr.data(), sizeof(SolveRowD) * hr.size(), hipMemcpyHostToDevice, B.stream));
         HIP_CHECK(hipMemcpyAsync(d_blks, hb.data(), sizeof(SolveBlkD) * hb.size(), hipMemcpyHostToDevice, B.stream));
         HIP_CHECK(hipMemcpyAsync(d_x, x, sizeof(val_t) * (size_t)xlen, hipMemcpyHostToDevice, B.stream));
         const size_t lds = sizeof(val_t) * (size_t)nb;
         for (size_t l = 0; l < (size_t)nlevel; l++)
         {
-            const size_t n = (size_t)(level_ptr[l + 1] - level_ptr[l]);
+            const size_t n = (size_t)(level_ptr[l + 1] - level_ptr[l]), nbl = blk_level_ptr[l + 1] - blk_level_ptr[l];
             if (!n)
                 continue;
+            if (nbl)
+                hipLaunchKernelGGL(block_trsv_gather_kernel, dim3((unsigned)nbl), dim3(256), 0, B.stream, d_blks + blk_level_ptr[l], (int)nb, d_x);
             if (upper)
-                hipLaunchKernelGGL(block_trsv_level_kernel<true>, dim3((unsigned)n), dim3(256), lds, B.stream, d_rows + level_ptr[l], d_blks, (int)nb, d_x);
+                hipLaunchKernelGGL(block_trsv_level_kernel<true>, dim3((unsigned)n), dim3(64), lds, B.stream, d_rows + level_ptr[l], (int)nb, d_x);
             else
-                hipLaunchKernelGGL(block_trsv_level_kernel<false>, dim3((unsigned)n), dim3(256), lds, B.stream, d_rows + level_ptr[l], d_blks, (int)nb, d_x);
+                hipLaunchKernelGGL(block_trsv_level_kernel<false>, dim3((unsigned)n), dim3(64), lds, B.stream, d_rows + level_ptr[l], (int)nb, d_x);
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(x, d_x, sizeof(val_t) * (size_t)xlen, hipMemcpyDeviceToHost, B.stream));

@@ -32,7 +32,7 @@ def library_for(platform, vtype="r64"):
 
 
 def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_factors=True, user_perm=None, nthread=4,
-              hip_options=None):
+              hip_options=None, scaling=False):
     """Runs pangulu_init + gstrf (+ gstrs with b = A*1) and returns info, factors (scipy CSC, permuted ordering),
     the permutation, x and ||Ax-b||/||b||."""
     n, cp, ri, va, coords = mat
@@ -50,7 +50,7 @@ def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_fa
     if ordering is None:
         ordering = "nd"
     h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering,
-                        coords=coords if ordering == "nd" else None, user_perm=user_perm, nthread=nthread, lib=lib)
+                        coords=coords if ordering == "nd" else None, user_perm=user_perm, nthread=nthread, lib=lib, scaling=scaling)
     out = {"info": h.info()}
     pa.pangulu_gstrf(h)
     out["info"] = h.info()

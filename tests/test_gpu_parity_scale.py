@@ -117,3 +117,18 @@ def test_device_solve_matches_host_sweep(vtype, gen, nb, monkeypatch):
     assert np.abs(dev["x"] - host["x"]).max() <= tol * scale
     assert np.abs(dev["x"] - ref["x"]).max() <= tol * scale
     assert dev["residual"] <= (1e-12 if vtype in ("r64", "cr64") else 5e-5)
+
+
+@pytest.mark.parametrize("nx,nb", [(6, 32), (8, 128), (10, 256)])
+def test_saddle_point_with_matching_on_the_hip_path(nx, nb):
+    """nlpkkt class without regularisation: [[H, J^T], [J, 0]].  With the maximum-product matching + scaling (MC64's job) in
+    front, the factorisation without pivoting goes through on the device and matches the oracle on the same scaled matrix."""
+    from .test_scaling import saddle
+
+    mat = saddle(nx)
+    gpu = factorize(mat, nb, "hip", scaling=True)
+    ref = factorize(mat, nb, oracle_library("r64"), scaling=True)
+    assert (gpu["perm"] == ref["perm"]).all()
+    for f in ("L", "U"):
+        assert max_rel_diff(gpu[f], ref[f]) <= 1e-11, f
+    assert gpu["residual"] <= 1e-10 and abs(gpu["residual"] - ref["residual"]) <= 1e-10

@@ -9,7 +9,7 @@ import csv
 import sys
 from collections import defaultdict
 
-ABBR = [("ssssm_dense", "SD"), ("ssssm_sparse", "SS"), ("trsm_dense", "TD"), ("trsm_sparse", "TS"), ("getrf", "GF"),
+ABBR = [("block_trsv", "solve"), ("ssssm_dense", "SD"), ("ssssm_sparse", "SS"), ("trsm_dense", "TD"), ("trsm_sparse", "TS"), ("getrf", "GF"),
         ("densify", "dn"), ("sparsify", "sp"), ("half_image", "hi"), ("diag_tile", "iv"), ("flop_count", "fc")]
 
 
@@ -31,7 +31,8 @@ def main(path, which=-1):
             cur = []
         cur.append(e)
     groups.append(cur)
-    groups = [g for g in groups if len(g) > 50]
+    # factorisations only (the triangular solve at the end of a bench run is a group of its own)
+    groups = [g for g in groups if len(g) > 50 and any(e[2] in ("SD", "SS", "GF") for e in g)]
     g = groups[which]
     t0, t1 = g[0][0], max(e[1] for e in g)
     # sweep

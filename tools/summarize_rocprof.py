@@ -10,6 +10,13 @@ SQ_* cycle counters are per-SE quad-cycles as that guide describes; only ratios 
 import collections, csv, glob, json, os, sys
 
 
+def short(name):
+    """kernel name without return type, anonymous namespace and argument list"""
+    name = name.replace("(anonymous namespace)::", "")
+    name = name.split("(")[0]
+    return name[5:] if name.startswith("void ") else name
+
+
 def files(d, suffix):
     return glob.glob(os.path.join(d, "*" + suffix)) + glob.glob(os.path.join(d, "*", "*" + suffix))
 
@@ -27,7 +34,7 @@ def main():
     for d in args[1:]:
         for f in files(d, "_counter_collection.csv"):
             for row in csv.DictReader(open(f)):
-                k = row["Kernel_Name"].split("(")[0]
+                k = short(row["Kernel_Name"])
                 agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
                 disp[k][row["Counter_Name"]].add(row["Dispatch_Id"])
     cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
@@ -36,7 +43,7 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     summary = {}
     for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"])):
-        name = r["Name"].split("(")[0]
+        name = short(r["Name"])
         if "rocclr" in name:
             continue
         c = agg.get(name, {})
