@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         atomicAdd(&dbg[slot], now_ - stamp_);                              \
         stamp_ = now_;                                                     \
     }
-    __shared__ __align__(16) double sA[DG_K * DG_LD];
-    __shared__ __align__(16) double sB[DG_K * DG_LD];
+    // two images of each slab: while the matrix cores consume one, the next slab (already in registers) is written into
+    // the other -- ONE barrier per slab instead of two (73.7 KB per workgroup: two workgroups still share a CU)
+    __shared__ __align__(16) double sAb[2][DG_K * DG_LD];
+    __shared__ __align__(16) double sBb[2][DG_K * DG_LD];
     const int tiles = nb / DG_TILE;
     const unsigned bid = logical_block_id((unsigned)(tiles * tiles)); // the tiles of one destination share operand halves: same XCD, same L2
     // (group, tile) of this workgroup: from the launch's work list (tiles no update of the group can reach are left out)
@@ -254,32 +256,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
                         acc[ni][mi][r] = -C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)];
                 }
     }
-    while (nxt_step >= 0)
+#define DG_STORE_LDS(buf_)                                                                           \
+    {                                                                                                \
+        double *sA_ = sAb[buf_], *sB_ = sBb[buf_];                                                   \
+        /* (pieces that were not fetched hold stale finite values; no MFMA reads them) */            \
+        *reinterpret_cast<double2 *>(&sA_[(a_k + 0) * DG_LD + a_m]) = ra0;                           \
+        *reinterpret_cast<double2 *>(&sA_[(a_k + 4) * DG_LD + a_m]) = ra1;                           \
+        *reinterpret_cast<double2 *>(&sA_[(a_k + 8) * DG_LD + a_m]) = ra2;                           \
+        *reinterpret_cast<double2 *>(&sA_[(a_k + 12) * DG_LD + a_m]) = ra3;                          \
+        sB_[b_k * DG_LD + b_n] = rb0.x;                                                              \
+        sB_[(b_k + 1) * DG_LD + b_n] = rb0.y;                                                        \
+        sB_[b_k * DG_LD + b_n + 32] = rb1.x;                                                         \
+        sB_[(b_k + 1) * DG_LD + b_n + 32] = rb1.y;                                                   \
+        sB_[b_k * DG_LD + b_n + 64] = rb2.x;                                                         \
+        sB_[(b_k + 1) * DG_LD + b_n + 64] = rb2.y;                                                   \
+        sB_[b_k * DG_LD + b_n + 96] = rb3.x;                                                         \
+        sB_[(b_k + 1) * DG_LD + b_n + 96] = rb3.y;                                                   \
+    }
+    // software pipeline: slab s in LDS image `buf` feeds the matrix cores, slab s+1 sits in registers (its loads went out one
+    // iteration ago) and goes into the other image afterwards, the loads of slab s+2 go out, one barrier
+    cur_ab = nxt_ab;
+    cur_bb = nxt_bb;
+    DG_STAMP(1)
+    DG_STORE_LDS(0)
+    DG_STAMP(2)
+    DG_NEXT_STEP(nxt_step)
+    if (nxt_step >= 0)
+        DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb)
+    __syncthreads();
+    DG_STAMP(3)
+    int buf = 0;
+    for (;;)
     {
-        cur_ab = nxt_ab;
-        cur_bb = nxt_bb;
-        __syncthreads(); // everyone is done reading the previous slab
-        DG_STAMP(1)
-        // (pieces that were not fetched hold stale finite values; no MFMA reads them)
-        *reinterpret_cast<double2 *>(&sA[(a_k + 0) * DG_LD + a_m]) = ra0;
-        *reinterpret_cast<double2 *>(&sA[(a_k + 4) * DG_LD + a_m]) = ra1;
-        *reinterpret_cast<double2 *>(&sA[(a_k + 8) * DG_LD + a_m]) = ra2;
-        *reinterpret_cast<double2 *>(&sA[(a_k + 12) * DG_LD + a_m]) = ra3;
-        sB[b_k * DG_LD + b_n] = rb0.x;
-        sB[(b_k + 1) * DG_LD + b_n] = rb0.y;
-        sB[b_k * DG_LD + b_n + 32] = rb1.x;
-        sB[(b_k + 1) * DG_LD + b_n + 32] = rb1.y;
-        sB[b_k * DG_LD + b_n + 64] = rb2.x;
-        sB[(b_k + 1) * DG_LD + b_n + 64] = rb2.y;
-        sB[b_k * DG_LD + b_n + 96] = rb3.x;
-        sB[(b_k + 1) * DG_LD + b_n + 96] = rb3.y;
-        DG_STAMP(2)
-        __syncthreads();
-        DG_STAMP(3)
-        DG_NEXT_STEP(nxt_step)
-        if (nxt_step >= 0)
-            DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb) // in flight while the matrix cores work
-        DG_STAMP(4)
+        const double *sA = sAb[buf], *sB = sBb[buf];
         const unsigned a4 = (cur_ab >> (wm / 16)) & 0xFu, b4 = (cur_bb >> (wn / 16)) & 0xFu;
         if (a4 && b4)
         {
@@ -313,7 +322,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         DG_STAMP(5)
         if (stamping)
             atomicAdd(&dbg[7], 1ull); // slab steps in the low word
+        if (nxt_step < 0)
+            break;
+        cur_ab = nxt_ab;
+        cur_bb = nxt_bb;
+        DG_STORE_LDS(buf ^ 1) // (waits for the slab's loads: they have been in flight since before the products above)
+        DG_STAMP(2)
+        DG_NEXT_STEP(nxt_step)
+        if (nxt_step >= 0)
+            DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb)
+        DG_STAMP(4)
+        __syncthreads(); // the other image is complete, and everyone is done reading this one
+        DG_STAMP(3)
+        buf ^= 1;
     }
+#undef DG_STORE_LDS
 #undef DG_NEXT_STEP
 #undef DG_FILL_WINDOW
 #undef DG_LOAD_SLAB
