@@ -37,10 +37,18 @@ __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 #define DG_LD 144 // padded slab row (doubles): rows of consecutive k land 32 banks apart
 #define DG_WINDOW 16 // tasks whose bookkeeping is held in LDS at a time
 
-#ifndef DG_WAVES_PER_EU
-#define DG_WAVES_PER_EU 2 // two workgroups per CU: one stages its slab while the other feeds the matrix cores
+// Wavefronts per workgroup.  4 (default): 64 x 64 sub-tiles (4 x 4 accumulators, 207 registers), two wavefronts per SIMD.
+// 8: every wavefront owns a 64 x 32 sub-tile (2 x 4 accumulators, 123 registers), two workgroups = sixteen wavefronts per
+// CU, four instruction streams per matrix-core pipe to cover each other's LDS waits, slab bookkeeping and barriers --
+// measured equal (bench matrix 46.1-48.1 vs 46.2-47.4 ms per factorisation; poisson3d(64): 36.9 vs 37.2 ms of update-kernel
+// time), so the variant with half the LDS operand reads per flop stays.
+#ifndef DG_WAVES
+#define DG_WAVES 4
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PER_EU, DG_WAVES_PER_EU))) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
+#define DG_THREADS (64 * DG_WAVES)
+#define DG_NI (DG_WAVES == 8 ? 2 : 4) // 16-column pieces of C per wavefront
+#define DG_WAVES_PER_EU (DG_WAVES / 2)
+__global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PER_EU, DG_WAVES_PER_EU))) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
                                                                const SsssmTaskD *__restrict__ tasks, int nb,
                                                                unsigned long long *__restrict__ product_counter,
                                                                unsigned long long *dbg, const u32 *__restrict__ work)
@@ -68,13 +76,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (scalar: the skip tests below must be scalar branches)
     const int M0 = (tile % tiles) * DG_TILE, N0 = (tile / tiles) * DG_TILE; // workgroup tile origin
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;                   // wavefront sub-tile inside it
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * (16 * DG_NI);         // wavefront sub-tile inside it
     const int l15 = lane & 15, l4 = lane >> 4;
     const SsssmGroupD G = groups[g];
 
-    v4f64 acc[4][4]; // [ni][mi]
+    v4f64 acc[DG_NI][4]; // [ni][mi]
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++)
+    for (int ni = 0; ni < DG_NI; ni++)
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
             acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -82,12 +90,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     // staging maps.  A slab (128 rows x 16 k, column-major source): thread -> rows 2*(tid & 63), +1 of k = (tid >> 6) + 4 i.
     // B slab (16 k x 128 cols): thread -> k pair 2*(tid & 7) of column (tid >> 3) + 32 i: 8 consecutive threads read one
     // 128-byte run of a column.
+    // (with 8 wavefronts: A rows 2*(tid & 63), +1 of k = (tid >> 6) + 8 i, i < 2;  B k pair 2*(tid & 7) of column (tid >> 3) + 64 i)
+    constexpr int NST = 16 / DG_WAVES;          // pieces each thread stages per operand (4 or 2)
+    constexpr int A_KSTEP = DG_WAVES;           // k distance between a thread's A pieces
+    constexpr int B_NSTEP = 8 * DG_WAVES;       // column distance between a thread's B pieces (32 or 64)
     const int a_m = 2 * (tid & 63), a_k = tid >> 6;
     const int b_k = 2 * (tid & 7), b_n = tid >> 3;
     const int a_slab = (tid & 63) >> 3;                            // which 16-row slab of the tile this thread stages
-    const int b_slab = __builtin_amdgcn_readfirstlane(tid >> 7);   // 16-column slab of piece i: b_slab + 2 i
-    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3; // next slab, in flight while the current one is consumed
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_double2(0.0, 0.0);
+    const int b_slab = __builtin_amdgcn_readfirstlane(tid >> 7);   // 16-column slab of piece i: b_slab + (B_NSTEP / 16) i
+    double2 ra[NST], rb[NST]; // next slab, in flight while the current one is consumed
+#pragma unroll
+    for (int i = 0; i < NST; i++)
+        ra[i] = rb[i] = make_double2(0.0, 0.0);
 
     const u32 ntask = G.task_end - G.task_begin;
     const int steps_per_task = nb / DG_K;
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         __syncthreads(); /* nobody reads the previous window any more */                             \
         const int t_ = tid >> 4, s_ = tid & 15;                                                      \
         unsigned v_ = 0;                                                                             \
-        if (win0 + t_ < (int)ntask && s_ < steps_per_task)                                           \
+        if (tid < 256 && win0 + t_ < (int)ntask && s_ < steps_per_task)                              \
         {                                                                                            \
             const SsssmTaskD &Tm_ = tasks[G.task_begin + win0 + t_];                                 \
             const unsigned ab_ = ((unsigned)mirror_map(Tm_.a.val, nb)[s_] >> (M0 / 16)) & 0xFFu;     \
@@ -134,9 +148,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
                 s_pb[t_] = Tm_.b.val;                                                                \
             }                                                                                        \
         }                                                                                            \
-        s_abbb[tid] = (unsigned short)v_;                                                            \
+        if (tid < 256)                                                                               \
+            s_abbb[tid] = (unsigned short)v_;                                                        \
         const unsigned long long bal_ = __ballot(v_ != 0);                                           \
-        if ((tid & 63) < 4)                                                                          \
+        if (tid < 256 && (tid & 63) < 4)                                                             \
             s_live[(tid >> 6) * 4 + (tid & 63)] = (unsigned)((bal_ >> (16 * (tid & 63))) & 0xFFFFull); \
         __syncthreads();                                                                             \
     }
@@ -199,19 +214,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         const double *B_ = nxt_pb + (size_t)(N0 + b_n) * nb + k0_ + b_k;                             \
         if (((ab_) >> a_slab) & 1u)                                                                  \
         {                                                                                            \
-            ra0 = *reinterpret_cast<const double2 *>(A_);                                            \
-            ra1 = *reinterpret_cast<const double2 *>(A_ + (size_t)4 * nb);                           \
-            ra2 = *reinterpret_cast<const double2 *>(A_ + (size_t)8 * nb);                           \
-            ra3 = *reinterpret_cast<const double2 *>(A_ + (size_t)12 * nb);                          \
+            _Pragma("unroll") for (int i_ = 0; i_ < NST; i_++)                                       \
+                ra[i_] = *reinterpret_cast<const double2 *>(A_ + (size_t)(A_KSTEP * i_) * nb);       \
         }                                                                                            \
-        if (((bb_) >> b_slab) & 1u)                                                                  \
-            rb0 = *reinterpret_cast<const double2 *>(B_);                                            \
-        if (((bb_) >> (b_slab + 2)) & 1u)                                                            \
-            rb1 = *reinterpret_cast<const double2 *>(B_ + (size_t)32 * nb);                          \
-        if (((bb_) >> (b_slab + 4)) & 1u)                                                            \
-            rb2 = *reinterpret_cast<const double2 *>(B_ + (size_t)64 * nb);                          \
-        if (((bb_) >> (b_slab + 6)) & 1u)                                                            \
-            rb3 = *reinterpret_cast<const double2 *>(B_ + (size_t)96 * nb);                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < NST; i_++)                                           \
+            if (((bb_) >> (b_slab + (B_NSTEP / 16) * i_)) & 1u)                                      \
+                rb[i_] = *reinterpret_cast<const double2 *>(B_ + (size_t)(B_NSTEP * i_) * nb);       \
     }
 
     DG_NEXT_STEP(nxt_step)
@@ -235,9 +243,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
         for (int e = lane; e < (int)ntask * 16; e += 64)
         {
             const unsigned v = s_abbb[e];
-            const unsigned a4 = ((v & 0xFFu) >> (wm / 16)) & 0xFu, b4 = ((v >> 8) >> (wn / 16)) & 0xFu;
+            const unsigned a4 = ((v & 0xFFu) >> (wm / 16)) & 0xFu, b4 = ((v >> 8) >> (wn / 16)) & ((1u << DG_NI) - 1u);
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++)
+            for (int ni = 0; ni < DG_NI; ni++)
                 if ((b4 >> ni) & 1u)
                     m |= a4 << (4 * ni);
         }
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
             m |= (unsigned)__shfl_xor((int)m, off, 64);
         pre = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
 #pragma unroll
-        for (int ni = 0; ni < 4; ni++)
+        for (int ni = 0; ni < DG_NI; ni++)
 #pragma unroll
             for (int mi = 0; mi < 4; mi++)
                 if ((pre >> (4 * ni + mi)) & 1u)
@@ -260,18 +268,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     {                                                                                                \
         double *sA_ = sAb[buf_], *sB_ = sBb[buf_];                                                   \
         /* (pieces that were not fetched hold stale finite values; no MFMA reads them) */            \
-        *reinterpret_cast<double2 *>(&sA_[(a_k + 0) * DG_LD + a_m]) = ra0;                           \
-        *reinterpret_cast<double2 *>(&sA_[(a_k + 4) * DG_LD + a_m]) = ra1;                           \
-        *reinterpret_cast<double2 *>(&sA_[(a_k + 8) * DG_LD + a_m]) = ra2;                           \
-        *reinterpret_cast<double2 *>(&sA_[(a_k + 12) * DG_LD + a_m]) = ra3;                          \
-        sB_[b_k * DG_LD + b_n] = rb0.x;                                                              \
-        sB_[(b_k + 1) * DG_LD + b_n] = rb0.y;                                                        \
-        sB_[b_k * DG_LD + b_n + 32] = rb1.x;                                                         \
-        sB_[(b_k + 1) * DG_LD + b_n + 32] = rb1.y;                                                   \
-        sB_[b_k * DG_LD + b_n + 64] = rb2.x;                                                         \
-        sB_[(b_k + 1) * DG_LD + b_n + 64] = rb2.y;                                                   \
-        sB_[b_k * DG_LD + b_n + 96] = rb3.x;                                                         \
-        sB_[(b_k + 1) * DG_LD + b_n + 96] = rb3.y;                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < NST; i_++)                                           \
+        {                                                                                            \
+            *reinterpret_cast<double2 *>(&sA_[(a_k + A_KSTEP * i_) * DG_LD + a_m]) = ra[i_];         \
+            sB_[b_k * DG_LD + b_n + B_NSTEP * i_] = rb[i_].x;                                        \
+            sB_[(b_k + 1) * DG_LD + b_n + B_NSTEP * i_] = rb[i_].y;                                  \
+        }                                                                                            \
     }
     // software pipeline: slab s in LDS image `buf` feeds the matrix cores, slab s+1 sits in registers (its loads went out one
     // iteration ago) and goes into the other image afterwards, the loads of slab s+2 go out, one barrier
@@ -289,26 +291,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     for (;;)
     {
         const double *sA = sAb[buf], *sB = sBb[buf];
-        const unsigned a4 = (cur_ab >> (wm / 16)) & 0xFu, b4 = (cur_bb >> (wn / 16)) & 0xFu;
+        const unsigned a4 = (cur_ab >> (wm / 16)) & 0xFu, b4 = (cur_bb >> (wn / 16)) & ((1u << DG_NI) - 1u);
         if (a4 && b4)
         {
             nprod += (unsigned)(__builtin_popcount(a4) * __builtin_popcount(b4));
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++)
+            for (int ni = 0; ni < DG_NI; ni++)
                 if ((b4 >> ni) & 1u)
                     touched |= a4 << (4 * ni);
 #pragma unroll
             for (int kq = 0; kq < DG_K / 4; kq++)
             {
-                double fa[4], fb[4];
+                double fa[4], fb[DG_NI];
 #pragma unroll
                 for (int mi = 0; mi < 4; mi++)
                     fa[mi] = sA[(kq * 4 + l4) * DG_LD + wm + mi * 16 + l15];
 #pragma unroll
-                for (int ni = 0; ni < 4; ni++)
+                for (int ni = 0; ni < DG_NI; ni++)
                     fb[ni] = sB[(kq * 4 + l4) * DG_LD + wn + ni * 16 + l15];
 #pragma unroll
-                for (int ni = 0; ni < 4; ni++)
+                for (int ni = 0; ni < DG_NI; ni++)
                 {
                     if (!((b4 >> ni) & 1u))
                         continue;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     if (pre)
     {
 #pragma unroll
-        for (int ni = 0; ni < 4; ni++)
+        for (int ni = 0; ni < DG_NI; ni++)
 #pragma unroll
             for (int mi = 0; mi < 4; mi++)
                 if ((pre >> (4 * ni + mi)) & 1u)
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PE
     // stores before it as well -- loads and stores share one counter and cannot be waited on separately -- which made this
     // epilogue 16 dependent memory round trips, 14 us of a workgroup's 42.
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++)
+    for (int ni = 0; ni < DG_NI; ni++)
     {
         const unsigned t4 = (touched >> (4 * ni)) & 0xFu;
         if (!t4)

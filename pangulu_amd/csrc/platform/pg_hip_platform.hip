@@ -2174,7 +2174,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 LaunchTimer lt(5, ds);
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 if (nw)
-                    hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(256), 0, ds, d_groups_d, d_tasks_d, nb,
+                    hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_groups_d, d_tasks_d, nb,
                                        B.opt_count_flops ? B.d_flops + 6 : nullptr, debug_ssssm ? B.d_flops + 8 : nullptr, d_work);
             }
             if (B.opt_count_flops)
