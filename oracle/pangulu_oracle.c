@@ -8,9 +8,12 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
  * (libpangulu_amd_*.so) never links or calls it.
  *
- * Pinning status: the reference itself cannot be compiled in this image without writing a stand-in
- * `cblas.h` (none is installed) and regenerating its platform helper, so no reference binary backs this
- * file.  It is pinned against the known answers SURVEY.md §8c / BASELINE.md §2 record from the reference's
+ * Pinning status: the FLOATING-POINT kernels below are "parity unpinned" by reference code -- the reference's CPU
+ * platform file includes cblas.h unconditionally, the image has none, and writing one would be a stand-in, so no
+ * reference binary backs GETRF/TSTRF/GESSM/SSSSM.  The INTEGER outputs (the four structural flop counters at the end
+ * of this file) ARE pinned bit for bit against the reference's own src/pangulu_kernel_interface.c:4-176, compiled from
+ * /root/reference under its PANGULU_PLATFORM_ENV switch into oracle/_ref/ (oracle/ref/ref_pin.c,
+ * tests/test_reference_pin.py).  The floating-point part is pinned against the known answers SURVEY.md §8c / BASELINE.md §2 record from the reference's
  * own run on its only fixture (examples/Trefethen_20b.mtx: symbolic nnz 285, structural flop 2491,
  * ||Ax-b||/||b|| ~ 2e-16) and on Poisson 24^3 (symbolic nnz 15 302 062, flop 8 686 870 069), and against
  * the reference's own correctness criteria (||L(U.1) - A.1|| / ||A.1||, src/pangulu_numeric.c:1082-1341,
