@@ -1,5 +1,13 @@
 // pg_hip_dense.h -- dense-mode blocks: column-major mirrors in HBM and the f64 matrix-core SSSSM kernel.
-// (included by pg_hip_platform.hip after the descriptor structs; R64 only)
+// (included by pg_hip_platform.hip after the descriptor structs; R64 and CR64)
+//
+// CR64 (round 2): a complex block's mirror is TWO real planes (real part, imaginary part), each laid out exactly like an R64
+// mirror (nb x nb doubles, occupancy map, saved-tiles slack), PG_PLANE_STRIDE(nb) doubles apart.  A complex update
+// C -= A B then is four real ones on the planes -- C_re -= A_re B_re, C_re += A_im B_im, C_im -= A_re B_im, C_im -= A_im B_re --
+// all through the real kernel below (a task carries a sign for its A operand; the two products of a destination plane
+// are consecutive tasks of one group, so they share the accumulators and the destination pass).  Complex flops and real
+// matrix-core flops are in the ratio 8 : 8, i.e. the complex rate equals the real MFMA rate.  The reference's GPU path
+// calls cublasZgemm on densified blocks for this (...0201000.cu:778-816).
 //
 // North star: "MFMA applied only on blocks whose fill makes the update effectively a dense contraction".  The
 // reference's rule is all-or-nothing (all three blocks completely full -> cuBLAS on the value arrays,
@@ -18,6 +26,11 @@
 // belongs to the block, so whatever lands in the mirror later (updates, solves) stays inside the map.  The MFMA update
 // skips K-slabs in which either operand is structurally zero, the dense solves skip empty strips and leading panels.
 #define MIRROR_MAP_BYTES 64
+// doubles from one plane of a mirror to the next (values + map + the slack a blocked GETRF saves diagonal tiles in)
+__host__ __device__ inline size_t mirror_plane_stride(int nb)
+{
+    return (size_t)nb * nb + MIRROR_MAP_BYTES / sizeof(double) + (size_t)16 * nb;
+}
 __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 {
     return reinterpret_cast<const unsigned short *>(mirror + (size_t)nb * nb);
@@ -124,8 +137,19 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
     __shared__ unsigned short s_abbb[DG_WINDOW * 16];     // (bbits << 8) | abits of (task, slab); 0 = nothing to do
     __shared__ unsigned s_live[DG_WINDOW];               // per task: which slabs are live
     __shared__ const double *s_pa[DG_WINDOW], *s_pb[DG_WINDOW];
+#if PG_PLANES > 1
+    __shared__ double s_sign[DG_WINDOW]; // sign of the task's product (complex updates as four real ones)
+    double nxt_sign = 1.0;
+#endif
     int win0 = -DG_WINDOW; // first task of the window in the tables
 
+#if PG_PLANES > 1
+#define DG_SET_SIGN(t_, Tm_) s_sign[t_] = (Tm_).sign;
+#define DG_GET_SIGN(i_) nxt_sign = s_sign[i_];
+#else
+#define DG_SET_SIGN(t_, Tm_)
+#define DG_GET_SIGN(i_)
+#endif
 #define DG_FILL_WINDOW()                                                                             \
     {                                                                                                \
         __syncthreads(); /* nobody reads the previous window any more */                             \
@@ -134,8 +158,9 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
         if (tid < 256 && win0 + t_ < (int)ntask && s_ < steps_per_task)                              \
         {                                                                                            \
             const SsssmTaskD &Tm_ = tasks[G.task_begin + win0 + t_];                                 \
-            const unsigned ab_ = ((unsigned)mirror_map(Tm_.a.val, nb)[s_] >> (M0 / 16)) & 0xFFu;     \
-            const uint4 mb_ = *reinterpret_cast<const uint4 *>(mirror_map(Tm_.b.val, nb) + N0 / 16); \
+            const double *pa_ = reinterpret_cast<const double *>(Tm_.a.val), *pb_ = reinterpret_cast<const double *>(Tm_.b.val); \
+            const unsigned ab_ = ((unsigned)mirror_map(pa_, nb)[s_] >> (M0 / 16)) & 0xFFu;           \
+            const uint4 mb_ = *reinterpret_cast<const uint4 *>(mirror_map(pb_, nb) + N0 / 16);       \
             const unsigned w_[4] = {mb_.x, mb_.y, mb_.z, mb_.w};                                     \
             unsigned bb_ = 0;                                                                        \
             _Pragma("unroll") for (int c_ = 0; c_ < 8; c_++)                                         \
@@ -144,8 +169,9 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
                 v_ = (bb_ << 8) | ab_;                                                               \
             if (s_ == 0)                                                                             \
             {                                                                                        \
-                s_pa[t_] = Tm_.a.val;                                                                \
-                s_pb[t_] = Tm_.b.val;                                                                \
+                s_pa[t_] = pa_;                                                                      \
+                s_pb[t_] = pb_;                                                                      \
+                DG_SET_SIGN(t_, Tm_)                                                                 \
             }                                                                                        \
         }                                                                                            \
         if (tid < 256)                                                                               \
@@ -170,6 +196,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
                 nxt_bb = v_ >> 8;                                                                    \
                 nxt_pa = s_pa[cur_t - win0];                                                         \
                 nxt_pb = s_pb[cur_t - win0];                                                         \
+                DG_GET_SIGN(cur_t - win0)                                                            \
                 (out_) = cur_t * steps_per_task + s_;                                                \
                 break;                                                                               \
             }                                                                                        \
@@ -189,8 +216,8 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
                 const int s_ = __builtin_ctzll(todo);                                                \
                 todo &= todo - 1;                                                                    \
                 (out_) = cur_t * steps_per_task + done_steps + s_;                                   \
-                nxt_pa = tasks[G.task_begin + cur_t].a.val;                                          \
-                nxt_pb = tasks[G.task_begin + cur_t].b.val;                                          \
+                nxt_pa = reinterpret_cast<const double *>(tasks[G.task_begin + cur_t].a.val);        \
+                nxt_pb = reinterpret_cast<const double *>(tasks[G.task_begin + cur_t].b.val);        \
                 break;                                                                               \
             }                                                                                        \
             if (cur_t >= 0 && done_steps + 64 < steps_per_task)                                      \
@@ -207,6 +234,11 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
         }                                                                                            \
     }
 
+#if PG_PLANES > 1
+#define DG_APPLY_SIGN(v_) { (v_).x *= nxt_sign; (v_).y *= nxt_sign; }
+#else
+#define DG_APPLY_SIGN(v_)
+#endif
 #define DG_LOAD_SLAB(step_, ab_, bb_)                                                                \
     {                                                                                                \
         const int k0_ = ((step_) % steps_per_task) * DG_K;                                           \
@@ -215,7 +247,10 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
         if (((ab_) >> a_slab) & 1u)                                                                  \
         {                                                                                            \
             _Pragma("unroll") for (int i_ = 0; i_ < NST; i_++)                                       \
+            {                                                                                        \
                 ra[i_] = *reinterpret_cast<const double2 *>(A_ + (size_t)(A_KSTEP * i_) * nb);       \
+                DG_APPLY_SIGN(ra[i_])                                                                \
+            }                                                                                        \
         }                                                                                            \
         _Pragma("unroll") for (int i_ = 0; i_ < NST; i_++)                                           \
             if (((bb_) >> (b_slab + (B_NSTEP / 16) * i_)) & 1u)                                      \
@@ -236,7 +271,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
     // C = -acc at the end), in flight together with the first slab, and the epilogue is stores only -- read-modify-write
     // at the end costs memory round trips that nothing hides.
     unsigned pre = 0;
-    double *__restrict__ C = G.cdense;
+    double *__restrict__ C = reinterpret_cast<double *>(G.cdense); // (CR64: one plane of the destination's mirror)
     if (mapped && ntask <= DG_WINDOW && !G.atomic)
     {
         unsigned m = 0;
@@ -342,6 +377,9 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
 #undef DG_NEXT_STEP
 #undef DG_FILL_WINDOW
 #undef DG_LOAD_SLAB
+#undef DG_APPLY_SIGN
+#undef DG_SET_SIGN
+#undef DG_GET_SIGN
     if (product_counter && lane == 0 && nprod)
         atomicAdd(product_counter, (unsigned long long)nprod); // 16 x 16 x 16 products issued to the matrix cores
 
@@ -417,8 +455,8 @@ struct MirrorJobD
     const u32 *ucp;
     const u16 *uri;
     const u32 *uvi;
-    double *uval;
-    double *dense;  // nb x nb column-major
+    val_t *uval;
+    double *dense;  // nb x nb column-major (CR64: the real plane; the imaginary one mirror_plane_stride(nb) doubles behind)
     const double *diag_tiles; // sparsify of a fresh LU image: its nb/16 diagonal tiles as GETRF left them (16 x 16 column-major
                               // each; the image's own have been inverted in place since), or nullptr
     unsigned long long move_bytes; // host side only (statistics): record entries read + image entries written, or the reverse
@@ -439,6 +477,26 @@ __device__ inline int mirror_column_of(const u32 *sp, int ncols, u32 p)
             hi = mid;
     }
     return lo;
+}
+
+__device__ inline void mirror_put(double *dense, size_t at, int nb, val_t v)
+{
+#if PG_PLANES > 1
+    dense[at] = v.re;
+    dense[at + mirror_plane_stride(nb)] = v.im;
+#else
+    (void)nb;
+    dense[at] = v;
+#endif
+}
+__device__ inline val_t mirror_get(const double *dense, size_t at, int nb)
+{
+#if PG_PLANES > 1
+    return val_t{dense[at], dense[at + mirror_plane_stride(nb)]};
+#else
+    (void)nb;
+    return dense[at];
+#endif
 }
 
 // grid = (jobs, slices): a workgroup owns a run of columns (whole 16-column slabs) of one block, so that a launch with
@@ -491,12 +549,24 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
             {
                 const int c = c0 + i / tpc, within = i % tpc;
                 if ((occ[c >> 4] >> (within >> 3)) & 1u)
+                {
                     reinterpret_cast<double2 *>(J.dense + (size_t)c * nb)[within] = make_double2(0.0, 0.0);
+#if PG_PLANES > 1
+                    reinterpret_cast<double2 *>(J.dense + mirror_plane_stride(nb) + (size_t)c * nb)[within] = make_double2(0.0, 0.0);
+#endif
+                }
             }
         }
         else
         {
+#if PG_PLANES > 1
+          for (int pl_ = 0; pl_ < PG_PLANES; pl_++)
+          {
+            double *base = J.dense + pl_ * mirror_plane_stride(nb) + (size_t)c0 * nb;
+#else
+          {
             double *base = J.dense + (size_t)c0 * nb;
+#endif
             const int words = ncols * nb;
             if ((words & 1) == 0 && (((size_t)c0 * nb) & 1) == 0)
             {
@@ -507,6 +577,7 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
             else
                 for (int i = threadIdx.x; i < words; i += blockDim.x)
                     base[i] = 0.0;
+          }
         }
         __syncthreads();
         // four entries per thread and pass: their index and value loads go out together, then the four stores (one
@@ -515,13 +586,13 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
         for (u32 p0 = e0 + threadIdx.x; p0 < e1; p0 += 4 * blockDim.x)
         {
             u32 r4[4];
-            double v4[4];
+            val_t v4[4];
 #pragma unroll
             for (int u = 0; u < 4; u++)
             {
                 const u32 p = p0 + u * blockDim.x;
                 r4[u] = p < e1 ? J.lo.idx[p] : 0u;
-                v4[u] = p < e1 ? J.lo.val[p] : 0.0;
+                v4[u] = p < e1 ? J.lo.val[p] : v_make(0);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++)
@@ -530,7 +601,7 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
                 if (p < e1)
                 {
                     const int c = c0 + mirror_column_of(sp, ncols, p);
-                    J.dense[(size_t)c * nb + r4[u]] = v4[u];
+                    mirror_put(J.dense, (size_t)c * nb + r4[u], nb, v4[u]);
                     if (mapped && !by_tiles)
                         atomicOr(&occ[c >> 4], 1u << (r4[u] >> 4));
                 }
@@ -540,7 +611,7 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
         {
             const int c = c0 + mirror_column_of(su, ncols, p);
             const u32 r = J.uri[p];
-            J.dense[(size_t)c * nb + r] = J.uval[J.uvi[p]];
+            mirror_put(J.dense, (size_t)c * nb + r, nb, J.uval[J.uvi[p]]);
             if (mapped)
                 atomicOr(&occ[c >> 4], 1u << (r >> 4));
         }
@@ -549,7 +620,12 @@ __global__ __launch_bounds__(256) void densify_kernel(const MirrorJobD *__restri
             __syncthreads();
             const int s_ = threadIdx.x;
             if (s_ < 16 && s_ * 16 >= c0 && s_ * 16 < c1)
+            {
                 map[s_] = (unsigned short)occ[s_];
+#if PG_PLANES > 1
+                reinterpret_cast<unsigned short *>(J.dense + mirror_plane_stride(nb) + (size_t)nb * nb)[s_] = (unsigned short)occ[s_];
+#endif
+            }
         }
     }
 }
@@ -575,7 +651,7 @@ __global__ __launch_bounds__(256) void sparsify_kernel(const MirrorJobD *__restr
         for (u32 p0 = e0 + threadIdx.x; p0 < e1; p0 += 4 * blockDim.x) // (four entries per pass, see densify_kernel)
         {
             u32 r4[4];
-            double v4[4];
+            val_t v4[4];
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 r4[u] = p0 + u * blockDim.x < e1 ? J.lo.idx[p0 + u * blockDim.x] : 0u;
@@ -585,9 +661,13 @@ __global__ __launch_bounds__(256) void sparsify_kernel(const MirrorJobD *__restr
                 const u32 p = p0 + u * blockDim.x;
                 const int c = c0 + mirror_column_of(sp, ncols, p < e1 ? p : e0);
                 const u32 r = r4[u];
+#if PG_PLANES == 1
                 v4[u] = p >= e1 ? 0.0
                                 : (J.diag_tiles && (r >> 4) == (u32)(c >> 4)) ? J.diag_tiles[((c >> 4) << 8) + ((c & 15) << 4) + (r & 15)]
                                                                             : J.dense[(size_t)c * nb + r];
+#else
+                v4[u] = p >= e1 ? v_make(0) : mirror_get(J.dense, (size_t)c * nb + r, nb);
+#endif
             }
 #pragma unroll
             for (int u = 0; u < 4; u++)
@@ -598,8 +678,12 @@ __global__ __launch_bounds__(256) void sparsify_kernel(const MirrorJobD *__restr
         {
             const int c = c0 + mirror_column_of(su, ncols, p);
             const u32 r = J.uri[p];
+#if PG_PLANES == 1
             J.uval[J.uvi[p]] = (J.diag_tiles && (r >> 4) == (u32)(c >> 4)) ? J.diag_tiles[((c >> 4) << 8) + ((c & 15) << 4) + (r & 15)]
                                                                         : J.dense[(size_t)c * nb + r];
+#else
+            J.uval[J.uvi[p]] = mirror_get(J.dense, (size_t)c * nb + r, nb);
+#endif
         }
     }
 }
@@ -609,6 +693,8 @@ __global__ __launch_bounds__(256) void ssssm_flop_count_kernel(const SsssmTaskD 
                                                                unsigned long long *flop_counter)
 {
     const SsssmTaskD T = tasks[blockIdx.x];
+    if (!T.count)
+        return; // (CR64: the other three real products of the same complex update)
     const u32 nnzb = T.b.ptr[nb];
     unsigned long long s = 0;
     for (u32 p = threadIdx.x; p < nnzb; p += blockDim.x)

@@ -2,7 +2,7 @@
 // pg_hip_platform.hip, after Backend / Segment / host_nnz / diag_halves).
 #pragma once
 
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
 
 struct BlockState
 {
@@ -152,8 +152,9 @@ double *obtain_mirror(BlockState &st, int nb)
 {
     if (st.mirror)
         return st.mirror;
-    // values + occupancy map (pg_hip_dense.h) + the nb/16 diagonal tiles a blocked GETRF saves before they are inverted
-    size_t mb = sizeof(double) * (size_t)nb * nb + MIRROR_MAP_BYTES + sizeof(double) * 16 * (size_t)nb;
+    // values + occupancy map (pg_hip_dense.h) + the nb/16 diagonal tiles a blocked GETRF saves before they are inverted;
+    // CR64: two such planes (real, imaginary)
+    size_t mb = PG_PLANES * (sizeof(double) * (size_t)nb * nb + MIRROR_MAP_BYTES + sizeof(double) * 16 * (size_t)nb);
     if (MP.mirror_bytes != mb)
     {
         // block order changed (or first use): start over
@@ -239,6 +240,7 @@ bool mirror_is_ahead(slot_t *s)
     return st.brow == s->brow_pos && st.bcol == s->bcol_pos && st.mirror && !st.sparse_current;
 }
 
+#if defined(CALCULATE_TYPE_R64)
 // dense LU image of the diagonal block `half` belongs to, if GETRF left one
 const double *lu_image_of(slot_t *half)
 {
@@ -289,6 +291,8 @@ const double *request_half_image(slot_t *half, int nb)
     st.sparse_current = true;
     return m;
 }
+
+#endif // R64: LU images
 
 // make sure the block has a mirror holding its current values; queues a densify job if it has to be (re)built.
 // Returns nullptr when no mirror can be had.

@@ -123,6 +123,17 @@ __device__ inline val_t clamp_pivot(val_t p)
     return p;
 }
 
+// Dense-mode updates (mirrors + the f64 MFMA update kernel): R64, and CR64 as two real planes per mirror (pg_hip_dense.h).
+// Dense-mode PANELS (blocked GETRF, dense TSTRF/GESSM on LU images) exist for R64 only.
+#if defined(CALCULATE_TYPE_R64) || defined(CALCULATE_TYPE_CR64)
+#define PG_DENSE_UPDATES 1
+#endif
+#if defined(CALCULATE_TYPE_CR64)
+#define PG_PLANES 2
+#else
+#define PG_PLANES 1
+#endif
+
 // -----------------------------------------------------------------------------------------------------------------
 // device-side descriptors
 // -----------------------------------------------------------------------------------------------------------------
@@ -137,6 +148,10 @@ struct SsssmTaskD
 {
     BlkView a; // op1 (L block), CSC
     BlkView b; // op2 (U block), CSC
+    // MFMA kernel only.  CR64: a complex update is four real products on the planes of the mirrors; `sign` multiplies the A
+    // operand (the A_im B_im product ADDS to the real plane), `count` marks the one of the four whose structural flops count
+    double sign;
+    u32 count, pad_;
 };
 
 struct SsssmGroupD
@@ -227,6 +242,43 @@ __device__ inline unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
+// a dense-mode destination as the sparse update kernel sees it: R64 one nb x nb image, CR64 two real planes (pg_hip_dense.h)
+__host__ __device__ inline size_t cdense_plane_stride(int nb) { return (size_t)nb * nb + 64 / sizeof(double) + (size_t)16 * nb; }
+__device__ inline val_t cdense_get(const val_t *cd, size_t at, int nb)
+{
+#if PG_PLANES > 1
+    const double *p = reinterpret_cast<const double *>(cd);
+    return val_t{p[at], p[at + cdense_plane_stride(nb)]};
+#else
+    (void)nb;
+    return cd[at];
+#endif
+}
+__device__ inline void cdense_put(val_t *cd, size_t at, int nb, val_t v)
+{
+#if PG_PLANES > 1
+    double *p = reinterpret_cast<double *>(cd);
+    p[at] = v.re;
+    p[at + cdense_plane_stride(nb)] = v.im;
+#else
+    (void)nb;
+    cd[at] = v;
+#endif
+}
+__device__ inline void cdense_atomic_add(val_t *cd, size_t at, int nb, val_t v)
+{
+#if PG_PLANES > 1
+    double *p = reinterpret_cast<double *>(cd);
+    if (v.re != 0)
+        atomicAdd(&p[at], v.re);
+    if (v.im != 0)
+        atomicAdd(&p[at + cdense_plane_stride(nb)], v.im);
+#else
+    (void)nb;
+    v_atomic_add(&cd[at], v);
+#endif
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // SSSSM, sparse.  grid = groups * ceil(nb / WAVES) workgroups of WAVES wavefronts; wave w of block (g, cb) owns
 // destination column cb*WAVES + w of group g.
@@ -277,7 +329,7 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
     {
         // dense-mode destination: the column is a contiguous run of its mirror
         for (int r = lane; r < nb; r += 64)
-            acc[r] = atomic ? v_make(0) : G.cdense[(size_t)j * nb + r];
+            acc[r] = atomic ? v_make(0) : cdense_get(G.cdense, (size_t)j * nb + r, nb);
     }
     else
     {
@@ -394,7 +446,7 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
         if (G.cdense)
         {
             for (int r = lane; r < nb; r += 64)
-                v_atomic_add(&G.cdense[(size_t)j * nb + r], acc[r]);
+                cdense_atomic_add(G.cdense, (size_t)j * nb + r, nb, acc[r]);
         }
         else
         {
@@ -408,7 +460,7 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
     else if (G.cdense)
     {
         for (int r = lane; r < nb; r += 64)
-            G.cdense[(size_t)j * nb + r] = acc[r];
+            cdense_put(G.cdense, (size_t)j * nb + r, nb, acc[r]);
     }
     else
     {
@@ -430,9 +482,11 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
 // -----------------------------------------------------------------------------------------------------------------
 // SSSSM, dense (R64) and the dense-mode mirrors: pg_hip_dense.h
 // -----------------------------------------------------------------------------------------------------------------
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 #include "pg_hip_dense.h"
+#endif
+#if defined(CALCULATE_TYPE_R64)
 #include "pg_hip_trsm_dense.h"
 #endif
 
@@ -1961,26 +2015,26 @@ void launch_ssssm(int nb, task_t **list, size_t n)
     {
         Segment seg = acquire_segment();
         // worst case per task: one group + one task descriptor in each class; fill until the segment is full
-        size_t max_tasks = seg.cap / (sizeof(SsssmGroupD) + sizeof(SsssmTaskD) + 32 + 4 * sizeof(u32)) / 2;
+        size_t max_tasks = seg.cap / (sizeof(SsssmGroupD) + sizeof(SsssmTaskD) + 32 + 4 * sizeof(u32)) / (2 * PG_PLANES * PG_PLANES);
         size_t take = std::min(n - i, max_tasks);
         SsssmTaskD *d_tasks_s, *d_tasks_d;
         SsssmGroupD *d_groups_s, *d_groups_d;
         SsssmTaskD *tasks_s = seg.alloc<SsssmTaskD>(take, &d_tasks_s);
-        SsssmTaskD *tasks_d = seg.alloc<SsssmTaskD>(take, &d_tasks_d);
+        SsssmTaskD *tasks_d = seg.alloc<SsssmTaskD>(take * PG_PLANES * PG_PLANES, &d_tasks_d); // (CR64: four real products per update)
         const int tiles_per_dim = nb >= DG_TILE_HOST ? nb / DG_TILE_HOST : 1;
         const unsigned ksplit = (nb <= 256 && nb % 64 == 0 && take * (size_t)(tiles_per_dim * tiles_per_dim) <= 64) ? 4u : 1u;
         SsssmGroupD *groups_s = seg.alloc<SsssmGroupD>(take, &d_groups_s);
-        SsssmGroupD *groups_d = seg.alloc<SsssmGroupD>(take * ksplit, &d_groups_d);
+        SsssmGroupD *groups_d = seg.alloc<SsssmGroupD>(take * ksplit * PG_PLANES, &d_groups_d);
         static std::vector<unsigned short> live_k; // per dense task and tile: K-slabs in which both operands have entries
-        live_k.assign(take * 4, 0);
+        live_k.assign(take * 4 * PG_PLANES * PG_PLANES, 0);
         u32 *d_work;
-        u32 *work = seg.alloc<u32>(take * ksplit * 4, &d_work); // (group, tile) of every workgroup of the MFMA launch
+        u32 *work = seg.alloc<u32>(take * ksplit * 4 * PG_PLANES, &d_work); // (group, tile) of every workgroup of the MFMA launch
         if (!tasks_s || !tasks_d || !groups_s || !groups_d || !work)
         {
             fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
             exit(EXIT_FAILURE);
         }
-        size_t ns = 0, nd = 0, gs = 0, gd = 0;
+        size_t ns = 0, nd = 0, gs = 0, gd = 0, nd_updates = 0; // nd: real MFMA tasks; nd_updates: the updates they stand for
         double bytes_s = 0, bytes_d = 0;
         size_t end = i + take;
         while (i < end)
@@ -2003,7 +2057,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             {
                 nnz_c = host_nnz(dst, nb);
             }
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
             // The destination works on its dense mirror when the mirror is already ahead of the sparse record, or
             // when at least one update of the group is heavy enough for the matrix cores.
             double *cm = nullptr;
@@ -2017,7 +2071,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 if (cm)
                 {
                     block_state(dst, nb).sparse_current = false; // from now on the mirror is ahead of the record
-                    G.cdense = cm;
+                    G.cdense = reinterpret_cast<val_t *>(cm);
                 }
             }
             if (!cm)
@@ -2035,43 +2089,58 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                     G.uval = up->d_value;
                 }
             }
-            size_t s0 = ns, d0 = nd;
+            size_t s0 = ns;
+#if defined(PG_DENSE_UPDATES)
+            // updates of this destination that go to the matrix cores: (operand mirrors, live K-slabs per tile)
+            struct Heavy
+            {
+                SsssmTaskD T;
+                unsigned short live[4];
+            };
+            static thread_local std::vector<Heavy> heavy;
+            heavy.clear();
+#endif
             for (size_t t = i; t < j; t++)
             {
                 slot_t *a = list[t]->op1, *b = list[t]->op2;
                 SsssmTaskD T;
+                memset(&T, 0, sizeof(T));
                 T.a = BlkView{a->d_columnpointer, a->d_rowindex, a->d_value};
                 T.b = BlkView{b->d_columnpointer, b->d_rowindex, b->d_value};
+                T.sign = 1.0;
+                T.count = 1;
                 u32 na = host_nnz(a, nb), nbz = host_nnz(b, nb);
                 double by = (SV + 2) * ((double)na + nbz) + (2 * SV + 2) * (double)nnz_c + 12.0 * (nb + 1);
                 bool on_mfma = false;
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
                 if (G.cdense && is_heavy_update(na, nbz, nb))
                 {
                     double *am = current_mirror(a, nb);
                     double *bm = am ? current_mirror(b, nb) : nullptr;
                     if (am && bm)
                     {
-                        T.a.val = am; // the pattern pointers stay: the flop counter reads them
-                        T.b.val = bm;
+                        T.a.val = reinterpret_cast<val_t *>(am); // the pattern pointers stay: the flop counter reads them
+                        T.b.val = reinterpret_cast<val_t *>(bm);
                         on_mfma = true;
                     }
                 }
-#endif
                 if (on_mfma)
                 {
-#if defined(CALCULATE_TYPE_R64)
                     // tiles of the destination this update can reach (tile = tm + tiles * tn), per K-slab
+                    Heavy H;
+                    H.T = T;
                     const BlockState *sa = MP.blocks.find(block_key(a)), *sb = MP.blocks.find(block_key(b));
-                    for (int tl = 0; tl < tiles_per_dim * tiles_per_dim; tl++)
-                        live_k[nd * 4 + tl] = (sa && sb && sa->occ_valid && sb->occ_valid)
-                                                  ? (unsigned short)(sa->occ_a[tl % tiles_per_dim] & sb->occ_b[tl / tiles_per_dim])
-                                                  : (unsigned short)0xFFFF;
-#endif
-                    tasks_d[nd++] = T;
+                    for (int tl = 0; tl < 4; tl++)
+                        H.live[tl] = tl >= tiles_per_dim * tiles_per_dim ? (unsigned short)0
+                                     : (sa && sb && sa->occ_valid && sb->occ_valid)
+                                         ? (unsigned short)(sa->occ_a[tl % tiles_per_dim] & sb->occ_b[tl / tiles_per_dim])
+                                         : (unsigned short)0xFFFF;
+                    heavy.push_back(H);
                     bytes_d += by;
+                    nd_updates++;
                 }
-                else
+#endif
+                if (!on_mfma)
                 {
                     tasks_s[ns++] = T;
                     bytes_s += by;
@@ -2082,9 +2151,13 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             size_t chunk = (size_t)(B.opt_group_chunk > 0 ? B.opt_group_chunk : 1 << 30);
             if (B.opt_group_chunk > 0 && take <= (size_t)B.opt_small_launch_tasks)
                 chunk = 1;
+            size_t nheavy = 0;
+#if defined(PG_DENSE_UPDATES)
+            nheavy = heavy.size();
+#endif
             // ... and a destination updated by both kernels at once (they run side by side on two streams) must take
             // atomics from both
-            const bool split = (ns - s0) > chunk || (nd - d0) > chunk || ((ns > s0) && (nd > d0) && B.opt_two_streams);
+            const bool split = (ns - s0) > chunk || nheavy > chunk || ((ns > s0) && nheavy && B.opt_two_streams);
             for (size_t c = s0; c < ns; c += chunk)
             {
                 G.task_begin = (u32)c;
@@ -2092,29 +2165,60 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 G.atomic = split ? 1u : 0u;
                 groups_s[gs++] = G;
             }
-            for (size_t c = d0; c < nd; c += chunk)
+#if defined(PG_DENSE_UPDATES)
+            // R64: one task per update.  CR64: per destination plane the two real products of every update, consecutive, so
+            // that one accumulator pass serves both (C_re -= A_re B_re - A_im B_im;  C_im -= A_re B_im + A_im B_re)
+            for (int plane = 0; plane < PG_PLANES && nheavy; plane++)
             {
-                G.task_begin = (u32)c;
-                G.task_end = (u32)std::min(nd, c + chunk);
-                G.atomic = (split || ksplit > 1) ? 1u : 0u;
-                const unsigned slabs = (unsigned)nb / 16u, per = slabs / ksplit;
-                for (unsigned q = 0; q < ksplit; q++)
+                const size_t d0 = nd;
+                for (const Heavy &H : heavy)
+                    for (int term = 0; term < PG_PLANES; term++)
+                    {
+                        SsssmTaskD T = H.T;
+#if PG_PLANES > 1
+                        const size_t ps = mirror_plane_stride(nb);
+                        double *am = reinterpret_cast<double *>(H.T.a.val), *bm = reinterpret_cast<double *>(H.T.b.val);
+                        // plane 0 (real):  + A_re B_re  - A_im B_im      plane 1 (imaginary):  + A_re B_im  + A_im B_re
+                        const int a_im = term, b_im = plane ^ term;
+                        T.a.val = reinterpret_cast<val_t *>(am + (a_im ? ps : 0));
+                        T.b.val = reinterpret_cast<val_t *>(bm + (b_im ? ps : 0));
+                        T.sign = (plane == 0 && term == 1) ? -1.0 : 1.0;
+                        T.count = (plane == 0 && term == 0) ? 1u : 0u;
+#endif
+                        for (int tl = 0; tl < 4; tl++)
+                            live_k[nd * 4 + tl] = H.live[tl];
+                        tasks_d[nd++] = T;
+                    }
+                SsssmGroupD GP = G;
+#if PG_PLANES > 1
+                GP.cdense = reinterpret_cast<val_t *>(reinterpret_cast<double *>(G.cdense) + (size_t)plane * mirror_plane_stride(nb));
+#endif
+                const size_t dchunk = chunk >= ((size_t)1 << 28) ? chunk : chunk * PG_PLANES;
+                for (size_t c = d0; c < nd; c += dchunk)
                 {
-                    G.slab_mask = ksplit > 1 ? (((1u << per) - 1u) << (q * per)) : 0u;
-                    const unsigned kmask = G.slab_mask ? G.slab_mask : 0xFFFFu;
-                    G.live_tiles = 0;
-                    for (u32 t = G.task_begin; t < G.task_end; t++)
-                        for (int tl = 0; tl < tiles_per_dim * tiles_per_dim; tl++)
-                            if (live_k[(size_t)t * 4 + tl] & kmask)
-                                G.live_tiles |= 1u << tl;
-                    groups_d[gd++] = G;
+                    GP.task_begin = (u32)c;
+                    GP.task_end = (u32)std::min(nd, c + dchunk);
+                    GP.atomic = (split || ksplit > 1) ? 1u : 0u;
+                    const unsigned slabs = (unsigned)nb / 16u, per = slabs / ksplit;
+                    for (unsigned q = 0; q < ksplit; q++)
+                    {
+                        GP.slab_mask = ksplit > 1 ? (((1u << per) - 1u) << (q * per)) : 0u;
+                        const unsigned kmask = GP.slab_mask ? GP.slab_mask : 0xFFFFu;
+                        GP.live_tiles = 0;
+                        for (u32 t = GP.task_begin; t < GP.task_end; t++)
+                            for (int tl = 0; tl < tiles_per_dim * tiles_per_dim; tl++)
+                                if (live_k[(size_t)t * 4 + tl] & kmask)
+                                    GP.live_tiles |= 1u << tl;
+                        groups_d[gd++] = GP;
+                    }
                 }
             }
+#endif
             G.slab_mask = 0;
             G.live_tiles = 0;
             i = j;
         }
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
         // mirrors that have to be (re)built for this launch, and sparse records that must catch up first
         if (!MP.to_sparsify.empty())
             flush_mirror_jobs(nb, MP.to_sparsify, false);
@@ -2151,7 +2255,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             B.stats.tasks[4] += ns;
             B.stats.alg_bytes[4] += bytes_s;
         }
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
         if (gd)
         {
             hipStream_t ds = B.stream;
@@ -2185,7 +2289,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join, 0)); // join before anything later on the main stream
             }
             B.stats.launches[5]++;
-            B.stats.tasks[5] += nd;
+            B.stats.tasks[5] += nd_updates;
             B.stats.alg_bytes[5] += bytes_d;
         }
 #endif
@@ -2302,17 +2406,19 @@ void launch_trsm(int nb, task_t **list, size_t n)
             {
                 require_sparse(dst, nb); // updates may have been accumulating in the block's mirror
                 tasks[nsparse++] = T;
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
                 if (BlockState *found = MP.blocks.find(block_key(dst)))
                     found->mirror_current = false; // the sparse solve rewrites the record
 #endif
             }
         }
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
         if (!MP.to_sparsify.empty())
             flush_mirror_jobs(nb, MP.to_sparsify, false);
         if (!MP.to_densify.empty())
             flush_mirror_jobs(nb, MP.to_densify, true);
+#endif
+#if defined(CALCULATE_TYPE_R64)
         if (!g_half_image_jobs.empty())
         {
             // images of remote diagonal blocks: build, then invert their diagonal tiles (main stream, before the solves)
@@ -2479,6 +2585,17 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             T.preloaded = 0;
             T.defer_gather = 0;
             T.invert_tiles = 0;
+#if defined(PG_DENSE_UPDATES) && !defined(CALCULATE_TYPE_R64)
+            {
+                // (CR64: no blocked kernel) updates may have accumulated in the block's mirror: the record catches up first,
+                // and the mirror is stale once the block is factorised
+                BlockState &st = block_state(lo, nb);
+                if (!st.sparse_current && st.mirror)
+                    MP.to_sparsify.push_back(mirror_job(lo, st.mirror, nb));
+                st.sparse_current = true;
+                st.mirror_current = false;
+            }
+#endif
 #if defined(CALCULATE_TYPE_R64)
             {
                 // work on the block's own mirror whenever the pool has one: it may already hold the block (updates
@@ -2520,7 +2637,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             by += (2 * SV + 2) * ((double)host_nnz(lo, nb) + host_nnz(up, nb)) + 8.0 * (nb + 1);
         }
         hipStream_t ks = gs;
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
         if (!MP.to_sparsify.empty())
         {
             flush_mirror_jobs(nb, MP.to_sparsify, false); // (main stream) these blocks must see it: stay on the main stream
@@ -2980,7 +3097,7 @@ extern "C"
 
     void pangulu_platform_0201001_prepare_blocks(pangulu_inblock_idx nb, pangulu_uint64_t nslot, pangulu_storage_slot_t **slots)
     {
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES)
         if (nb > 256 || nb % 16 != 0 || nslot == 0)
             return;
         static const bool enabled = !(getenv("PANGULU_HIP_OCCUPANCY_SUMMARIES") && atoi(getenv("PANGULU_HIP_OCCUPANCY_SUMMARIES")) == 0);

@@ -132,3 +132,30 @@ def test_saddle_point_with_matching_on_the_hip_path(nx, nb):
     for f in ("L", "U"):
         assert max_rel_diff(gpu[f], ref[f]) <= 1e-11, f
     assert gpu["residual"] <= 1e-10 and abs(gpu["residual"] - ref["residual"]) <= 1e-10
+
+
+@pytest.mark.parametrize("permille", [10, 0, 1001])
+@pytest.mark.parametrize("name,gen,nb", [
+    ("poisson14c_nb128", lambda: M.poisson3d(14, dtype=np.complex128, shift=0.5j), 128),
+    ("fem27c_14_nb256", lambda: M.fem27(14, dtype=np.complex128), 256),
+    ("randomc_700_nb128", lambda: M.random_pattern(700, 0.02, 4, dtype=np.complex128), 128),
+], ids=["poisson14c_nb128", "fem27c_14_nb256", "randomc_700_nb128"])
+def test_cr64_updates_on_the_matrix_cores(name, gen, nb, permille):
+    """CR64 dense-mode updates: a complex block's mirror is two real planes, a complex update four real MFMA products
+    (pg_hip_dense.h; the reference calls cublasZgemm here, ...0201000.cu:778-816).  Every mix of mirrored and sparse
+    blocks must give the oracle's factors; threshold 0 puts every update on the matrix cores, 1001 none."""
+    mat = gen()
+    gpu = factorize(mat, nb, "hip", vtype="cr64", hip_options={_lib.HIP_OPT_DENSE_THRESHOLD_PERMILLE: permille})
+    ref = factorize(mat, nb, oracle_library("cr64"), vtype="cr64")
+    st = gpu["hip_stats"]
+    if permille == 0:
+        assert st["ssssm_dense_mfma"]["tasks"] > 0 and st["ssssm_sparse"]["tasks"] == 0, st
+    if permille == 1001:
+        assert st["ssssm_dense_mfma"]["tasks"] == 0
+    if permille == 10 and nb == 256:
+        assert st["ssssm_dense_mfma"]["tasks"] > 0, st
+    for f in ("L", "U"):
+        assert max_rel_diff(gpu[f], ref[f]) <= 1e-12, (name, f, permille)
+    assert gpu["residual"] <= 1e-12 and lu_check(mat, gpu) <= 1e-12
+    counted = sum(v["flops"] for v in st.values())
+    assert counted == gpu["info"]["flop"], (counted, gpu["info"]["flop"])
