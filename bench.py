@@ -331,7 +331,7 @@ def main():
         line = {
             "metric": "numeric factorisation GFLOP/s (pangulu_gstrf, R64)",
             "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "step_ms": [round(1e3 * t, 2) for t in times], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if not args.mtx else "file",
             "config": {
                 "workload": workload, "n": int(info["n"]), "nnz": int(info["nnz"]), "nb": int(info["nb"]),

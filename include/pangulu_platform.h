@@ -275,6 +275,11 @@ extern "C"
     void pangulu_platform_0201001_block_trsv(pangulu_inblock_idx nb, int upper, pangulu_uint64_t nlevel, const pangulu_uint64_t *level_ptr,
                                              const pangulu_hip_solve_row_t *rows, pangulu_storage_slot_t *const *blk_slots,
                                              const pangulu_exblock_idx *blk_bcol, calculate_type *x, pangulu_uint64_t xlen);
+    /* Optional: keep the calling thread (and threads it creates afterwards) on the CPUs of the NUMA node the device hangs off
+     * while enable = 1, restore its previous affinity mask with enable = 0 (the reference pins its threads as well,
+     * src/pangulu_thread.c:3-12).  The native host calls it around pangulu_init / gstrf / gstrs.  Returns 0 when the mask
+     * was changed / restored, non-zero when there was nothing to do (no NUMA information, PANGULU_AMD_BIND_NUMA=0). */
+    int pangulu_platform_0201001_bind_near_device(int enable);
     /* stream all numeric kernels are launched on (a hipStream_t); for event timing in bench.py */
     void *pangulu_platform_0201001_get_stream(void);
     /* Cumulative per-kernel-class counters since the last reset.  Classes: 1 GETRF, 2 TSTRF, 3 GESSM,

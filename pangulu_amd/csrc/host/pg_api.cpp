@@ -72,6 +72,7 @@ void bind_builtin_hip(Platform &p)
     p.marker_done = pangulu_platform_0201001_marker_done;
     p.marker_wait = pangulu_platform_0201001_marker_wait;
     p.block_trsv = pangulu_platform_0201001_block_trsv;
+    p.bind_near_device = pangulu_platform_0201001_bind_near_device;
 }
 
 Platform &active_platform()
@@ -93,6 +94,26 @@ Options &pending_options() { return g_options; }
 } // namespace pg
 
 using namespace pg;
+
+namespace
+{
+// the calling thread stays next to the device for the duration of an API call (pangulu_platform_0201001_bind_near_device)
+struct NearDevice
+{
+    Platform &plat;
+    bool bound = false;
+    explicit NearDevice(Platform &p) : plat(p)
+    {
+        if (!plat.host_memory && plat.bind_near_device)
+            bound = plat.bind_near_device(1) == 0;
+    }
+    ~NearDevice()
+    {
+        if (bound)
+            plat.bind_near_device(0);
+    }
+};
+} // namespace
 
 extern "C"
 {
@@ -324,6 +345,7 @@ extern "C"
             int dev = lr ? atoi(lr) % ndev : rank % ndev;
             plat.set_default_device(dev);
         }
+        NearDevice near(plat); // analysis + record upload from the device's NUMA node (host arena, pinned staging)
 
         Solver *S = new Solver();
         memset(&S->info, 0, sizeof(S->info));
@@ -507,6 +529,7 @@ extern "C"
             exit(1);
         }
         Solver *S = (Solver *)*pangulu_handle;
+        NearDevice near(active_platform());
         numeric_factorize(*S);
     }
 
@@ -519,6 +542,7 @@ extern "C"
             exit(1);
         }
         Solver *S = (Solver *)*pangulu_handle;
+        NearDevice near(active_platform());
         Comm *comm = world();
         std::vector<val_t> b(S->n);
         const bool scaled = !S->scale_row.empty();

@@ -72,6 +72,7 @@ struct Platform
     void *(*marker_record)() = nullptr;
     int (*marker_done)(void *) = nullptr;
     void (*marker_wait)(void *) = nullptr;
+    int (*bind_near_device)(int) = nullptr;
     void (*block_trsv)(pangulu_inblock_idx, int, pangulu_uint64_t, const pangulu_uint64_t *, const pangulu_hip_solve_row_t *, slot_t *const *,
                        const pangulu_exblock_idx *, val_t *, pangulu_uint64_t) = nullptr;
 };

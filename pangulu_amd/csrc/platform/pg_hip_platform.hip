@@ -20,6 +20,9 @@
 // PANGULU_TOL pivot clamp of :79-84,152-157, which the reference's GPU path lacks).
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+#include <cctype>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -2903,6 +2906,91 @@ extern "C"
         *device_num = n;
     }
 
+    // CPUs of the NUMA node the device hangs off (sysfs), intersected with what the thread may run on.
+    static bool cpus_near_device(int device, cpu_set_t *out)
+    {
+        char bdf[64] = {0};
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return false;
+        }
+        for (char *c = bdf; *c; c++)
+            *c = (char)tolower(*c);
+        char path[160];
+        snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+        FILE *f = fopen(path, "r");
+        int node = -1;
+        if (!f || fscanf(f, "%d", &node) != 1)
+            node = -1;
+        if (f)
+            fclose(f);
+        if (node < 0)
+            return false;
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        f = fopen(path, "r");
+        if (!f)
+            return false;
+        char list[1024] = {0};
+        const bool got = fgets(list, sizeof(list), f) != nullptr;
+        fclose(f);
+        if (!got)
+            return false;
+        cpu_set_t allowed, want;
+        CPU_ZERO(&want);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+            return false;
+        for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n"))
+        {
+            int lo = 0, hi = 0;
+            const int k = sscanf(tok, "%d-%d", &lo, &hi);
+            if (k < 1)
+                continue;
+            if (k == 1)
+                hi = lo;
+            for (int c = lo; c <= hi && c < CPU_SETSIZE; c++)
+                if (CPU_ISSET(c, &allowed))
+                    CPU_SET(c, &want);
+        }
+        if (CPU_COUNT(&want) == 0)
+            return false;
+        *out = want;
+        return true;
+    }
+
+    // Keep the calling thread (and the threads it creates) on the CPUs next to the device while `enable`, give it back its
+    // old mask otherwise.  The host side of the factorisation is two latency-critical threads (scheduler and launcher) that
+    // write task descriptors into pinned host memory the kernels read in place: on the two-socket bench host a
+    // factorisation takes 46.0-48.1 ms with them on the device's NUMA node, 50-60 ms (and single steps up to 74 ms) wherever
+    // the OS puts them, 62 ms on the other socket.  The reference pins its threads too (pangulu_bind_to_core,
+    // src/pangulu_thread.c:3-12).  PANGULU_AMD_BIND_NUMA=0 turns it off.  Returns 0 when the mask was changed / restored.
+    int pangulu_platform_0201001_bind_near_device(int enable)
+    {
+        static thread_local cpu_set_t saved;
+        static thread_local bool have_saved = false;
+        static const bool off = getenv("PANGULU_AMD_BIND_NUMA") && atoi(getenv("PANGULU_AMD_BIND_NUMA")) == 0;
+        if (off)
+            return 1;
+        if (!enable)
+        {
+            if (!have_saved)
+                return 1;
+            have_saved = false;
+            return sched_setaffinity(0, sizeof(saved), &saved) == 0 ? 0 : 1;
+        }
+        if (have_saved)
+            return 0; // (nested: already there)
+        cpu_set_t want;
+        if (!cpus_near_device(B.device, &want))
+            return 1;
+        if (sched_getaffinity(0, sizeof(saved), &saved) != 0)
+            return 1;
+        if (sched_setaffinity(0, sizeof(want), &want) != 0)
+            return 1;
+        have_saved = true;
+        return 0;
+    }
+
     void pangulu_platform_0201001_set_default_device(int device_num)
     {
         B.device = device_num;
@@ -2910,7 +2998,11 @@ extern "C"
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device_num));
         pangulu_gpu_shared_mem_size = (int)prop.sharedMemPerBlock;
+        // (the pinned descriptor segments are allocated here: from the device's NUMA node)
+        const int bound = pangulu_platform_0201001_bind_near_device(1);
         ensure_ready();
+        if (bound == 0)
+            pangulu_platform_0201001_bind_near_device(0);
     }
 
     void pangulu_platform_0201001_get_device_name(char *name, int device_num)
