@@ -10,6 +10,7 @@ struct BlockState
     bool mirror_current = false; // mirror holds the block's current values
     bool sparse_current = true;  // the sparse record holds the block's current values
     bool lu_image = false;       // diagonal block: the mirror holds L\\U with inverted diagonal tiles (pg_hip_trsm_dense.h)
+    bool lu_map = false;         // ... and the occupancy map behind it describes the factorised block (tiled GETRF)
     unsigned char image_halves = 0; // ... of which triangles: 1 = strictly lower (L), 2 = upper (U)
     u32 brow = 0, bcol = 0, nnz = 0;
     // Host-side occupancy summary of an OWNED off-diagonal block's pattern (pangulu_platform_0201001_prepare_blocks, once
@@ -253,6 +254,12 @@ const double *lu_image_of(slot_t *half)
         return nullptr;
     return st.mirror;
 }
+bool lu_image_has_map(slot_t *half)
+{
+    slot_t *lo = canon_dst(half);
+    const BlockState *found = MP.blocks.find(block_key(lo));
+    return found && found->lu_image && found->lu_map;
+}
 
 // A diagonal block factorised on another rank has no image here: queue one to be built from the halves that have
 // arrived (pg_hip_trsm_dense.h, half_image_kernel).  Returns the mirror, or nullptr when the pool is exhausted.
@@ -286,6 +293,7 @@ const double *request_half_image(slot_t *half, int nb)
     J.dense = m;
     g_half_image_jobs.push_back(J);
     st.lu_image = true;
+    st.lu_map = false; // (half_image_kernel writes no map)
     st.image_halves = halves;
     st.mirror_current = false; // (the mirror is an image now, not the block)
     st.sparse_current = true;

@@ -138,6 +138,9 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             ops += (unsigned long long)nl * (1ull + 2ull * (nu - 1));
     }
     __syncthreads();
+    // the image is a mirror: the dense solves of this level skip structurally empty factor tiles by this map
+    if (T.invert_tiles && tid < 16)
+        reinterpret_cast<unsigned short *>(D + (size_t)nb * nb)[tid] = (unsigned short)smap[tid];
     GETRF_STAMP(0)
 
     auto live = [&](int ti, int tj) -> bool

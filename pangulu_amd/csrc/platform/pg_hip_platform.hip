@@ -2388,7 +2388,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
                         D.b = bm;
                         D.lu = lu;
                         D.is_tstrf = T.is_tstrf;
-                        D.pad_ = 0;
+                        D.lu_map = lu_image_has_map(half) ? 1u : 0u;
                         {
                             // strips of the solve = row slabs (TSTRF) / column slabs (GESSM) of the block
                             const BlockState *sd = MP.blocks.find(block_key(dst));
@@ -2542,6 +2542,13 @@ void launch_trsm(int nb, task_t **list, size_t n)
 // ---- GETRF -------------------------------------------------------------------------------------------------------
 // `gs`: stream the factorisation kernels go to (the main stream, or a side stream that has already been made to wait
 // for everything these blocks depend on; the caller joins it back)
+// the tiled GETRF kernel (pg_hip_getrf_tiled.h) is the default; PANGULU_HIP_GETRF_TILED=0 selects round 1's kernels
+inline bool getrf_tiled_selected()
+{
+    static const bool on = !(getenv("PANGULU_HIP_GETRF_TILED") && atoi(getenv("PANGULU_HIP_GETRF_TILED")) == 0);
+    return on;
+}
+
 void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_join)
 {
     HostTimer ht(2);
@@ -2621,6 +2628,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         }
                         lu_images.push_back(m);
                         st.lu_image = true;
+                        st.lu_map = getrf_tiled_selected();
                         st.image_halves = 3;
                     }
                     else if (!st.sparse_current && st.mirror)
@@ -2669,7 +2677,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 // without -- both kernels slow down when they share CUs; off by default)
                 static const long narrow_from = getenv("PANGULU_HIP_GETRF_NARROW_FROM") ? atol(getenv("PANGULU_HIP_GETRF_NARROW_FROM")) : 1 << 30;
                 static const bool lookahead_kernel = !(getenv("PANGULU_HIP_GETRF_LOOKAHEAD") && atoi(getenv("PANGULU_HIP_GETRF_LOOKAHEAD")) == 0);
-                static const bool tiled_kernel = !(getenv("PANGULU_HIP_GETRF_TILED") && atoi(getenv("PANGULU_HIP_GETRF_TILED")) == 0);
+                static const bool tiled_kernel = getrf_tiled_selected();
                 if (tiled_kernel)
                 {
                     // static tile ownership + a dedicated factorisation wavefront (pg_hip_getrf_tiled.h)

@@ -21,7 +21,8 @@ struct TrsmDenseTaskD
     double *b;        // mirror of the block being solved, overwritten by the solution
     const double *lu; // LU image of the diagonal block with inverted diagonal tiles
     u32 is_tstrf;
-    u32 pad_;
+    u32 lu_map; // 1: the occupancy map behind `lu` describes the factorised block (written by getrf_tiled_f64_kernel / densify):
+                // products with structurally empty factor tiles are skipped; 0: every tile of the factor counts as live
 };
 
 // one wavefront per 16 x 16 diagonal tile: lane c < 16 computes column c of inv(U_pp) (back substitution) and of
@@ -364,6 +365,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
     }
     if (my_lv == 0)
         return;
+    // which factor tiles (q, p), q < p, hold pattern entries: column p of U's tile grid (TSTRF) / row p of L's (GESSM).
+    // Diagonal blocks of the leaf levels are sparse at tile granularity too; a product with an empty factor tile is an
+    // exact no-op, so it is neither loaded nor multiplied.
+    const unsigned short *fmap = mirror_map(LU, nb);
+    const bool use_fmap = T.lu_map != 0;
     // factor tile (q, p): the four k-quarters of this lane's A operand
     const size_t a_lane = tstrf ? (size_t)l15 * nb + l4 : (size_t)l4 * nb + l15;
 #define TRSM_A_PTR(q_, p_) (LU + a_lane + (tstrf ? (size_t)(16 * (p_)) * nb + 16 * (q_) : (size_t)(16 * (q_)) * nb + 16 * (p_)))
@@ -385,6 +391,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
     {
         if (!((my_lv >> p) & 1u))
             continue; // (wavefront-uniform)
+        // live products of this panel: solution tile q live AND factor tile (q, p) live
+        unsigned lq = my_lv;
+        if (use_fmap)
+        {
+            unsigned fl = 0;
+            if (tstrf)
+                fl = fmap[p]; // tile column p of the image: bit q = rows 16q..
+            else
+            {
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+                    fl |= (((unsigned)fmap[q] >> p) & 1u) << q; // tile row p: bit q = columns 16q..
+            }
+            lq &= (unsigned)__builtin_amdgcn_readfirstlane((int)fl);
+        }
         // the inverted diagonal tile goes in flight first, it is needed last
         double ad[4];
         TRSM_A_LOAD(ad, p, p)
@@ -395,9 +416,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
         double a0[4], a1[4], n0[4], n1[4];
         if (p > 0)
         {
-            if ((my_lv >> 0) & 1u)
+            if ((lq >> 0) & 1u)
                 TRSM_A_LOAD(n0, 0, p)
-            if (p > 1 && ((my_lv >> 1) & 1u))
+            if (p > 1 && ((lq >> 1) & 1u))
                 TRSM_A_LOAD(n1, 1, p)
         }
 #pragma unroll
@@ -409,17 +430,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
                 a0[kq] = n0[kq];
                 a1[kq] = n1[kq];
             }
-            if (q + 2 < p && ((my_lv >> (q + 2)) & 1u))
+            if (q + 2 < p && ((lq >> (q + 2)) & 1u))
                 TRSM_A_LOAD(n0, q + 2, p)
-            if (q + 3 < p && ((my_lv >> (q + 3)) & 1u))
+            if (q + 3 < p && ((lq >> (q + 3)) & 1u))
                 TRSM_A_LOAD(n1, q + 3, p)
-            if ((my_lv >> q) & 1u)
+            if ((lq >> q) & 1u)
             {
 #pragma unroll
                 for (int kq = 0; kq < 4; kq++)
                     part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[kq], xs[q][kq], part[kq], 0, 0, 0);
             }
-            if (q + 1 < p && ((my_lv >> (q + 1)) & 1u))
+            if (q + 1 < p && ((lq >> (q + 1)) & 1u))
             {
 #pragma unroll
                 for (int kq = 0; kq < 4; kq++)
