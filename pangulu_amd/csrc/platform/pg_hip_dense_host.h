@@ -108,7 +108,10 @@ MirrorPool MP;
 
 inline bool dense_mode_available(int nb)
 {
-    return (nb % DG_TILE == 0) && B.opt_dense_permille <= 1000;
+    // 128 or 256: the work lists, the per-task live-slab tables and the (group, tile) encoding of a launch are built for at
+    // most 2 x 2 tiles of 128 and 16 K-slabs; larger block orders stay on the pattern-driven kernels (found by
+    // test_block_orders_beyond_the_tuned_ones: nb = 384 used to overrun those tables)
+    return (nb % DG_TILE == 0) && nb <= 256 && B.opt_dense_permille <= 1000;
 }
 
 // Is C -= A*B worth the matrix cores?  The LDS kernel's time grows with the structural flops, about 2*nnzA*nnzB/nb for

@@ -159,3 +159,14 @@ def test_cr64_updates_on_the_matrix_cores(name, gen, nb, permille):
     assert gpu["residual"] <= 1e-12 and lu_check(mat, gpu) <= 1e-12
     counted = sum(v["flops"] for v in st.values())
     assert counted == gpu["info"]["flop"], (counted, gpu["info"]["flop"])
+
+
+@pytest.mark.parametrize("nb", [384, 512, 96, 48])
+def test_block_orders_beyond_the_tuned_ones(nb):
+    """nb = 384 / 512: above the 256 the occupancy maps, the tiled GETRF and the dense solves are built for (the MFMA update
+    kernel then treats every 16 x 16 piece as live, GETRF and the solves fall back to the pattern-driven kernels); nb = 96 / 48:
+    not a multiple of 128, no dense mode at all.  The reference accepts any nb (16-bit in-block indices)."""
+    mat = M.fem27(12)
+    gpu = factorize(mat, nb, "hip")
+    ref = factorize(mat, nb, oracle_library("r64"))
+    _check(mat, nb, gpu, ref, res_tol=2e-12)
