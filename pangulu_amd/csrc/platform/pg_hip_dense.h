@@ -47,7 +47,12 @@ __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 // ---------------------------------------------------------------------------------------------------------------
 #define DG_TILE 128
 #define DG_K 16
-#define DG_LD 144 // padded slab row (doubles): rows of consecutive k land 32 banks apart
+#ifndef DG_LD
+// padded slab row (doubles).  144 (round 1) makes the MFMA fragment reads conflict-free but lands rows two apart on the same
+// banks, which is exactly what the B-slab staging writes (eight threads write rows 0, 2, .. 14 of one column at once: an
+// 8-way conflict per store); 146 / 148 spread those too: 24.6 -> 23.6 ms of update-kernel time (152: 24.8, 136: 24.2)
+#define DG_LD 148
+#endif
 #define DG_WINDOW 16 // tasks whose bookkeeping is held in LDS at a time
 
 // Wavefronts per workgroup.  4 (default): 64 x 64 sub-tiles (4 x 4 accumulators, 207 registers), two wavefronts per SIMD.
