@@ -39,14 +39,42 @@ __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 // ---------------------------------------------------------------------------------------------------------------
 // C(nb x nb) -= sum_t A_t * B_t on dense mirrors.  Workgroup = 4 wavefronts = one 128 x 128 tile of C; each
 // wavefront a 64 x 64 sub-tile as 4 x 4 accumulators of v_mfma_f64_16x16x4_f64.  K runs over all tasks of the
-// group in steps of 16: the 128 x 16 slab of A and the 16 x 128 slab of B go through LDS ([k][m] / [k][n], row
-// stride 144 doubles = conflict-free b64 fragment reads), the next slab is prefetched into registers while the
-// current one feeds the matrix cores.  The product is formed transposed (A operand from the B slab, B operand from
-// the A slab) so that accumulator register g of lane l is C(m0 + (l & 15), n0 + (l >> 4) + 4 g): the final
+// group in steps of 16: the 128 x 16 slab of A and the 16 x 128 slab of B go through LDS ([k][m] / [k][n], padded
+// rows = conflict-free b64 fragment reads).  The product is formed transposed (A operand from the B slab, B operand
+// from the A slab) so that accumulator register g of lane l is C(m0 + (l & 15), n0 + (l >> 4) + 4 g): the final
 // read-modify-write of C moves 128-byte segments.
+//
+// Pipeline (round 2, third version).  Structural zeros come from the occupancy maps behind the mirrors: per window of
+// DG_WINDOW tasks all 256 threads test one (task, K-slab) pair each and the live ones are compacted into a step list
+// in LDS (one packed word per step: which 16-row pieces of A, which 16-column pieces of B, slab, task).  The main
+// loop walks that list with TWO slabs of operands in flight in registers (sets X and Y) besides the one in LDS:
+//     iteration j:   issue loads of step j+2  |  MFMAs of step j from LDS image j&1  |  wait for step j+1 only,
+//                    write it to image (j+1)&1  |  barrier
+// so a slab's loads have two product phases to arrive -- with partly filled blocks one phase (a few hundred to two
+// thousand cycles) is shorter than a loaded memory round trip, and the wait at the LDS stage was 16 % of the kernel.
+// Loads and stores share one counter (vmcnt) that retires in order, and the compiler's wait insertion assumes the worst
+// at every join of control flow: the slab loads therefore are UNCONDITIONAL -- a piece that is structurally empty, and
+// the two steps past the end of the list, load 16 bytes from the start of the mirror instead (an L1 hit, never used) --
+// which keeps the count between "loads of step j+1" and "now" a compile-time constant (8).
 // ---------------------------------------------------------------------------------------------------------------
 #define DG_TILE 128
 #define DG_K 16
+// a workgroup-uniform address pinned in scalar registers: the compiler otherwise folds it into 64-bit per-lane arithmetic
+// (base + lane offset first, then the uniform part on top, in vector instructions) instead of the scalar-base form of
+// global_load / global_store (scalar base + 32-bit lane offset + immediate)
+__device__ inline const char __attribute__((address_space(1))) *dg_scalar_base(const char __attribute__((address_space(1))) *p)
+{
+    unsigned long long v = (unsigned long long)p;
+    asm("" : "+s"(v));
+    return (const char __attribute__((address_space(1))) *)v;
+}
+// ... and the 32-bit lane offset kept as a value of the using basic block (hoisted out of it, its zero extension arrives as a
+// 64-bit register pair and the scalar-base form is not selected)
+__device__ inline unsigned dg_lane_offset(unsigned v)
+{
+    asm("" : "+v"(v));
+    return v;
+}
 #ifndef DG_LD
 // padded slab row (doubles).  144 (round 1) makes the MFMA fragment reads conflict-free but lands rows two apart on the same
 // banks, which is exactly what the B-slab staging writes (eight threads write rows 0, 2, .. 14 of one column at once: an
@@ -54,22 +82,17 @@ __device__ inline const unsigned short *mirror_map(const double *mirror, int nb)
 #define DG_LD 148
 #endif
 #define DG_WINDOW 16 // tasks whose bookkeeping is held in LDS at a time
+// f64 MFMAs reuse the BLGP immediate as NEG bits (bit 0: first source): D = C - A B without negating anything beforehand
+#define DG_NEG_A 1
 
-// Wavefronts per workgroup.  4 (default): 64 x 64 sub-tiles (4 x 4 accumulators, 207 registers), two wavefronts per SIMD.
-// 8: every wavefront owns a 64 x 32 sub-tile (2 x 4 accumulators, 123 registers), two workgroups = sixteen wavefronts per
-// CU, four instruction streams per matrix-core pipe to cover each other's LDS waits, slab bookkeeping and barriers --
-// measured equal (bench matrix 46.1-48.1 vs 46.2-47.4 ms per factorisation; poisson3d(64): 36.9 vs 37.2 ms of update-kernel
-// time), so the variant with half the LDS operand reads per flop stays.
-#ifndef DG_WAVES
+// 4 wavefronts per workgroup: 64 x 64 sub-tiles (4 x 4 accumulators), two workgroups = two wavefronts per SIMD.  (A variant
+// with 8 wavefronts of 64 x 32 sub-tiles, sixteen wavefronts per CU, measured equal in round 2 and was dropped.)
 #define DG_WAVES 4
-#endif
 #define DG_THREADS (64 * DG_WAVES)
-#define DG_NI (DG_WAVES == 8 ? 2 : 4) // 16-column pieces of C per wavefront
-#define DG_WAVES_PER_EU (DG_WAVES / 2)
-__global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_WAVES_PER_EU, DG_WAVES_PER_EU))) void ssssm_dense_f64_kernel(const SsssmGroupD *__restrict__ groups,
-                                                               const SsssmTaskD *__restrict__ tasks, int nb,
+#define DG_NI 4 // 16-column pieces of C per wavefront
+__global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssssm_dense_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb,
                                                                unsigned long long *__restrict__ product_counter,
-                                                               unsigned long long *dbg, const u32 *__restrict__ work)
+                                                               unsigned long long *dbg, const SsssmWorkD *__restrict__ work)
 {
     // (debug stamps: every 64th workgroup adds its phase times; PANGULU_HIP_DEBUG_SSSSM)
     const bool stamping = dbg && threadIdx.x == 0 && (blockIdx.x & 63) == 0;
@@ -81,97 +104,90 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
         atomicAdd(&dbg[slot], now_ - stamp_);                              \
         stamp_ = now_;                                                     \
     }
-    // two images of each slab: while the matrix cores consume one, the next slab (already in registers) is written into
-    // the other -- ONE barrier per slab instead of two (73.7 KB per workgroup: two workgroups still share a CU)
+    // two LDS images of a slab pair: while the matrix cores consume one, the next slab is written into the other -- one
+    // barrier per slab (75.8 KB per workgroup: two workgroups share a CU)
     __shared__ __align__(16) double sAb[2][DG_K * DG_LD];
     __shared__ __align__(16) double sBb[2][DG_K * DG_LD];
     const int tiles = nb / DG_TILE;
     const unsigned bid = logical_block_id((unsigned)(tiles * tiles)); // the tiles of one destination share operand halves: same XCD, same L2
-    // (group, tile) of this workgroup: from the launch's work list (tiles no update of the group can reach are left out)
-    const u32 item = work[bid];
-    const int g = (int)(item >> 2);
-    const int tile = (int)(item & 3u);
+    // destination tile and update queue of this workgroup: one self-contained item of the launch's work list (tiles no
+    // update of the group can reach are left out).  Start-up is a chain of dependent memory round trips -- item, task
+    // descriptors (with the operands' occupancy maps inside), first slabs -- and with ten live slabs per workgroup on
+    // average (fem27(80)) every trip saved is a few percent of the kernel: round 2 had five (work index, group, tasks,
+    // maps behind the mirrors, slabs).
+    const SsssmWorkD G = work[bid];
+    const int tile = (int)G.tile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (scalar: the skip tests below must be scalar branches)
     const int M0 = (tile % tiles) * DG_TILE, N0 = (tile / tiles) * DG_TILE; // workgroup tile origin
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * (16 * DG_NI);         // wavefront sub-tile inside it
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;                   // wavefront sub-tile inside it
     const int l15 = lane & 15, l4 = lane >> 4;
-    const SsssmGroupD G = groups[g];
 
-    v4f64 acc[DG_NI][4]; // [ni][mi]
-#pragma unroll
-    for (int ni = 0; ni < DG_NI; ni++)
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++)
-            acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    v4f64 acc[DG_NI][4]; // [ni][mi]; initialised below, once it is known which pieces are going to be used
 
     // staging maps.  A slab (128 rows x 16 k, column-major source): thread -> rows 2*(tid & 63), +1 of k = (tid >> 6) + 4 i.
     // B slab (16 k x 128 cols): thread -> k pair 2*(tid & 7) of column (tid >> 3) + 32 i: 8 consecutive threads read one
     // 128-byte run of a column.
-    // (with 8 wavefronts: A rows 2*(tid & 63), +1 of k = (tid >> 6) + 8 i, i < 2;  B k pair 2*(tid & 7) of column (tid >> 3) + 64 i)
-    constexpr int NST = 16 / DG_WAVES;          // pieces each thread stages per operand (4 or 2)
-    constexpr int A_KSTEP = DG_WAVES;           // k distance between a thread's A pieces
-    constexpr int B_NSTEP = 8 * DG_WAVES;       // column distance between a thread's B pieces (32 or 64)
-    const int a_m = 2 * (tid & 63), a_k = tid >> 6;
+    const int a_m = 2 * (tid & 63), a_k = wave; // (a_k = tid >> 6, as a scalar)
     const int b_k = 2 * (tid & 7), b_n = tid >> 3;
     const int a_slab = (tid & 63) >> 3;                            // which 16-row slab of the tile this thread stages
-    const int b_slab = __builtin_amdgcn_readfirstlane(tid >> 7);   // 16-column slab of piece i: b_slab + (B_NSTEP / 16) i
-    double2 ra[NST], rb[NST]; // next slab, in flight while the current one is consumed
-#pragma unroll
-    for (int i = 0; i < NST; i++)
-        ra[i] = rb[i] = make_double2(0.0, 0.0);
+    const int b_slab = __builtin_amdgcn_readfirstlane(tid >> 7);   // 16-column slab of piece i: b_slab + 2 i
+    // the two slabs in flight (first-class vector values: a struct type here is copied with memcpy through a stack slot),
+    // loaded through global-address-space pointers (the mirror addresses pass through LDS as integers; left generic they
+    // become flat loads, which also count against the LDS counter)
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    typedef const v2f64 __attribute__((address_space(1))) *slab_ptr;
+    v2f64 raX[4], rbX[4], raY[4], rbY[4];
 
     const u32 ntask = G.task_end - G.task_begin;
-    const int steps_per_task = nb / DG_K;
-    // Structural zeros, from the occupancy maps behind the mirrors (nb <= 256; otherwise everything counts as live).
+    const int steps_per_task = nb / DG_K; // <= 16: dense mode needs nb <= 256 (the occupancy maps have 16 x 16 bits)
     // For K-slab s of a task:  abits = which of the tile's eight 16-row slabs of A(:, s) hold pattern entries,
     //                          bbits = which of its eight 16-column slabs of B(s, :) do.
     // A slab is visited if both are non-zero; only live 16 x 16 pieces are fetched, and a wavefront issues the MFMAs
     // of a 16 x 16 x 16 product only when both its pieces are live -- for fill-in patterns of a few percent to a few
     // tens of percent that is a small fraction of the full contraction.  All of this is scalar (workgroup- or
     // wavefront-uniform) control flow.
-    const bool mapped = nb <= 256;
-    int cur_t = -1, nxt_step = -1;
-    unsigned long long todo = 0;
-    int done_steps = 0; // (only nb > 256: slabs of the current task handed out so far, 64 at a time)
-    unsigned nxt_ab = 0xFF, nxt_bb = 0xFF, cur_ab, cur_bb, touched = 0, nprod = 0;
-    const double *nxt_pa = nullptr, *nxt_pb = nullptr; // mirrors of the task the next step belongs to
+    unsigned touched = 0, nprod = 0;
     // Per-task bookkeeping of up to DG_WINDOW tasks at a time lives in LDS, filled by all 256 threads at once (thread
     // = one (task, slab) pair): chasing task -> mirror -> map through global memory once per task costs microseconds
     // of exposed latency per task, more than the slabs of a sparse update themselves.
-    __shared__ unsigned short s_abbb[DG_WINDOW * 16];     // (bbits << 8) | abits of (task, slab); 0 = nothing to do
-    __shared__ unsigned s_live[DG_WINDOW];               // per task: which slabs are live
+    __shared__ u32 s_step[DG_WINDOW * 16];   // live steps of the window in order: task << 20 | slab << 16 | bbits << 8 | abits
+    __shared__ u32 s_cnt[DG_WAVES];
     __shared__ const double *s_pa[DG_WINDOW], *s_pb[DG_WINDOW];
 #if PG_PLANES > 1
     __shared__ double s_sign[DG_WINDOW]; // sign of the task's product (complex updates as four real ones)
-    double nxt_sign = 1.0;
-#endif
-    int win0 = -DG_WINDOW; // first task of the window in the tables
-
-#if PG_PLANES > 1
 #define DG_SET_SIGN(t_, Tm_) s_sign[t_] = (Tm_).sign;
-#define DG_GET_SIGN(i_) nxt_sign = s_sign[i_];
 #else
 #define DG_SET_SIGN(t_, Tm_)
-#define DG_GET_SIGN(i_)
 #endif
+    int win0 = -DG_WINDOW; // first task of the window in the tables
+    int nwin = 0, iwin = 0; // steps in the window's list, next one to hand out
+
 #define DG_FILL_WINDOW()                                                                             \
     {                                                                                                \
         __syncthreads(); /* nobody reads the previous window any more */                             \
         const int t_ = tid >> 4, s_ = tid & 15;                                                      \
         unsigned v_ = 0;                                                                             \
-        if (tid < 256 && win0 + t_ < (int)ntask && s_ < steps_per_task)                              \
+        if (win0 + t_ < (int)ntask && s_ < steps_per_task)                                           \
         {                                                                                            \
             const SsssmTaskD &Tm_ = tasks[G.task_begin + win0 + t_];                                 \
             const double *pa_ = reinterpret_cast<const double *>(Tm_.a.val), *pb_ = reinterpret_cast<const double *>(Tm_.b.val); \
-            const unsigned ab_ = ((unsigned)mirror_map(pa_, nb)[s_] >> (M0 / 16)) & 0xFFu;           \
-            const uint4 mb_ = *reinterpret_cast<const uint4 *>(mirror_map(pb_, nb) + N0 / 16);       \
-            const unsigned w_[4] = {mb_.x, mb_.y, mb_.z, mb_.w};                                     \
-            unsigned bb_ = 0;                                                                        \
-            _Pragma("unroll") for (int c_ = 0; c_ < 8; c_++)                                         \
-                bb_ |= (((w_[c_ >> 1] >> (16 * (c_ & 1))) >> s_) & 1u) << c_;                        \
+            unsigned ab_, bb_ = 0;                                                                   \
+            if (Tm_.has_map)                                                                         \
+            {                                                                                        \
+                ab_ = ((unsigned)Tm_.amap[s_] >> (M0 / 16)) & 0xFFu;                                 \
+                bb_ = ((unsigned)Tm_.bmap_t[s_] >> (N0 / 16)) & 0xFFu;                               \
+            }                                                                                        \
+            else                                                                                     \
+            {                                                                                        \
+                ab_ = ((unsigned)mirror_map(pa_, nb)[s_] >> (M0 / 16)) & 0xFFu;                      \
+                const uint4 mb_ = *reinterpret_cast<const uint4 *>(mirror_map(pb_, nb) + N0 / 16);   \
+                const unsigned w_[4] = {mb_.x, mb_.y, mb_.z, mb_.w};                                 \
+                _Pragma("unroll") for (int c_ = 0; c_ < 8; c_++)                                     \
+                    bb_ |= (((w_[c_ >> 1] >> (16 * (c_ & 1))) >> s_) & 1u) << c_;                    \
+            }                                                                                        \
             if (ab_ && bb_ && (!G.slab_mask || ((G.slab_mask >> s_) & 1u)))                          \
-                v_ = (bb_ << 8) | ab_;                                                               \
+                v_ = (bb_ << 8) | ab_ | ((unsigned)s_ << 16) | ((unsigned)t_ << 20);                 \
             if (s_ == 0)                                                                             \
             {                                                                                        \
                 s_pa[t_] = pa_;                                                                      \
@@ -179,111 +195,170 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
                 DG_SET_SIGN(t_, Tm_)                                                                 \
             }                                                                                        \
         }                                                                                            \
-        if (tid < 256)                                                                               \
-            s_abbb[tid] = (unsigned short)v_;                                                        \
         const unsigned long long bal_ = __ballot(v_ != 0);                                           \
-        if (tid < 256 && (tid & 63) < 4)                                                             \
-            s_live[(tid >> 6) * 4 + (tid & 63)] = (unsigned)((bal_ >> (16 * (tid & 63))) & 0xFFFFull); \
+        if (lane == 0)                                                                               \
+            s_cnt[wave] = (u32)__builtin_popcountll(bal_);                                           \
         __syncthreads();                                                                             \
+        unsigned at_ = (unsigned)__builtin_popcountll(bal_ & ((1ull << lane) - 1ull)), all_ = 0;     \
+        _Pragma("unroll") for (int w_i = 0; w_i < DG_WAVES; w_i++)                                   \
+        {                                                                                            \
+            const unsigned c_ = s_cnt[w_i];                                                          \
+            at_ += w_i < wave ? c_ : 0u;                                                             \
+            all_ += c_;                                                                              \
+        }                                                                                            \
+        if (v_)                                                                                      \
+            s_step[at_] = v_;                                                                        \
+        __syncthreads();                                                                             \
+        nwin = __builtin_amdgcn_readfirstlane((int)all_);                                            \
+        iwin = 0;                                                                                    \
     }
 
-#define DG_NEXT_STEP(out_)                                                                           \
-    {                                                                                                \
-        (out_) = -1;                                                                                 \
-        while (mapped)                                                                               \
-        {                                                                                            \
-            if (todo)                                                                                \
-            {                                                                                        \
-                const int s_ = __builtin_ctzll(todo);                                                \
-                todo &= todo - 1;                                                                    \
-                const unsigned v_ = s_abbb[(cur_t - win0) * 16 + s_];                                \
-                nxt_ab = v_ & 0xFFu;                                                                 \
-                nxt_bb = v_ >> 8;                                                                    \
-                nxt_pa = s_pa[cur_t - win0];                                                         \
-                nxt_pb = s_pb[cur_t - win0];                                                         \
-                DG_GET_SIGN(cur_t - win0)                                                            \
-                (out_) = cur_t * steps_per_task + s_;                                                \
-                break;                                                                               \
-            }                                                                                        \
-            if (++cur_t >= (int)ntask)                                                               \
-                break;                                                                               \
-            if (cur_t >= win0 + DG_WINDOW)                                                           \
-            {                                                                                        \
-                win0 = cur_t;                                                                        \
-                DG_FILL_WINDOW()                                                                     \
-            }                                                                                        \
-            todo = s_live[cur_t - win0];                                                             \
-        }                                                                                            \
-        while (!mapped)                                                                              \
-        {                                                                                            \
-            if (todo)                                                                                \
-            {                                                                                        \
-                const int s_ = __builtin_ctzll(todo);                                                \
-                todo &= todo - 1;                                                                    \
-                (out_) = cur_t * steps_per_task + done_steps + s_;                                   \
-                nxt_pa = reinterpret_cast<const double *>(tasks[G.task_begin + cur_t].a.val);        \
-                nxt_pb = reinterpret_cast<const double *>(tasks[G.task_begin + cur_t].b.val);        \
-                break;                                                                               \
-            }                                                                                        \
-            if (cur_t >= 0 && done_steps + 64 < steps_per_task)                                      \
-            {                                                                                        \
-                done_steps += 64;                                                                    \
-                const int left_ = steps_per_task - done_steps;                                       \
-                todo = left_ >= 64 ? ~0ull : ((1ull << left_) - 1ull);                               \
-                continue;                                                                            \
-            }                                                                                        \
-            if (++cur_t >= (int)ntask)                                                               \
-                break;                                                                               \
-            done_steps = 0;                                                                          \
-            todo = steps_per_task >= 64 ? ~0ull : ((1ull << steps_per_task) - 1ull);                 \
-        }                                                                                            \
-    }
-
+    // next live step -> (ab, bb, k0, pa, pb, sign) as scalars; past the end: ab = bb = 0 and the destination's own mirror
+    // as a harmless address for the dummy loads
 #if PG_PLANES > 1
-#define DG_APPLY_SIGN(v_) { (v_).x *= nxt_sign; (v_).y *= nxt_sign; }
+#define DG_STEP_SIGN(sg_, t_) sg_ = s_sign[t_];
+#define DG_STEP_NOSIGN(sg_) sg_ = 1.0;
 #else
-#define DG_APPLY_SIGN(v_)
+#define DG_STEP_SIGN(sg_, t_)
+#define DG_STEP_NOSIGN(sg_)
 #endif
-#define DG_LOAD_SLAB(step_, ab_, bb_)                                                                \
+#define DG_FETCH(ab_, bb_, k0_, pa_, pb_, sg_)                                                       \
     {                                                                                                \
-        const int k0_ = ((step_) % steps_per_task) * DG_K;                                           \
-        const double *A_ = nxt_pa + (size_t)(k0_ + a_k) * nb + M0 + a_m;                             \
-        const double *B_ = nxt_pb + (size_t)(N0 + b_n) * nb + k0_ + b_k;                             \
-        if (((ab_) >> a_slab) & 1u)                                                                  \
+        while (iwin == nwin && win0 + DG_WINDOW < (int)ntask)                                        \
         {                                                                                            \
-            _Pragma("unroll") for (int i_ = 0; i_ < NST; i_++)                                       \
-            {                                                                                        \
-                ra[i_] = *reinterpret_cast<const double2 *>(A_ + (size_t)(A_KSTEP * i_) * nb);       \
-                DG_APPLY_SIGN(ra[i_])                                                                \
-            }                                                                                        \
+            win0 += DG_WINDOW;                                                                       \
+            DG_FILL_WINDOW()                                                                         \
         }                                                                                            \
-        _Pragma("unroll") for (int i_ = 0; i_ < NST; i_++)                                           \
-            if (((bb_) >> (b_slab + (B_NSTEP / 16) * i_)) & 1u)                                      \
-                rb[i_] = *reinterpret_cast<const double2 *>(B_ + (size_t)(B_NSTEP * i_) * nb);       \
+        if (iwin < nwin)                                                                             \
+        {                                                                                            \
+            const unsigned e_ = (unsigned)__builtin_amdgcn_readfirstlane((int)s_step[iwin]);         \
+            iwin++;                                                                                  \
+            ab_ = e_ & 0xFFu;                                                                        \
+            bb_ = (e_ >> 8) & 0xFFu;                                                                 \
+            k0_ = (int)((e_ >> 16) & 15u) * DG_K;                                                    \
+            const unsigned long long a64_ = reinterpret_cast<unsigned long long>(s_pa[e_ >> 20]);    \
+            const unsigned long long b64_ = reinterpret_cast<unsigned long long>(s_pb[e_ >> 20]);    \
+            pa_ = reinterpret_cast<const double *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a64_ >> 32)) << 32) | \
+                                                   (unsigned)__builtin_amdgcn_readfirstlane((int)a64_)); \
+            pb_ = reinterpret_cast<const double *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64_ >> 32)) << 32) | \
+                                                   (unsigned)__builtin_amdgcn_readfirstlane((int)b64_)); \
+            DG_STEP_SIGN(sg_, e_ >> 20)                                                              \
+        }                                                                                            \
+        else                                                                                         \
+        {                                                                                            \
+            ab_ = bb_ = 0;                                                                           \
+            k0_ = 0;                                                                                 \
+            pa_ = pb_ = reinterpret_cast<const double *>(G.cdense);                                  \
+            DG_STEP_NOSIGN(sg_)                                                                      \
+        }                                                                                            \
     }
 
-    DG_NEXT_STEP(nxt_step)
+    // all eight loads of a slab, unconditionally (see the header): dead pieces read 16 bytes that are in the mirror anyway.
+    // Addresses are a workgroup-uniform base (scalar registers, scalar arithmetic) plus a per-thread byte offset that never
+    // changes: an f64 MFMA occupies the SIMD's vector ALU for its whole 64 cycles -- no vector instruction of the other
+    // wavefront on the SIMD issues beside it (tools/experiments/mfma_f64_coissue.hip: MFMA stream + integer stream on one
+    // SIMD take the SUM of their times) -- so every vector instruction spent on address arithmetic is time taken from the
+    // matrix pipe.  Round 2's first version computed 64-bit vector addresses per load (about 100 vector instructions per slab).
+    typedef const char __attribute__((address_space(1))) *gbytes;
+    const unsigned a_voff = (unsigned)a_m * 8u;                       // A: rows a_m, a_m+1 of column (k0 + a_k + 4 i), tile origin in the base
+    const unsigned b_voff = ((unsigned)b_n * (unsigned)nb + (unsigned)b_k) * 8u; // B: rows k0 + b_k, +1 of column N0 + b_n + 32 i
+    const unsigned a_bit = 1u << a_slab;
+#define DG_LOAD_SLAB(ra_, rb_, ab_, bb_, k0_, pa_, pb_)                                              \
+    {                                                                                                \
+        const unsigned av_ = ((ab_) & a_bit) ? a_voff : 0u;                                          \
+        const gbytes A_ = (gbytes)(pa_) + ((size_t)((k0_) + a_k) * nb + M0) * 8;                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                             \
+            ra_[i_] = *(slab_ptr)(dg_scalar_base(A_ + (size_t)(4 * i_) * nb * 8) + av_);             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                             \
+        {                                                                                            \
+            const bool live_ = ((bb_) >> (b_slab + 2 * i_)) & 1u;                                    \
+            const gbytes Bi_ = (gbytes)(pb_) + (live_ ? ((size_t)(N0 + 32 * i_) * nb + (k0_)) * 8 : (size_t)0); \
+            rb_[i_] = *(slab_ptr)(dg_scalar_base(Bi_) + dg_lane_offset(live_ ? b_voff : 0u));      \
+        }                                                                                            \
+    }
+#if PG_PLANES > 1
+#define DG_SIGNED(v_, sg_) ((v_) * (sg_))
+#else
+#define DG_SIGNED(v_, sg_) (v_)
+#endif
+#define DG_STORE_LDS(buf_, ra_, rb_, sg_)                                                            \
+    {                                                                                                \
+        double *sA_ = sAb[buf_], *sB_ = sBb[buf_];                                                   \
+        /* (pieces that were not fetched hold whatever the dummy load returned; no MFMA reads them) */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                             \
+        {                                                                                            \
+            *reinterpret_cast<v2f64 *>(&sA_[(a_k + 4 * i_) * DG_LD + a_m]) = DG_SIGNED(ra_[i_], sg_); \
+            sB_[b_k * DG_LD + b_n + 32 * i_] = rb_[i_].x;                                            \
+            sB_[(b_k + 1) * DG_LD + b_n + 32 * i_] = rb_[i_].y;                                      \
+        }                                                                                            \
+    }
+#define DG_PRODUCTS(buf_, ab_, bb_)                                                                  \
+    {                                                                                                \
+        const double *sA = sAb[buf_], *sB = sBb[buf_];                                               \
+        const unsigned a4 = ((ab_) >> (wm / 16)) & 0xFu, b4 = ((bb_) >> (wn / 16)) & 0xFu;           \
+        if (a4 && b4)                                                                                \
+        {                                                                                            \
+            nprod += (unsigned)(__builtin_popcount(a4) * __builtin_popcount(b4));                    \
+            _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                     \
+                if ((b4 >> ni) & 1u)                                                                 \
+                    touched |= a4 << (4 * ni);                                                       \
+            _Pragma("unroll") for (int kq = 0; kq < DG_K / 4; kq++)                                  \
+            {                                                                                        \
+                double fa[4], fb[DG_NI];                                                             \
+                _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                     \
+                    fa[mi] = sA[(kq * 4 + l4) * DG_LD + wm + mi * 16 + l15];                         \
+                _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                 \
+                    fb[ni] = sB[(kq * 4 + l4) * DG_LD + wn + ni * 16 + l15];                         \
+                _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                 \
+                {                                                                                    \
+                    if (!((b4 >> ni) & 1u))                                                          \
+                        continue;                                                                    \
+                    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                 \
+                        if ((a4 >> mi) & 1u)                                                         \
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, DG_NEG_A); \
+                }                                                                                    \
+            }                                                                                        \
+        }                                                                                            \
+    }
+
+    // steps 0, 1, 2 ... alternate between the scalar sets (0: even steps, 1: odd steps)
+    unsigned ab0, bb0, ab1, bb1;
+    int k00, k01;
+    const double *pa0, *pb0, *pa1, *pb1;
+    double sg0 = 1.0, sg1 = 1.0;
+    (void)sg0;
+    (void)sg1;
+    DG_FETCH(ab0, bb0, k00, pa0, pb0, sg0)
     DG_STAMP(0)
-    if (nxt_step < 0)
+    if (!(ab0 | bb0))
     {
         if (stamping)
             atomicAdd(&dbg[7], 1ull << 32); // (empty workgroups in the high word)
         return; // nothing of these updates reaches this tile
     }
-    DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb)
+    DG_LOAD_SLAB(raX, rbX, ab0, bb0, k00, pa0, pb0)
     // A group that owns its destination and whose whole queue fits the bookkeeping window knows from the maps which
-    // 16 x 16 pieces of C it is going to touch: their values go into the accumulators now (negated: acc = -C + sum A B,
-    // C = -acc at the end), in flight together with the first slab, and the epilogue is stores only -- read-modify-write
-    // at the end costs memory round trips that nothing hides.
+    // 16 x 16 pieces of C it is going to touch: their values go into the accumulators now, in flight together with the
+    // first slabs (the MFMAs below subtract: acc = C - sum A B), and the epilogue is stores only -- read-modify-write at
+    // the end costs memory round trips that nothing hides.
     unsigned pre = 0;
-    double *__restrict__ C = reinterpret_cast<double *>(G.cdense); // (CR64: one plane of the destination's mirror)
-    if (mapped && ntask <= DG_WINDOW && !G.atomic)
+    // (CR64: one plane of the destination's mirror.)  Global address space spelled out: a pointer that comes out of a
+    // descriptor in memory is generic to the compiler, and generic (flat) accesses also count against the LDS counter
+    double __attribute__((address_space(1))) *C = (double __attribute__((address_space(1))) *)reinterpret_cast<double *>(G.cdense);
+    // element (m, n) of this wavefront's piece (ni, mi), register r: scalar part (tile, wavefront, piece, register) + one
+    // per-thread byte offset
+    const unsigned c_voff = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
+#define DG_C(ni_, mi_, r_)                                                                           \
+    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((const char __attribute__((address_space(1))) *)C +                    \
+                                                                  ((size_t)(N0 + wn + (ni_) * 16 + 4 * (r_)) * nb + M0 + wm) * 8) + \
+                                                   dg_lane_offset(c_voff) + (mi_) * 128))
+    if (ntask <= DG_WINDOW && !G.atomic)
     {
         unsigned m = 0;
-        for (int e = lane; e < (int)ntask * 16; e += 64)
+        for (int e = lane; e < nwin; e += 64)
         {
-            const unsigned v = s_abbb[e];
-            const unsigned a4 = ((v & 0xFFu) >> (wm / 16)) & 0xFu, b4 = ((v >> 8) >> (wn / 16)) & ((1u << DG_NI) - 1u);
+            const unsigned v = s_step[e];
+            const unsigned a4 = ((v & 0xFFu) >> (wm / 16)) & 0xFu, b4 = (((v >> 8) & 0xFFu) >> (wn / 16)) & 0xFu;
 #pragma unroll
             for (int ni = 0; ni < DG_NI; ni++)
                 if ((b4 >> ni) & 1u)
@@ -301,90 +376,69 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
                 {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        acc[ni][mi][r] = -C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)];
+                        acc[ni][mi][r] = DG_C(ni, mi, r);
+                }
+                else
+                {
+                    // no product of this queue lands here and the epilogue leaves the piece alone: whatever the registers
+                    // hold will do (not even the 8 moves that would zero them -- every vector instruction counts, see above)
+                    asm volatile("" : "=v"(acc[ni][mi]));
                 }
     }
-#define DG_STORE_LDS(buf_)                                                                           \
-    {                                                                                                \
-        double *sA_ = sAb[buf_], *sB_ = sBb[buf_];                                                   \
-        /* (pieces that were not fetched hold stale finite values; no MFMA reads them) */            \
-        _Pragma("unroll") for (int i_ = 0; i_ < NST; i_++)                                           \
-        {                                                                                            \
-            *reinterpret_cast<double2 *>(&sA_[(a_k + A_KSTEP * i_) * DG_LD + a_m]) = ra[i_];         \
-            sB_[b_k * DG_LD + b_n + B_NSTEP * i_] = rb[i_].x;                                        \
-            sB_[(b_k + 1) * DG_LD + b_n + B_NSTEP * i_] = rb[i_].y;                                  \
-        }                                                                                            \
+    else
+    {
+#pragma unroll
+        for (int ni = 0; ni < DG_NI; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
     }
-    // software pipeline: slab s in LDS image `buf` feeds the matrix cores, slab s+1 sits in registers (its loads went out one
-    // iteration ago) and goes into the other image afterwards, the loads of slab s+2 go out, one barrier
-    cur_ab = nxt_ab;
-    cur_bb = nxt_bb;
+    DG_FETCH(ab1, bb1, k01, pa1, pb1, sg1)
+    DG_LOAD_SLAB(raY, rbY, ab1, bb1, k01, pa1, pb1)
     DG_STAMP(1)
-    DG_STORE_LDS(0)
+    DG_STORE_LDS(0, raX, rbX, sg0)
     DG_STAMP(2)
-    DG_NEXT_STEP(nxt_step)
-    if (nxt_step >= 0)
-        DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb)
     __syncthreads();
     DG_STAMP(3)
-    int buf = 0;
-    for (;;)
+    // No exit from the middle of the loop: a step past the end of the list is all dummy loads and no products, and the
+    // single back edge keeps the compiler's view of what is in flight exact (with a break between the loads of one set
+    // and their LDS stage it assumed them pending at the loop head and drained the whole queue there).
+    do
     {
-        const double *sA = sAb[buf], *sB = sBb[buf];
-        const unsigned a4 = (cur_ab >> (wm / 16)) & 0xFu, b4 = (cur_bb >> (wn / 16)) & ((1u << DG_NI) - 1u);
-        if (a4 && b4)
-        {
-            nprod += (unsigned)(__builtin_popcount(a4) * __builtin_popcount(b4));
-#pragma unroll
-            for (int ni = 0; ni < DG_NI; ni++)
-                if ((b4 >> ni) & 1u)
-                    touched |= a4 << (4 * ni);
-#pragma unroll
-            for (int kq = 0; kq < DG_K / 4; kq++)
-            {
-                double fa[4], fb[DG_NI];
-#pragma unroll
-                for (int mi = 0; mi < 4; mi++)
-                    fa[mi] = sA[(kq * 4 + l4) * DG_LD + wm + mi * 16 + l15];
-#pragma unroll
-                for (int ni = 0; ni < DG_NI; ni++)
-                    fb[ni] = sB[(kq * 4 + l4) * DG_LD + wn + ni * 16 + l15];
-#pragma unroll
-                for (int ni = 0; ni < DG_NI; ni++)
-                {
-                    if (!((b4 >> ni) & 1u))
-                        continue;
-#pragma unroll
-                    for (int mi = 0; mi < 4; mi++)
-                        if ((a4 >> mi) & 1u)
-                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-                }
-            }
-        }
+        // even step: image 0 holds it, set Y the next one; set X is free for the one after
+        const unsigned cab0 = ab0, cbb0 = bb0;
+        DG_FETCH(ab0, bb0, k00, pa0, pb0, sg0)
+        DG_LOAD_SLAB(raX, rbX, ab0, bb0, k00, pa0, pb0)
+        DG_STAMP(4)
+        DG_PRODUCTS(0, cab0, cbb0)
+        DG_STAMP(5)
+        DG_STORE_LDS(1, raY, rbY, sg1) // (waits for the loads of set Y only: those of set X, issued above, stay in flight)
+        DG_STAMP(2)
+        __syncthreads(); // image 1 is complete, and everyone is done reading image 0
+        DG_STAMP(3)
+        // odd step, roles swapped
+        const unsigned cab1 = ab1, cbb1 = bb1;
+        DG_FETCH(ab1, bb1, k01, pa1, pb1, sg1)
+        DG_LOAD_SLAB(raY, rbY, ab1, bb1, k01, pa1, pb1)
+        DG_STAMP(4)
+        DG_PRODUCTS(1, cab1, cbb1)
         DG_STAMP(5)
         if (stamping)
-            atomicAdd(&dbg[7], 1ull); // slab steps in the low word
-        if (nxt_step < 0)
-            break;
-        cur_ab = nxt_ab;
-        cur_bb = nxt_bb;
-        DG_STORE_LDS(buf ^ 1) // (waits for the slab's loads: they have been in flight since before the products above)
+            atomicAdd(&dbg[7], (cab1 ? 2ull : 1ull)); // slab steps in the low word
+        DG_STORE_LDS(0, raX, rbX, sg0)
         DG_STAMP(2)
-        DG_NEXT_STEP(nxt_step)
-        if (nxt_step >= 0)
-            DG_LOAD_SLAB(nxt_step, nxt_ab, nxt_bb)
-        DG_STAMP(4)
-        __syncthreads(); // the other image is complete, and everyone is done reading this one
+        __syncthreads();
         DG_STAMP(3)
-        buf ^= 1;
-    }
+    } while (ab0 | bb0);
 #undef DG_STORE_LDS
-#undef DG_NEXT_STEP
+#undef DG_FETCH
 #undef DG_FILL_WINDOW
 #undef DG_LOAD_SLAB
-#undef DG_APPLY_SIGN
+#undef DG_PRODUCTS
+#undef DG_SIGNED
 #undef DG_SET_SIGN
-#undef DG_GET_SIGN
+#undef DG_STEP_SIGN
+#undef DG_STEP_NOSIGN
     if (product_counter && lane == 0 && nprod)
         atomicAdd(product_counter, (unsigned long long)nprod); // 16 x 16 x 16 products issued to the matrix cores
 
@@ -398,7 +452,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
                 {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)] = -acc[ni][mi][r];
+                        DG_C(ni, mi, r) = acc[ni][mi][r];
                 }
         touched = 0; // (= pre: everything has been written)
     }
@@ -422,9 +476,8 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
 #pragma unroll
                 for (int r = 0; r < 4; r++)
                 {
-                    const size_t off = (size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15);
                     if (acc[ni][mi][r] != 0.0)
-                        atomicAdd(&C[off], -acc[ni][mi][r]);
+                        atomicAdd((double *)&DG_C(ni, mi, r), acc[ni][mi][r]);
                 }
             }
             continue;
@@ -434,7 +487,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
         for (int mi = 0; mi < 4; mi++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                old[mi][r] = ((t4 >> mi) & 1u) ? C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)] : 0.0;
+                old[mi][r] = ((t4 >> mi) & 1u) ? DG_C(ni, mi, r) : 0.0;
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
         {
@@ -442,11 +495,12 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
                 continue; // no product reached this 16 x 16 piece of C
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                C[(size_t)(N0 + wn + ni * 16 + l4 + 4 * r) * nb + (M0 + wm + mi * 16 + l15)] = old[mi][r] - acc[ni][mi][r];
+                DG_C(ni, mi, r) = old[mi][r] + acc[ni][mi][r];
         }
     }
     DG_STAMP(6)
 #undef DG_STAMP
+#undef DG_C
 }
 
 // ---------------------------------------------------------------------------------------------------------------

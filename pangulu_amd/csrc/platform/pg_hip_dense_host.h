@@ -21,6 +21,10 @@ struct BlockState
     // The launch code uses it to leave out workgroups that would find nothing to do.
     bool occ_valid = false;
     unsigned short occ_a[2] = {0, 0}, occ_b[2] = {0, 0}, occ_rows = 0, occ_cols = 0;
+    // ... and the full 16 x 16 occupancy map, as densify writes it behind the mirror (word c: row slabs with entries in column
+    // slab c) and transposed (word r: column slabs with entries in row slab r).  Update tasks carry them to the MFMA kernel,
+    // which then needs no second memory round trip (descriptor -> mirror -> map) before it knows what to fetch.
+    unsigned short occ_map[16] = {0}, occ_map_t[16] = {0};
 };
 
 // Open-addressing table block key -> BlockState.  Looked up three times per update task (destination and both operands)
@@ -410,6 +414,8 @@ void reset_block_states()
                            fresh.occ_b[1] = st.occ_b[1];
                            fresh.occ_rows = st.occ_rows;
                            fresh.occ_cols = st.occ_cols;
+                           memcpy(fresh.occ_map, st.occ_map, sizeof(fresh.occ_map));
+                           memcpy(fresh.occ_map_t, st.occ_map_t, sizeof(fresh.occ_map_t));
                            st = fresh; });
     MP.cursor = 0;
     MP.to_densify.clear();

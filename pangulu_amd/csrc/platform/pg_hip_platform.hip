@@ -154,7 +154,23 @@ struct SsssmTaskD
     // MFMA kernel only.  CR64: a complex update is four real products on the planes of the mirrors; `sign` multiplies the A
     // operand (the A_im B_im product ADDS to the real plane), `count` marks the one of the four whose structural flops count
     double sign;
-    u32 count, pad_;
+    u32 count;
+    // has_map: amap / bmap_t hold the occupancy of the operands (from the host's summaries, BlockState::occ_map):
+    //   amap[s]   bit r: A has pattern entries in row slab r of K-slab (column slab) s
+    //   bmap_t[s] bit c: B has pattern entries in column slab c of K-slab (row slab) s
+    // otherwise (blocks received from another rank) the kernel reads the maps behind the mirrors
+    u32 has_map;
+    unsigned short amap[16], bmap_t[16];
+};
+static_assert(sizeof(SsssmTaskD) == 128, "two task descriptors per 256 bytes");
+
+// one workgroup of the MFMA update launch: a 128 x 128 tile of one destination and the queue of updates that reach it
+struct SsssmWorkD
+{
+    val_t *cdense;          // the destination's mirror (CR64: one plane of it)
+    u32 task_begin, task_end;
+    u32 atomic, slab_mask;  // as in SsssmGroupD
+    u32 tile, pad_;
 };
 
 struct SsssmGroupD
@@ -1770,7 +1786,7 @@ void ensure_ready()
     // Descriptors are written once by the host and read once per workgroup: the kernels read them straight from
     // pinned host memory (non-coherent, so the device L2 may cache them) instead of waiting for a staging copy per
     // launch (rocprofv3 showed ~1900 blit dispatches, ~50 ms, per factorisation of the bench matrix).
-    B.ring.seg_bytes = (size_t)4 << 20;
+    B.ring.seg_bytes = (size_t)8 << 20;
     HIP_CHECK(hipHostMalloc((void **)&B.ring.h, B.ring.seg_bytes * Ring::NSEG, hipHostMallocNonCoherent | hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&B.ring.d, B.ring.h, 0));
     for (int i = 0; i < Ring::NSEG; i++)
@@ -2018,7 +2034,11 @@ void launch_ssssm(int nb, task_t **list, size_t n)
     {
         Segment seg = acquire_segment();
         // worst case per task: one group + one task descriptor in each class; fill until the segment is full
-        size_t max_tasks = seg.cap / (sizeof(SsssmGroupD) + sizeof(SsssmTaskD) + 32 + 4 * sizeof(u32)) / (2 * PG_PLANES * PG_PLANES);
+        // (per update: a task descriptor in each class -- PG_PLANES^2 real products on the MFMA side --, a group in each, four
+        // work items per MFMA group; the K-split of very small launches multiplies groups and work items of <= 64 tasks by four)
+        const size_t per_task = sizeof(SsssmTaskD) * (1 + PG_PLANES * PG_PLANES) + sizeof(SsssmGroupD) * (1 + PG_PLANES) +
+                                sizeof(SsssmWorkD) * 4 * PG_PLANES;
+        size_t max_tasks = (seg.cap - 64 * 4 * PG_PLANES * (sizeof(SsssmGroupD) + 4 * sizeof(SsssmWorkD)) - 4096) / per_task;
         size_t take = std::min(n - i, max_tasks);
         SsssmTaskD *d_tasks_s, *d_tasks_d;
         SsssmGroupD *d_groups_s, *d_groups_d;
@@ -2030,8 +2050,8 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         SsssmGroupD *groups_d = seg.alloc<SsssmGroupD>(take * ksplit * PG_PLANES, &d_groups_d);
         static std::vector<unsigned short> live_k; // per dense task and tile: K-slabs in which both operands have entries
         live_k.assign(take * 4 * PG_PLANES * PG_PLANES, 0);
-        u32 *d_work;
-        u32 *work = seg.alloc<u32>(take * ksplit * 4 * PG_PLANES, &d_work); // (group, tile) of every workgroup of the MFMA launch
+        SsssmWorkD *d_work;
+        SsssmWorkD *work = seg.alloc<SsssmWorkD>(take * ksplit * 4 * PG_PLANES, &d_work); // every workgroup of the MFMA launch
         if (!tasks_s || !tasks_d || !groups_s || !groups_d || !work)
         {
             fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
@@ -2138,6 +2158,12 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                                      : (sa && sb && sa->occ_valid && sb->occ_valid)
                                          ? (unsigned short)(sa->occ_a[tl % tiles_per_dim] & sb->occ_b[tl / tiles_per_dim])
                                          : (unsigned short)0xFFFF;
+                    if (sa && sb && sa->occ_valid && sb->occ_valid)
+                    {
+                        H.T.has_map = 1;
+                        memcpy(H.T.amap, sa->occ_map, sizeof(H.T.amap));
+                        memcpy(H.T.bmap_t, sb->occ_map_t, sizeof(H.T.bmap_t));
+                    }
                     heavy.push_back(H);
                     bytes_d += by;
                     nd_updates++;
@@ -2277,11 +2303,14 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                 for (size_t gi = 0; gi < gd; gi++)
                     for (int tl = 0; tl < tiles * tiles; tl++)
                         if ((groups_d[gi].live_tiles >> tl) & 1u)
-                            work[nw++] = (u32)(gi << 2) | (u32)tl;
+                        {
+                            const SsssmGroupD &Gd = groups_d[gi];
+                            work[nw++] = SsssmWorkD{Gd.cdense, Gd.task_begin, Gd.task_end, Gd.atomic, Gd.slab_mask, (u32)tl, 0u};
+                        }
                 LaunchTimer lt(5, ds);
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 if (nw)
-                    hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_groups_d, d_tasks_d, nb,
+                    hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb,
                                        B.opt_count_flops ? B.d_flops + 6 : nullptr, debug_ssssm ? B.d_flops + 8 : nullptr, d_work);
             }
             if (B.opt_count_flops)
@@ -3207,7 +3236,7 @@ extern "C"
         std::lock_guard<std::mutex> g(B.mutex);
         struct Occ
         {
-            unsigned short a[2], b[2], rows, cols;
+            unsigned short a[2], b[2], rows, cols, map[16], map_t[16];
         };
         std::vector<Occ> occ((size_t)nslot);
         // the patterns are walked by a few threads (half a billion entries for the bench matrix), the table is filled by one
@@ -3229,7 +3258,13 @@ extern "C"
                                               bits |= (unsigned short)(1u << (ri[p] >> 4));
                                           m[c >> 4] |= bits;
                                       }
-                                      Occ o = {{0, 0}, {0, 0}, 0, 0};
+                                      Occ o;
+                                      memset(&o, 0, sizeof(o));
+                                      memcpy(o.map, m, sizeof(o.map));
+                                      for (int c = 0; c < 16; c++)
+                                          for (int r = 0; r < 16; r++)
+                                              if ((m[c] >> r) & 1)
+                                                  o.map_t[r] |= (unsigned short)(1u << c);
                                       for (int sl = 0; sl < (int)nb / 16; sl++)
                                       {
                                           if (m[sl] & 0x00FF)
@@ -3255,6 +3290,8 @@ extern "C"
             st.occ_b[1] = occ[i].b[1];
             st.occ_rows = occ[i].rows;
             st.occ_cols = occ[i].cols;
+            memcpy(st.occ_map, occ[i].map, sizeof(st.occ_map));
+            memcpy(st.occ_map_t, occ[i].map_t, sizeof(st.occ_map_t));
         }
 #else
         (void)nb;
