@@ -302,20 +302,29 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                     \
                 if ((b4 >> ni) & 1u)                                                                 \
                     touched |= a4 << (4 * ni);                                                       \
+            /* operand fragments of k-quarter kq+1 are read while the matrix cores work on kq: the LDS round trip      */ \
+            /* (4 per slab) would otherwise sit in front of every group of sixteen MFMAs                               */ \
+            double fa[2][4], fb[2][DG_NI];                                                           \
+            _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                         \
+                fa[0][mi] = sA[l4 * DG_LD + wm + mi * 16 + l15];                                     \
+            _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                     \
+                fb[0][ni] = sB[l4 * DG_LD + wn + ni * 16 + l15];                                     \
             _Pragma("unroll") for (int kq = 0; kq < DG_K / 4; kq++)                                  \
             {                                                                                        \
-                double fa[4], fb[DG_NI];                                                             \
-                _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                     \
-                    fa[mi] = sA[(kq * 4 + l4) * DG_LD + wm + mi * 16 + l15];                         \
-                _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                 \
-                    fb[ni] = sB[(kq * 4 + l4) * DG_LD + wn + ni * 16 + l15];                         \
+                if (kq + 1 < DG_K / 4)                                                               \
+                {                                                                                    \
+                    _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                 \
+                        fa[(kq + 1) & 1][mi] = sA[((kq + 1) * 4 + l4) * DG_LD + wm + mi * 16 + l15]; \
+                    _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                             \
+                        fb[(kq + 1) & 1][ni] = sB[((kq + 1) * 4 + l4) * DG_LD + wn + ni * 16 + l15]; \
+                }                                                                                    \
                 _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                 \
                 {                                                                                    \
                     if (!((b4 >> ni) & 1u))                                                          \
                         continue;                                                                    \
                     _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                 \
                         if ((a4 >> mi) & 1u)                                                         \
-                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ni], fa[mi], acc[ni][mi], 0, 0, DG_NEG_A); \
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kq & 1][ni], fa[kq & 1][mi], acc[ni][mi], 0, 0, DG_NEG_A); \
                 }                                                                                    \
             }                                                                                        \
         }                                                                                            \

@@ -1718,6 +1718,7 @@ struct Backend
     bool ready = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool bulk_streams_masked = false; // stream / stream2 leave PANGULU_HIP_RESERVED_CUS CUs to the GETRF stream
     hipStream_t stream2 = nullptr; // side stream: the MFMA update kernel runs beside the LDS update kernel
     hipStream_t stream3 = nullptr; // second side stream: GETRFs of a batch run beside its TSTRF/GESSM solves
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
@@ -1771,8 +1772,35 @@ void ensure_ready()
         exit(EXIT_FAILURE);
     }
     HIP_CHECK(hipSetDevice(B.device));
-    HIP_CHECK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&B.stream2, hipStreamNonBlocking));
+    // Optional (PANGULU_HIP_RESERVED_CUS=n, default 0 = off): the bulk streams (updates, solves, mirror maintenance) leave n
+    // CUs alone -- mask bit i is CU i / 8 of XCD i % 8 (tools/experiments/cu_mask_probe.hip) -- and the GETRF stream
+    // (stream3) sees all of them.  A GETRF workgroup needs 139 KB of LDS, i.e. a CU to itself, and an update launch that is
+    // still handing out workgroups never leaves one empty: the factorisations of the upper tree levels took 240-470 us
+    // beside such a launch against 205 us alone (tools/launch_size_histogram.py).  Measured with n = 8: GETRF time 15.3 ->
+    // 13.4 ms (bench matrix) and 58 -> 25 ms (fem27(80)), but the update kernel lost more than the 3 % of CUs it gave up
+    // (fem27(80): 126 -> 137 ms) and the factorisation did not get faster (47.3 vs 45.4-47.7 ms; 187 vs 175 ms): off.
+    {
+        long reserved = 0;
+        if (const char *e = getenv("PANGULU_HIP_RESERVED_CUS"))
+            reserved = atol(e);
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, B.device));
+        const int ncu = prop.multiProcessorCount;
+        if (reserved > 0 && reserved < ncu / 2 && ncu % 32 == 0)
+        {
+            std::vector<uint32_t> mask((size_t)ncu / 32, 0xFFFFFFFFu);
+            for (int i = ncu - (int)reserved; i < ncu; i++)
+                mask[(size_t)i / 32] &= ~(1u << (i % 32));
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&B.stream, (uint32_t)mask.size(), mask.data()));
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&B.stream2, (uint32_t)mask.size(), mask.data()));
+            B.bulk_streams_masked = true;
+        }
+        else
+        {
+            HIP_CHECK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+            HIP_CHECK(hipStreamCreateWithFlags(&B.stream2, hipStreamNonBlocking));
+        }
+    }
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_join, hipEventDisableTiming));
     HIP_CHECK(hipStreamCreateWithFlags(&B.stream3, hipStreamNonBlocking));
@@ -2824,7 +2852,8 @@ void process_run(int nb, task_t *tasks, size_t n, std::vector<task_t *> &getrf, 
     // The factorisations, the solves and the updates of one run are independent of each other: the GETRFs (a handful of
     // workgroups, latency-bound) go to a side stream that waits only for what was queued before this run and run beside
     // the update and TSTRF/GESSM kernels; the main stream joins at the end of the run.
-    bool side = B.opt_two_streams && !getrf.empty() && (!trsm.empty() || !ssssm.empty());
+    // (with CU-masked bulk streams a run of GETRFs alone goes there as well: a leaf level has one workgroup per CU)
+    bool side = B.opt_two_streams && !getrf.empty() && (!trsm.empty() || !ssssm.empty() || B.bulk_streams_masked);
     if (side)
     {
         HIP_CHECK(hipEventRecord(B.ev_fork3, B.stream));
