@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
     const u32 item = work[logical_block_id((unsigned)slabs)];
     const unsigned bid = (item >> 2) * (unsigned)slabs + (item & 3u);
     const TrsmDenseTaskD T = tasks[bid / slabs];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int o0 = (bid % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
     double *__restrict__ Bm = T.b;
     const double *__restrict__ LU = T.lu;
@@ -370,82 +370,109 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
     // exact no-op, so it is neither loaded nor multiplied.
     const unsigned short *fmap = mirror_map(LU, nb);
     const bool use_fmap = T.lu_map != 0;
-    // factor tile (q, p): the four k-quarters of this lane's A operand
-    const size_t a_lane = tstrf ? (size_t)l15 * nb + l4 : (size_t)l4 * nb + l15;
-#define TRSM_A_PTR(q_, p_) (LU + a_lane + (tstrf ? (size_t)(16 * (p_)) * nb + 16 * (q_) : (size_t)(16 * (q_)) * nb + 16 * (p_)))
-#define TRSM_A_LOAD(dst_, q_, p_)                                                  \
-    {                                                                              \
-        const double *ap_ = TRSM_A_PTR(q_, p_);                                    \
-        _Pragma("unroll") for (int kq_ = 0; kq_ < 4; kq_++)                        \
-            (dst_)[kq_] = tstrf ? ap_[4 * kq_] : ap_[(size_t)(4 * kq_) * nb];      \
+    // (the map words as scalars: the bit tests below then cost no vector instructions)
+    unsigned fm[NP];
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+        fm[c] = use_fmap ? (unsigned)__builtin_amdgcn_readfirstlane((int)fmap[c]) : 0xFFFFu;
+    // factor tile (q, p): the four k-quarters of this lane's A operand.  Addresses are scalar bases (tile, k-quarter) plus one
+    // constant lane offset: an f64 MFMA holds the SIMD's vector ALU for its 64 cycles, so vector address arithmetic is paid
+    // for in matrix-pipe time (pg_hip_dense.h, dg_scalar_base)
+    typedef const char __attribute__((address_space(1))) *gbytes;
+    typedef const double __attribute__((address_space(1))) *gdouble_c;
+    const unsigned a_voff = (unsigned)(tstrf ? l15 * nb + l4 : l4 * nb + l15) * 8u;
+#define TRSM_A_LOAD(dst_, q_, p_)                                                                                   \
+    {                                                                                                               \
+        const gbytes ab_ = (gbytes)LU + (tstrf ? (size_t)(16 * (p_)) * nb + 16 * (q_) : (size_t)(16 * (q_)) * nb + 16 * (p_)) * 8; \
+        _Pragma("unroll") for (int kq_ = 0; kq_ < 4; kq_++)                                                         \
+            (dst_)[kq_] = *(gdouble_c)(dg_scalar_base(ab_ + (tstrf ? (size_t)(4 * kq_) : (size_t)(4 * kq_) * nb) * 8) + dg_lane_offset(a_voff)); \
     }
+    // element g of this lane in solution tile p (TSTRF: X^T tiles, GESSM: X tiles; see the header)
+    const unsigned x_voff = (unsigned)(tstrf ? l4 * nb + l15 : l15 * nb + l4) * 8u;
+#define TRSM_X(p_, g_)                                                                                              \
+    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((gbytes)Bm + (tstrf ? (size_t)(16 * (p_) + 4 * (g_)) * nb + o0     \
+                                                                                         : (size_t)o0 * nb + 16 * (p_) + 4 * (g_)) * 8) + \
+                                                   dg_lane_offset(x_voff)))
     v4f64 xs[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++)
 #pragma unroll
         for (int g = 0; g < 4; g++)
-            xs[p][g] = !((my_lv >> p) & 1u) ? 0.0
-                                             : (tstrf ? Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] : Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g]);
+            xs[p][g] = !((my_lv >> p) & 1u) ? 0.0 : TRSM_X(p, g);
+    // live products of panel p: solution tile q live AND factor tile (q, p) live
+#define TRSM_LIVE_Q(out_, p_)                                                       \
+    {                                                                               \
+        unsigned fl_ = 0;                                                           \
+        if (tstrf)                                                                  \
+            fl_ = fm[p_]; /* tile column p of the image: bit q = rows 16q.. */      \
+        else                                                                        \
+        {                                                                           \
+            _Pragma("unroll") for (int q_ = 0; q_ < NP; q_++)                       \
+                fl_ |= ((fm[q_] >> (p_)) & 1u) << q_; /* tile row p: bit q = columns 16q.. */ \
+        }                                                                           \
+        (out_) = my_lv & fl_;                                                       \
+    }
+    // Factor tiles in flight: two register sets of two tiles each, used in turn by the stages of a panel (two products per
+    // stage; the loops are fully unrolled, so the set index is static and nothing is copied), and the inverted diagonal tile
+    // of the panel (two sets, by panel parity).  The first tiles of panel p+1 and its diagonal tile are requested at the end
+    // of panel p, before its diagonal multiply: without that every panel began with a full round trip to L2 (16 per
+    // wavefront, a third of a lone workgroup's 70 us).
+    double at[2][2][4], adb[2][4];
+    bool fetched = false; // the first loads of the coming panel have been issued by the one before
+    int set0 = 0;         // set of the coming panel's first stage (static after unrolling)
+#define TRSM_FIRST_LOADS(p_, lq_, set_)                                             \
+    {                                                                               \
+        TRSM_A_LOAD(adb[(p_) & 1], p_, p_) /* needed last */                        \
+        if ((p_) > 0 && (((lq_) >> 0) & 1u))                                        \
+            TRSM_A_LOAD(at[set_][0], 0, p_)                                         \
+        if ((p_) > 1 && (((lq_) >> 1) & 1u))                                        \
+            TRSM_A_LOAD(at[set_][1], 1, p_)                                         \
+    }
 #pragma unroll
     for (int p = 0; p < NP; p++)
     {
+        const int st = set0;
+        set0 = (set0 + (p + 1) / 2) & 1; // a panel has (p + 1) / 2 stages
         if (!((my_lv >> p) & 1u))
-            continue; // (wavefront-uniform)
-        // live products of this panel: solution tile q live AND factor tile (q, p) live
-        unsigned lq = my_lv;
-        if (use_fmap)
         {
-            unsigned fl = 0;
-            if (tstrf)
-                fl = fmap[p]; // tile column p of the image: bit q = rows 16q..
-            else
-            {
-#pragma unroll
-                for (int q = 0; q < NP; q++)
-                    fl |= (((unsigned)fmap[q] >> p) & 1u) << q; // tile row p: bit q = columns 16q..
-            }
-            lq &= (unsigned)__builtin_amdgcn_readfirstlane((int)fl);
+            fetched = false;
+            continue; // (wavefront-uniform)
         }
-        // the inverted diagonal tile goes in flight first, it is needed last
-        double ad[4];
-        TRSM_A_LOAD(ad, p, p)
+        unsigned lq;
+        TRSM_LIVE_Q(lq, p)
+        if (!fetched)
+            TRSM_FIRST_LOADS(p, lq, st)
         v4f64 part[4];
         part[0] = xs[p];
         part[1] = part[2] = part[3] = (v4f64){0.0, 0.0, 0.0, 0.0};
-        // products with the live tiles q < p, two steps of q per stage, the next stage's tiles in flight meanwhile
-        double a0[4], a1[4], n0[4], n1[4];
-        if (p > 0)
-        {
-            if ((lq >> 0) & 1u)
-                TRSM_A_LOAD(n0, 0, p)
-            if (p > 1 && ((lq >> 1) & 1u))
-                TRSM_A_LOAD(n1, 1, p)
-        }
 #pragma unroll
         for (int q = 0; q < p; q += 2)
         {
-#pragma unroll
-            for (int kq = 0; kq < 4; kq++)
-            {
-                a0[kq] = n0[kq];
-                a1[kq] = n1[kq];
-            }
+            const int cur = (st + (q >> 1)) & 1, nxt = cur ^ 1;
             if (q + 2 < p && ((lq >> (q + 2)) & 1u))
-                TRSM_A_LOAD(n0, q + 2, p)
+                TRSM_A_LOAD(at[nxt][0], q + 2, p)
             if (q + 3 < p && ((lq >> (q + 3)) & 1u))
-                TRSM_A_LOAD(n1, q + 3, p)
+                TRSM_A_LOAD(at[nxt][1], q + 3, p)
             if ((lq >> q) & 1u)
             {
 #pragma unroll
                 for (int kq = 0; kq < 4; kq++)
-                    part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[kq], xs[q][kq], part[kq], 0, 0, 0);
+                    part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[cur][0][kq], xs[q][kq], part[kq], 0, 0, 1); // (NEG field: part -= a x)
             }
             if (q + 1 < p && ((lq >> (q + 1)) & 1u))
             {
 #pragma unroll
                 for (int kq = 0; kq < 4; kq++)
-                    part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[kq], xs[q + 1][kq], part[kq], 0, 0, 0);
+                    part[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[cur][1][kq], xs[q + 1][kq], part[kq], 0, 0, 1);
             }
+        }
+        fetched = false;
+        if (p + 1 < NP && ((my_lv >> (p + 1)) & 1u))
+        {
+            unsigned lqn;
+            TRSM_LIVE_Q(lqn, p + 1)
+            TRSM_FIRST_LOADS(p + 1, lqn, set0)
+            fetched = true;
         }
         v4f64 acc = (part[0] + part[1]) + (part[2] + part[3]);
         // multiply by the inverted diagonal tile (upper part: inv(U_pp); strictly lower part: inv(L_pp), unit diagonal)
@@ -454,17 +481,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
         for (int kq = 0; kq < 4; kq++)
         {
             const int k = kq * 4 + l4; // TSTRF: A''[i = c'][k = c] = invU(c, c');  GESSM: A[i = r'][k = r] = invL(r', r)
+            const double adk = adb[p & 1][kq];
             double a;
             if (tstrf)
-                a = (k <= l15) ? ad[kq] : 0.0;
+                a = (k <= l15) ? adk : 0.0;
             else
-                a = (l15 > k) ? ad[kq] : ((l15 == k) ? 1.0 : 0.0);
+                a = (l15 > k) ? adk : ((l15 == k) ? 1.0 : 0.0);
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[kq], x, 0, 0, 0);
         }
         xs[p] = x;
     }
+#undef TRSM_FIRST_LOADS
+#undef TRSM_LIVE_Q
 #undef TRSM_A_LOAD
-#undef TRSM_A_PTR
 #pragma unroll
     for (int p = 0; p < NP; p++)
     {
@@ -472,13 +501,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
             continue;
 #pragma unroll
         for (int g = 0; g < 4; g++)
-        {
-            if (tstrf)
-                Bm[(size_t)(16 * p + l4 + 4 * g) * nb + o0 + l15] = xs[p][g];
-            else
-                Bm[(size_t)(o0 + l15) * nb + 16 * p + l4 + 4 * g] = xs[p][g];
-        }
+            TRSM_X(p, g) = xs[p][g];
     }
+#undef TRSM_X
 }
 
 // structural flops of the solves that ran on the dense path (src/pangulu_kernel_interface.c:84-159): one workgroup
