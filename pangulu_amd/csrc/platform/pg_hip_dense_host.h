@@ -44,6 +44,11 @@ struct BlockTable
         x *= 0x9E3779B97F4A7C15ull;
         return (size_t)(x >> 24);
     }
+    void prefetch(const void *k) const
+    {
+        if (count)
+            __builtin_prefetch(&tab[hash(k) & mask]);
+    }
     BlockState *find(const void *k)
     {
         if (count == 0)

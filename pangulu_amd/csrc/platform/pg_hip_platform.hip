@@ -1966,6 +1966,22 @@ inline slot_t *canon_dst(slot_t *s)
     return s;
 }
 
+// Building the descriptors of a task touches, per operand, the slot struct, the last entry of its pattern pointer array and
+// its block-table entry -- nine cache misses per update, and the leaf levels of the bench matrix (8000 updates + 4000
+// solves per level) were bound by this thread, not by the device.  Two-stage software prefetch, a fixed distance ahead in
+// the task list: the slot structs first, then what their fields point to.
+inline void prefetch_task_slots(const task_t *t)
+{
+    for (const slot_t *s : {t->op1, t->op2, t->opdst})
+        if (s)
+        {
+            __builtin_prefetch(s);
+            __builtin_prefetch(reinterpret_cast<const char *>(s) + 64);
+            __builtin_prefetch(reinterpret_cast<const char *>(s) + 128);
+        }
+}
+void prefetch_task_details(const task_t *t, int nb); // (needs the block table: defined after pg_hip_dense_host.h)
+
 inline void diag_halves(slot_t *any, slot_t **upper, slot_t **lower)
 {
     if (any->is_upper)
@@ -2046,11 +2062,39 @@ const double SV = (double)sizeof(val_t);
 
 #include "pg_hip_dense_host.h"
 
+void prefetch_task_details(const task_t *t, int nb)
+{
+    for (slot_t *s : {t->op1, t->op2, t->opdst})
+        if (s)
+        {
+            if (s->columnpointer)
+                __builtin_prefetch(&s->columnpointer[nb]);
+#if defined(PG_DENSE_UPDATES)
+            MP.blocks.prefetch(block_key(s));
+#endif
+        }
+}
+constexpr size_t PREFETCH_SLOTS_AHEAD = 24, PREFETCH_DETAILS_AHEAD = 12;
+
 // ---- SSSSM -----------------------------------------------------------------------------------------------------
 // Tasks arrive grouped by destination.  Per group the destination is either dense-mode (updates accumulate in its
 // mirror) or sparse; per task the update runs on the matrix cores when destination and both operands have mirrors,
 // on the LDS-accumulator kernel otherwise.
 #define DG_TILE_HOST 128 // = DG_TILE of pg_hip_dense.h (R64 only; harmless elsewhere)
+// Tasks per launch (PANGULU_HIP_LAUNCH_CHUNK).  The host builds the descriptors of a launch before it can start: a leaf level
+// of the bench matrix has 8000 updates and 4000 solves, and the device sat idle for 260 us per level while their mirror
+// jobs and descriptors were written.  Cut into chunks, the first kernels run while the rest is being prepared.
+size_t launch_chunk_tasks()
+{
+    static const size_t chunk = []()
+    {
+        const char *e = getenv("PANGULU_HIP_LAUNCH_CHUNK");
+        long v = e ? atol(e) : 0;
+        return v > 0 ? (size_t)v : ~(size_t)0;
+    }();
+    return chunk;
+}
+
 void launch_ssssm(int nb, task_t **list, size_t n)
 {
     if (n == 0)
@@ -2067,7 +2111,7 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         const size_t per_task = sizeof(SsssmTaskD) * (1 + PG_PLANES * PG_PLANES) + sizeof(SsssmGroupD) * (1 + PG_PLANES) +
                                 sizeof(SsssmWorkD) * 4 * PG_PLANES;
         size_t max_tasks = (seg.cap - 64 * 4 * PG_PLANES * (sizeof(SsssmGroupD) + 4 * sizeof(SsssmWorkD)) - 4096) / per_task;
-        size_t take = std::min(n - i, max_tasks);
+        size_t take = std::min(n - i, std::min(max_tasks, launch_chunk_tasks()));
         SsssmTaskD *d_tasks_s, *d_tasks_d;
         SsssmGroupD *d_groups_s, *d_groups_d;
         SsssmTaskD *tasks_s = seg.alloc<SsssmTaskD>(take, &d_tasks_s);
@@ -2153,6 +2197,10 @@ void launch_ssssm(int nb, task_t **list, size_t n)
 #endif
             for (size_t t = i; t < j; t++)
             {
+                if (t + PREFETCH_SLOTS_AHEAD < n)
+                    prefetch_task_slots(list[t + PREFETCH_SLOTS_AHEAD]);
+                if (t + PREFETCH_DETAILS_AHEAD < n)
+                    prefetch_task_details(list[t + PREFETCH_DETAILS_AHEAD], nb);
                 slot_t *a = list[t]->op1, *b = list[t]->op2;
                 SsssmTaskD T;
                 memset(&T, 0, sizeof(T));
@@ -2367,6 +2415,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
     {
         Segment seg = acquire_segment();
         size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64 + 80 + 4 * sizeof(u32))); // (+80: a remote-diagonal image job per task at worst)
+        take = std::min(take, launch_chunk_tasks());
         TrsmTaskD *d_tasks, *d_ftasks;
         TrsmTaskD *tasks = seg.alloc<TrsmTaskD>(take, &d_tasks);
         TrsmTaskD *ftasks = seg.alloc<TrsmTaskD>(take, &d_ftasks); // sparse views of the dense-path tasks (flop counting)
@@ -2384,6 +2433,10 @@ void launch_trsm(int nb, task_t **list, size_t n)
 #endif
         for (size_t k = 0; k < take; k++)
         {
+            if (i + k + PREFETCH_SLOTS_AHEAD < n)
+                prefetch_task_slots(list[i + k + PREFETCH_SLOTS_AHEAD]);
+            if (i + k + PREFETCH_DETAILS_AHEAD < n)
+                prefetch_task_details(list[i + k + PREFETCH_DETAILS_AHEAD], nb);
             task_t *t = list[i + k];
             slot_t *dst = t->opdst, *diag = t->op1;
             // opdiag may be either half (…0100000.c:143-145,184-186); only the half the solve reads has to exist

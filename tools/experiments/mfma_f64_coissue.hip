@@ -8,7 +8,7 @@
 #include <cstdio>
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(512) void k(int role_a, int role_b, unsigned long long *out, double *sink)
+__global__ __launch_bounds__(512) void k(int role_a, int role_b, unsigned long long *out, double *sink, int prio_b)
 {
     __shared__ double lds[4096];
     const int wave = threadIdx.x >> 6;
@@ -16,6 +16,8 @@ __global__ __launch_bounds__(512) void k(int role_a, int role_b, unsigned long l
     for (int i = threadIdx.x; i < 4096; i += 512)
         lds[i] = i;
     __syncthreads();
+    if (wave >= 4 && prio_b)
+        __builtin_amdgcn_s_setprio(3); // (does a higher wave priority get the second wavefront's VALU work in between the MFMAs?)
     unsigned long long t0 = __builtin_readcyclecounter();
     double r = 0;
     if (role == 1)
@@ -94,16 +96,17 @@ int main()
     hipMalloc(&d, sizeof(h));
     hipMalloc(&sink, 8);
     const char *names[] = {"idle", "mfma_f64 x16384", "int valu x131072", "fma_f64 x131072", "ds_read_b64 x32768 + add"};
-    const int combos[][2] = {{1, 0}, {2, 0}, {3, 0}, {4, 0}, {1, 1}, {1, 2}, {1, 3}, {1, 4}, {2, 2}, {3, 3}};
+    const int combos[][3] = {{1, 0, 0}, {2, 0, 0}, {3, 0, 0}, {4, 0, 0}, {1, 1, 0}, {1, 2, 0}, {1, 3, 0}, {1, 4, 0}, {2, 2, 0}, {3, 3, 0},
+                             {1, 2, 1}, {1, 3, 1}, {1, 4, 1}, {1, 1, 1}};
     for (auto &c : combos)
     {
         for (int rep = 0; rep < 2; rep++)
         {
-            hipLaunchKernelGGL(k, dim3(1), dim3(512), 0, 0, c[0], c[1], d, sink);
+            hipLaunchKernelGGL(k, dim3(1), dim3(512), 0, 0, c[0], c[1], d, sink, c[2]);
             hipDeviceSynchronize();
         }
         hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-        printf("waves 0-3: %-28s waves 4-7: %-28s | clocks wave0 %9llu wave4 %9llu\n", names[c[0]], names[c[1]], h[0], h[4]);
+        printf("waves 0-3: %-28s waves 4-7: %-28s %s| clocks wave0 %9llu wave4 %9llu\n", names[c[0]], names[c[1]], c[2] ? "(s_setprio 3) " : "", h[0], h[4]);
     }
     return 0;
 }
