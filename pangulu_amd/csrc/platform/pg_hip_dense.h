@@ -85,12 +85,23 @@ __device__ inline unsigned dg_lane_offset(unsigned v)
 // f64 MFMAs reuse the BLGP immediate as NEG bits (bit 0: first source): D = C - A B without negating anything beforehand
 #define DG_NEG_A 1
 
-// 4 wavefronts per workgroup: 64 x 64 sub-tiles (4 x 4 accumulators), two workgroups = two wavefronts per SIMD.  (A variant
-// with 8 wavefronts of 64 x 32 sub-tiles, sixteen wavefronts per CU, measured equal in round 2 and was dropped.)
-#define DG_WAVES 4
+// Wavefronts per workgroup (compile time).
+//   8 (default since the end of round 2): 64 x 32 sub-tiles (2 x 4 accumulators), 125 registers, two workgroups = four
+//      wavefronts per SIMD; one slab in flight in registers, MFMA operand fragments single-buffered (no registers for
+//      more -- the other three wavefronts of the SIMD cover those waits).
+//   4: 64 x 64 sub-tiles (4 x 4 accumulators), 247 registers, two wavefronts per SIMD; two slabs in flight, fragments of the
+//      next k-quarter read while the matrix cores work on the current one.
+// Measured equal in the middle of round 2, when every slab still cost each wavefront ~100 vector instructions of address
+// arithmetic (twice the wavefronts = twice that, against the matrix pipe: see dg_scalar_base).  After the diet: bench
+// matrix 43.8-43.9 ms with 8 against 46.0-46.3 ms with 4 (same box, alternating runs), fem27(80) 166.9 against 170.3 ms.
+#ifndef DG_WAVES
+#define DG_WAVES 8
+#endif
 #define DG_THREADS (64 * DG_WAVES)
-#define DG_NI 4 // 16-column pieces of C per wavefront
-__global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssssm_dense_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb,
+#define DG_NI (DG_WAVES == 8 ? 2 : 4) // 16-column pieces of C per wavefront (8 wavefronts: 64 x 32 sub-tiles, four wavefronts per SIMD)
+#define DG_NST (16 / DG_WAVES)        // 16-byte pieces of each operand slab a thread stages (4 or 2)
+#define DG_FB (DG_WAVES == 8 ? 1 : 2)  // MFMA operand fragment buffers
+__global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_WAVES / 2, DG_WAVES / 2))) void ssssm_dense_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb,
                                                                unsigned long long *__restrict__ product_counter,
                                                                unsigned long long *dbg, const SsssmWorkD *__restrict__ work)
 {
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (scalar: the skip tests below must be scalar branches)
     const int M0 = (tile % tiles) * DG_TILE, N0 = (tile / tiles) * DG_TILE; // workgroup tile origin
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;                   // wavefront sub-tile inside it
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * (16 * DG_NI);         // wavefront sub-tile inside it
     const int l15 = lane & 15, l4 = lane >> 4;
 
     v4f64 acc[DG_NI][4]; // [ni][mi]; initialised below, once it is known which pieces are going to be used
@@ -131,13 +142,17 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int a_m = 2 * (tid & 63), a_k = wave; // (a_k = tid >> 6, as a scalar)
     const int b_k = 2 * (tid & 7), b_n = tid >> 3;
     const int a_slab = (tid & 63) >> 3;                            // which 16-row slab of the tile this thread stages
-    const int b_slab = __builtin_amdgcn_readfirstlane(tid >> 7);   // 16-column slab of piece i: b_slab + 2 i
+    const int b_slab = __builtin_amdgcn_readfirstlane(tid >> 7);   // 16-column slab of piece i: b_slab + (DG_WAVES / 2) i
     // the two slabs in flight (first-class vector values: a struct type here is copied with memcpy through a stack slot),
     // loaded through global-address-space pointers (the mirror addresses pass through LDS as integers; left generic they
     // become flat loads, which also count against the LDS counter)
     typedef double v2f64 __attribute__((ext_vector_type(2)));
     typedef const v2f64 __attribute__((address_space(1))) *slab_ptr;
-    v2f64 raX[4], rbX[4], raY[4], rbY[4];
+#if DG_WAVES == 8
+    v2f64 raX[DG_NST], rbX[DG_NST];
+#else
+    v2f64 raX[DG_NST], rbX[DG_NST], raY[DG_NST], rbY[DG_NST];
+#endif
 
     const u32 ntask = G.task_end - G.task_begin;
     const int steps_per_task = nb / DG_K; // <= 16: dense mode needs nb <= 256 (the occupancy maps have 16 x 16 bits)
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         __syncthreads(); /* nobody reads the previous window any more */                             \
         const int t_ = tid >> 4, s_ = tid & 15;                                                      \
         unsigned v_ = 0;                                                                             \
-        if (win0 + t_ < (int)ntask && s_ < steps_per_task)                                           \
+        if (tid < 256 && win0 + t_ < (int)ntask && s_ < steps_per_task)                              \
         {                                                                                            \
             const SsssmTaskD &Tm_ = tasks[G.task_begin + win0 + t_];                                 \
             const double *pa_ = reinterpret_cast<const double *>(Tm_.a.val), *pb_ = reinterpret_cast<const double *>(Tm_.b.val); \
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }                                                                                            \
         const unsigned long long bal_ = __ballot(v_ != 0);                                           \
         if (lane == 0)                                                                               \
-            s_cnt[wave] = (u32)__builtin_popcountll(bal_);                                           \
+            s_cnt[wave] = (u32)__builtin_popcountll(bal_); /* (wavefronts 4..7: zero) */             \
         __syncthreads();                                                                             \
         unsigned at_ = (unsigned)__builtin_popcountll(bal_ & ((1ull << lane) - 1ull)), all_ = 0;     \
         _Pragma("unroll") for (int w_i = 0; w_i < DG_WAVES; w_i++)                                   \
@@ -267,12 +282,12 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     {                                                                                                \
         const unsigned av_ = ((ab_) & a_bit) ? a_voff : 0u;                                          \
         const gbytes A_ = (gbytes)(pa_) + ((size_t)((k0_) + a_k) * nb + M0) * 8;                     \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                             \
-            ra_[i_] = *(slab_ptr)(dg_scalar_base(A_ + (size_t)(4 * i_) * nb * 8) + av_);             \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < DG_NST; i_++)                                        \
+            ra_[i_] = *(slab_ptr)(dg_scalar_base(A_ + (size_t)(DG_WAVES * i_) * nb * 8) + av_);      \
+        _Pragma("unroll") for (int i_ = 0; i_ < DG_NST; i_++)                                        \
         {                                                                                            \
-            const bool live_ = ((bb_) >> (b_slab + 2 * i_)) & 1u;                                    \
-            const gbytes Bi_ = (gbytes)(pb_) + (live_ ? ((size_t)(N0 + 32 * i_) * nb + (k0_)) * 8 : (size_t)0); \
+            const bool live_ = ((bb_) >> (b_slab + (DG_WAVES / 2) * i_)) & 1u;                       \
+            const gbytes Bi_ = (gbytes)(pb_) + (live_ ? ((size_t)(N0 + 8 * DG_WAVES * i_) * nb + (k0_)) * 8 : (size_t)0); \
             rb_[i_] = *(slab_ptr)(dg_scalar_base(Bi_) + dg_lane_offset(live_ ? b_voff : 0u));      \
         }                                                                                            \
     }
@@ -285,17 +300,17 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     {                                                                                                \
         double *sA_ = sAb[buf_], *sB_ = sBb[buf_];                                                   \
         /* (pieces that were not fetched hold whatever the dummy load returned; no MFMA reads them) */ \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < DG_NST; i_++)                                        \
         {                                                                                            \
-            *reinterpret_cast<v2f64 *>(&sA_[(a_k + 4 * i_) * DG_LD + a_m]) = DG_SIGNED(ra_[i_], sg_); \
-            sB_[b_k * DG_LD + b_n + 32 * i_] = rb_[i_].x;                                            \
-            sB_[(b_k + 1) * DG_LD + b_n + 32 * i_] = rb_[i_].y;                                      \
+            *reinterpret_cast<v2f64 *>(&sA_[(a_k + DG_WAVES * i_) * DG_LD + a_m]) = DG_SIGNED(ra_[i_], sg_); \
+            sB_[b_k * DG_LD + b_n + 8 * DG_WAVES * i_] = rb_[i_].x;                                  \
+            sB_[(b_k + 1) * DG_LD + b_n + 8 * DG_WAVES * i_] = rb_[i_].y;                            \
         }                                                                                            \
     }
 #define DG_PRODUCTS(buf_, ab_, bb_)                                                                  \
     {                                                                                                \
         const double *sA = sAb[buf_], *sB = sBb[buf_];                                               \
-        const unsigned a4 = ((ab_) >> (wm / 16)) & 0xFu, b4 = ((bb_) >> (wn / 16)) & 0xFu;           \
+        const unsigned a4 = ((ab_) >> (wm / 16)) & 0xFu, b4 = ((bb_) >> (wn / 16)) & ((1u << DG_NI) - 1u); \
         if (a4 && b4)                                                                                \
         {                                                                                            \
             nprod += (unsigned)(__builtin_popcount(a4) * __builtin_popcount(b4));                    \
@@ -303,20 +318,25 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 if ((b4 >> ni) & 1u)                                                                 \
                     touched |= a4 << (4 * ni);                                                       \
             /* operand fragments of k-quarter kq+1 are read while the matrix cores work on kq: the LDS round trip      */ \
-            /* (4 per slab) would otherwise sit in front of every group of sixteen MFMAs                               */ \
-            double fa[2][4], fb[2][DG_NI];                                                           \
-            _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                         \
-                fa[0][mi] = sA[l4 * DG_LD + wm + mi * 16 + l15];                                     \
-            _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                     \
-                fb[0][ni] = sB[l4 * DG_LD + wn + ni * 16 + l15];                                     \
+            /* (4 per slab) would otherwise sit in front of every group of sixteen MFMAs.  (8 wavefronts: no registers  */ \
+            /* for that, and four wavefronts per SIMD to cover it: DG_FB = 1 buffer)                                    */ \
+            double fa[DG_FB][4], fb[DG_FB][DG_NI];                                                   \
+            if (DG_FB == 2)                                                                          \
+            {                                                                                        \
+                _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                     \
+                    fa[0][mi] = sA[l4 * DG_LD + wm + mi * 16 + l15];                                 \
+                _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                 \
+                    fb[0][ni] = sB[l4 * DG_LD + wn + ni * 16 + l15];                                 \
+            }                                                                                        \
             _Pragma("unroll") for (int kq = 0; kq < DG_K / 4; kq++)                                  \
             {                                                                                        \
-                if (kq + 1 < DG_K / 4)                                                               \
+                const int kr = DG_FB == 2 ? kq + 1 : kq; /* the quarter read in this round */        \
+                if (kr < DG_K / 4)                                                                   \
                 {                                                                                    \
                     _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                 \
-                        fa[(kq + 1) & 1][mi] = sA[((kq + 1) * 4 + l4) * DG_LD + wm + mi * 16 + l15]; \
+                        fa[kr % DG_FB][mi] = sA[(kr * 4 + l4) * DG_LD + wm + mi * 16 + l15];         \
                     _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                             \
-                        fb[(kq + 1) & 1][ni] = sB[((kq + 1) * 4 + l4) * DG_LD + wn + ni * 16 + l15]; \
+                        fb[kr % DG_FB][ni] = sB[(kr * 4 + l4) * DG_LD + wn + ni * 16 + l15];         \
                 }                                                                                    \
                 _Pragma("unroll") for (int ni = 0; ni < DG_NI; ni++)                                 \
                 {                                                                                    \
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         continue;                                                                    \
                     _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                 \
                         if ((a4 >> mi) & 1u)                                                         \
-                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kq & 1][ni], fa[kq & 1][mi], acc[ni][mi], 0, 0, DG_NEG_A); \
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kq % DG_FB][ni], fa[kq % DG_FB][mi], acc[ni][mi], 0, 0, DG_NEG_A); \
                 }                                                                                    \
             }                                                                                        \
         }                                                                                            \
@@ -367,7 +387,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int e = lane; e < nwin; e += 64)
         {
             const unsigned v = s_step[e];
-            const unsigned a4 = ((v & 0xFFu) >> (wm / 16)) & 0xFu, b4 = (((v >> 8) & 0xFFu) >> (wn / 16)) & 0xFu;
+            const unsigned a4 = ((v & 0xFFu) >> (wm / 16)) & 0xFu, b4 = (((v >> 8) & 0xFFu) >> (wn / 16)) & ((1u << DG_NI) - 1u);
 #pragma unroll
             for (int ni = 0; ni < DG_NI; ni++)
                 if ((b4 >> ni) & 1u)
@@ -402,6 +422,39 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             for (int mi = 0; mi < 4; mi++)
                 acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
     }
+#if DG_WAVES == 8
+    // Eight wavefronts (128 registers each): ONE slab in flight -- set X only; four wavefronts per SIMD cover the rest.
+    // Invariant at the loop head: image 0 holds step j (scalars 0), scalars 1 describe step j+1 (possibly past the end).
+    DG_FETCH(ab1, bb1, k01, pa1, pb1, sg1)
+    DG_STAMP(1)
+    DG_STORE_LDS(0, raX, rbX, sg0)
+    DG_STAMP(2)
+    __syncthreads();
+    DG_STAMP(3)
+    do
+    {
+        DG_LOAD_SLAB(raX, rbX, ab1, bb1, k01, pa1, pb1)
+        DG_STAMP(4)
+        DG_PRODUCTS(0, ab0, bb0)
+        DG_STAMP(5)
+        DG_STORE_LDS(1, raX, rbX, sg1)
+        DG_STAMP(2)
+        __syncthreads();
+        DG_STAMP(3)
+        DG_FETCH(ab0, bb0, k00, pa0, pb0, sg0)
+        DG_LOAD_SLAB(raX, rbX, ab0, bb0, k00, pa0, pb0)
+        DG_STAMP(4)
+        DG_PRODUCTS(1, ab1, bb1)
+        DG_STAMP(5)
+        if (stamping)
+            atomicAdd(&dbg[7], (ab1 ? 2ull : 1ull)); // slab steps in the low word
+        DG_STORE_LDS(0, raX, rbX, sg0)
+        DG_STAMP(2)
+        __syncthreads();
+        DG_STAMP(3)
+        DG_FETCH(ab1, bb1, k01, pa1, pb1, sg1)
+    } while (ab0 | bb0);
+#else
     DG_FETCH(ab1, bb1, k01, pa1, pb1, sg1)
     DG_LOAD_SLAB(raY, rbY, ab1, bb1, k01, pa1, pb1)
     DG_STAMP(1)
@@ -439,6 +492,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         __syncthreads();
         DG_STAMP(3)
     } while (ab0 | bb0);
+#endif
 #undef DG_STORE_LDS
 #undef DG_FETCH
 #undef DG_FILL_WINDOW
