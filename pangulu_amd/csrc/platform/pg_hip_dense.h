@@ -81,7 +81,9 @@ __device__ inline unsigned dg_lane_offset(unsigned v)
 // 8-way conflict per store); 146 / 148 spread those too: 24.6 -> 23.6 ms of update-kernel time (152: 24.8, 136: 24.2)
 #define DG_LD 148
 #endif
-#define DG_WINDOW 16 // tasks whose bookkeeping is held in LDS at a time
+#ifndef DG_WINDOW
+#define DG_WINDOW 16 // tasks whose bookkeeping is held in LDS at a time (one (task, K-slab) pair per thread: 16 or 32)
+#endif
 // f64 MFMAs reuse the BLGP immediate as NEG bits (bit 0: first source): D = C - A B without negating anything beforehand
 #define DG_NEG_A 1
 
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(DG_W
         __syncthreads(); /* nobody reads the previous window any more */                             \
         const int t_ = tid >> 4, s_ = tid & 15;                                                      \
         unsigned v_ = 0;                                                                             \
-        if (tid < 256 && win0 + t_ < (int)ntask && s_ < steps_per_task)                              \
+        if (tid < DG_WINDOW * 16 && win0 + t_ < (int)ntask && s_ < steps_per_task)                   \
         {                                                                                            \
             const SsssmTaskD &Tm_ = tasks[G.task_begin + win0 + t_];                                 \
             const double *pa_ = reinterpret_cast<const double *>(Tm_.a.val), *pb_ = reinterpret_cast<const double *>(Tm_.b.val); \
