@@ -158,6 +158,10 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one process per GPU)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # completion signals by polling instead of interrupts (must be set before the runtime starts): the scheduler and launcher
+    # threads wait on hundreds of short events per factorisation; measured 44.2 ms (all 40 steps within 43.8-44.8) against
+    # 44.6 ms (44.0-48.0) on one box.  A user of the library sets it the same way.
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     os.environ["LOCAL_RANK"] = str(local_rank)
 
     import torch  # device selection + the synchronise the contract asks for; not on the compute path

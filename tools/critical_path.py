@@ -21,16 +21,20 @@ def cls(name):
 
 
 def main(path, which=-1):
-    rows = [r for r in csv.DictReader(open(path)) if "rocclr" not in r["Kernel_Name"]]  # (the un-timed reset copies)
-    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), cls(r["Kernel_Name"])) for r in rows)
-    # factorisations are separated by the un-timed reset (copies, no kernels): split at gaps > 2 ms
-    groups, cur = [], [ev[0]]
-    for e in ev[1:]:
-        if e[0] - max(x[1] for x in cur[-50:]) > 2_000_000:
-            groups.append(cur)
-            cur = []
-        cur.append(e)
-    groups.append(cur)
+    # factorisations are separated by the un-timed reset of the block values, whose device-to-device copies show up as
+    # rocclr copy kernels: a new group starts after every run of them (a fixed idle-time threshold mistook a 2 ms host
+    # stall inside a factorisation for the boundary once)
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    groups, cur = [], []
+    for r in rows:
+        if "rocclr" in r["Kernel_Name"]:
+            if cur:
+                groups.append(cur)
+                cur = []
+            continue
+        cur.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), cls(r["Kernel_Name"])))
+    if cur:
+        groups.append(cur)
     # factorisations only (the triangular solve at the end of a bench run is a group of its own)
     groups = [g for g in groups if len(g) > 50 and any(e[2] in ("SD", "SS", "GF") for e in g)]
     g = groups[which]
