@@ -199,7 +199,7 @@ extern "C"
      *   PANGULU_HIP_OPT_HOST_MIRROR (default 1): after GETRF/TSTRF/GESSM copy the block's values back into
      *     slot->value like …0201000.cu:639-640,680,714 does (the reference host's MPI send and SpTRSV read
      *     host memory).  The native host keeps factors device-resident and sets 0.
-     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 10): an update C -= A*B whose operands have a
+     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 5): an update C -= A*B whose operands have a
      *     geometric-mean fill sqrt(dA*dB) of at least this many per mille runs on the f64 MFMA kernel on dense
      *     mirrors of the three blocks (kept in HBM, built once per block); a destination that has a mirror
      *     accumulates all its updates there.  1000 = only completely full operands (the reference's
