@@ -1,0 +1,42 @@
+"""Every back-end switch that ships must still produce the oracle's factors: each setting runs in its own process (the
+switches are read once) on a mid-size matrix at nb = 256 where the dense paths engage.  Tolerance 1e-12 on the factors
+relative to their largest entry, residual and the reference's factor check (src/pangulu_numeric.c:1082-1341) below 1e-12."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SWITCHES = [
+    {},  # defaults
+    {"PANGULU_HIP_TRSM_DIRECT": "0"},          # LDS-staged dense solves
+    {"PANGULU_HIP_GETRF_TILED": "0"},          # round-1 GETRF with look-ahead inside the block
+    {"PANGULU_HIP_GETRF_TILED": "0", "PANGULU_HIP_GETRF_LOOKAHEAD": "0"},
+    {"PANGULU_HIP_RECORDS_STREAM": "0"},       # sparsify jobs of finished blocks on the main stream
+    {"PANGULU_HIP_OCCUPANCY_SUMMARIES": "0"},  # no host-side pattern summaries: maps read behind the mirrors, full work lists
+    {"PANGULU_HIP_RESERVED_CUS": "8"},         # CU-masked bulk streams
+    {"PANGULU_HIP_LAUNCH_CHUNK": "64"},        # launches cut into chunks of 64 tasks
+    {"PANGULU_AMD_ASYNC_LAUNCH": "0"},         # platform calls on the scheduler thread
+    {"PANGULU_AMD_BIND_NUMA": "0"},
+    {"HSA_ENABLE_INTERRUPT": "0"},             # what bench.py sets
+]
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=["+".join("%s=%s" % kv for kv in e.items()) or "defaults" for e in SWITCHES])
+def test_backend_switch_keeps_parity(env):
+    e = dict(os.environ)
+    e.update(env)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "env_switch_worker.py"), "shell"], env=e, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["dL"] <= 1e-12 and r["dU"] <= 1e-12, r
+    assert r["residual"] <= 1e-12 and r["lu_check"] <= 1e-12, r
+    assert r["flop_counted"] == r["flop"], r
+    assert r["dense_updates"] > 0 and r["dense_solves"] > 0 and r["getrf_launches"] > 0, r
