@@ -222,3 +222,40 @@ def test_spmv_vecadd_sptrsv_operators(vtype):
                 fh("free")(dx)
     finally:
         g.free()
+
+
+def test_operators_reproduce_the_committed_vectors():
+    """The HIP operators, one call per task, against tests/golden/operator_vectors.json (the oracle's before/after vectors,
+    committed with the script that made them): every task's destination sum / sum of squares and the full vectors of the first
+    GETRF, TSTRF, GESSM and SSSSM, 1e-12 relative to the largest entry."""
+    import importlib.util
+    import json
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_operator_vectors", os.path.join(here, "make_operator_vectors.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(os.path.join(here, "operator_vectors.json")))
+    hip, fh, _ = _platforms("r64")
+    recs = S.exported_records(mk.case_matrix(), mk.CASE["nb"], "r64")
+    g = S.BlockMatrix(recs, mk.CASE["nb"], np.float64, hip)
+    try:
+        tasks = g.tasks()
+        assert len(tasks) == len(gold["tasks"])
+        for (kid, dst, a, b), want in zip(tasks, gold["tasks"]):
+            assert mk.KIND[kid] == want["kind"] and [int(dst.brow), int(dst.bcol), int(dst.is_upper)] == want["dst"]
+            halves = [dst] if kid != S.GETRF else [dst, g.blocks[(dst.brow, dst.bcol, 0 if dst.is_upper else 1)]]
+            if "before" in want:
+                for h, w in zip(halves, want["before"]):
+                    assert np.abs(h.download_values() - np.array(w)).max(initial=0.0) <= 1e-12
+            _run_serial(fh, g, [(kid, dst, a, b)])
+            fh("synchronize")()
+            after = [h.download_values() for h in halves]
+            scale = max(1.0, max(float(np.abs(x).max(initial=0.0)) for x in after))
+            assert abs(sum(float(x.sum()) for x in after) - want["sum"]) <= 1e-12 * scale * sum(x.size for x in after)
+            if "after" in want:
+                for x, w in zip(after, want["after"]):
+                    assert np.abs(x - np.array(w)).max(initial=0.0) <= 1e-12 * scale
+    finally:
+        g.free()

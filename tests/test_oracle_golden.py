@@ -134,3 +134,42 @@ def test_openblas_backed_ssssm_matches_triple_loop():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert float(out.stdout.strip().splitlines()[-1]) < 1e-13
+
+
+def test_operator_vectors_are_what_the_oracle_produces():
+    """tests/golden/operator_vectors.json (made by tests/golden/make_operator_vectors.py): the oracle's 0100000 operators, one
+    call per task on hand-built slots, reproduce the committed before/after vectors -- sums of every task to 1e-13 relative,
+    the full vectors of the first task of each kind to 1e-14 absolute on O(1) data."""
+    import ctypes
+    import importlib.util
+    import json
+    import os
+
+    import numpy as np
+
+    from . import slots as S
+    from .helpers import oracle_library
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_operator_vectors", os.path.join(here, "make_operator_vectors.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(os.path.join(here, "operator_vectors.json")))
+    assert gold["case"] == mk.CASE
+    recs = S.exported_records(mk.case_matrix(), mk.CASE["nb"], mk.CASE["vtype"])
+    bm = S.BlockMatrix(recs, mk.CASE["nb"], np.float64, None)
+    fo = S.declare_platform(ctypes.CDLL(oracle_library(mk.CASE["vtype"])), "0100000")
+    trace = mk.replay(mk.oracle_call(fo), bm)
+    assert len(trace) == len(gold["tasks"]) and len(bm.blocks) == gold["blocks"]
+    full = 0
+    for got, want in zip(trace, gold["tasks"]):
+        assert (got["kind"], got["dst"], got.get("op1"), got.get("op2")) == (want["kind"], want["dst"], want.get("op1"), want.get("op2"))
+        assert abs(got["sum"] - want["sum"]) <= 1e-13 * max(1.0, abs(want["sum"]))
+        assert abs(got["sumsq"] - want["sumsq"]) <= 1e-13 * max(1.0, abs(want["sumsq"]))
+        if "after" in want:
+            full += 1
+            for g, w in zip(got["before"], want["before"]):
+                assert np.abs(np.array(g) - np.array(w)).max(initial=0.0) <= 1e-14
+            for g, w in zip(got["after"], want["after"]):
+                assert np.abs(np.array(g) - np.array(w)).max(initial=0.0) <= 1e-14
+    assert full == 4
