@@ -138,7 +138,7 @@ struct Sched
     bool panel_lookahead_on = true;   // PANGULU_AMD_PANEL_LOOKAHEAD (0 disables)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
-    double gather_max_s = 600e-6, gather_quiet_s = 60e-6, t_gather = 0;
+    double gather_max_s = 600e-6, gather_quiet_s = 60e-6, t_gather = 0, t_idle = 0, t_work = 0;
     // ... but only while blocks ARE arriving: the receive thread counts arrivals and pulls in flight; a drain that
     // follows a dispatch with neither (the subtree phase of the factorisation exchanges nothing) goes out at once
     std::atomic<u64> arrivals{0};
@@ -836,7 +836,9 @@ struct Sched
                               "(%llu updates queued): a block that was announced never arrived, or a dependency cycle",
                               S.rank, now - t_last_progress, (long long)S.rank_remain_task, (long long)S.rank_remain_recv,
                               (unsigned long long)S.pending_total);
+                    const double t_idle0 = wall_seconds();
                     usleep(20);
+                    t_idle += wall_seconds() - t_idle0;
                 }
                 else
                     t_last_progress = 0;
@@ -844,8 +846,15 @@ struct Sched
             }
             t_last_progress = 0;
             S.rank_remain_task -= (i64)batch.size();
+            const double t_work0 = wall_seconds();
             work_batched();
+            t_work += wall_seconds() - t_work0;
         }
+        if (trace)
+            fprintf(stderr, "[pangulu_amd trace] rank %d: scheduler loop %.1f ms: waiting for arrivals (nothing runnable) %.1f, gathering small batches %.1f, "
+                            "dispatch + release %.1f (platform calls %.1f), %llu batches\n",
+                    S.rank, 1e3 * (wall_seconds() - t_loop_begin), 1e3 * t_idle, 1e3 * t_gather, 1e3 * t_work, 1e3 * t_platform,
+                    (unsigned long long)batches);
         // updates into tiles are always flushed by the tile's own panel task, so nothing can be left
         if (S.pending_total != 0)
             fatal("scheduler finished with %llu queued updates", (unsigned long long)S.pending_total);
