@@ -213,6 +213,16 @@ void assign_subtrees(Solver &S)
                 stack.push_back(c);
         }
     }
+    // Experimental (PANGULU_AMD_TOP_COLUMNS_ON_RANK0=K, default 0 = off): the last K block columns -- the top of the tree, a
+    // chain of levels with one or two diagonal blocks each, where a 2D block-cyclic map makes every level several round trips
+    // between ranks -- go to rank 0 with their whole panels.  Trades balance for latency.  On two ranks sharing one GPU (the
+    // only multi-rank configuration the builder can run) it changed nothing: 159-168 vs 163-172 ms.
+    if (const char *tk = getenv("PANGULU_AMD_TOP_COLUMNS_ON_RANK0"))
+    {
+        const long K = atol(tk);
+        for (u32 k = nbk; k-- > 0 && (long)(nbk - k) <= K;)
+            S.home[k] = 0;
+    }
     if (S.rank == 0 && getenv("PANGULU_AMD_TRACE"))
     {
         size_t top = 0;
