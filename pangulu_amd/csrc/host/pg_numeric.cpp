@@ -654,8 +654,16 @@ struct Sched
         S.pending_dirty.resize(w);
     }
 
+    double t_sec[5] = {0, 0, 0, 0, 0}; // (trace) work_batched: queued updates, panel call, send gate, successor release
     void work_batched()
     {
+        double t_s = wall_seconds();
+#define SEC(i_)                            \
+    {                                      \
+        const double now_ = wall_seconds(); \
+        t_sec[i_] += now_ - t_s;           \
+        t_s = now_;                        \
+    }
         // (1) every update queued on a tile of this drain runs first, as one batch
         {
             std::lock_guard<std::mutex> g(S.info_mutex);
@@ -665,6 +673,7 @@ struct Sched
                 rebuild_dirty_list();
         }
         run_updates_and_release_operands();
+        SEC(0)
         // (2) the panel tasks themselves.  A few diagonal factorisations on their own leave the device almost idle
         // (one workgroup each): every update queued anywhere else goes into the same call, the back-end runs the
         // two kinds side by side
@@ -712,6 +721,7 @@ struct Sched
         }
         else
             run_platform_batch(batch);
+        SEC(1)
         if (multi)
         {
             // finished blocks are about to be announced: either the transport holds the announcements back until a
@@ -719,6 +729,7 @@ struct Sched
             if (!(use_markers && comm->set_send_gate(current_marker())))
                 plat.synchronize();
         }
+        SEC(2)
         // (3) successor release
         std::lock_guard<std::mutex> g(S.info_mutex);
         for (auto &t : batch)
@@ -746,6 +757,8 @@ struct Sched
                 release_after_U(t.opdst, level, t.col, multi);
             }
         }
+        SEC(3)
+#undef SEC
     }
 
     // nothing runnable: use the time for queued updates (src/pangulu_task.c:93-177)
@@ -852,9 +865,9 @@ struct Sched
         }
         if (trace)
             fprintf(stderr, "[pangulu_amd trace] rank %d: scheduler loop %.1f ms: waiting for arrivals (nothing runnable) %.1f, gathering small batches %.1f, "
-                            "dispatch + release %.1f (platform calls %.1f), %llu batches\n",
+                            "dispatch + release %.1f (platform calls %.1f; queued updates %.1f, panel call %.1f, send gate %.1f, successor release %.1f), %llu batches\n",
                     S.rank, 1e3 * (wall_seconds() - t_loop_begin), 1e3 * t_idle, 1e3 * t_gather, 1e3 * t_work, 1e3 * t_platform,
-                    (unsigned long long)batches);
+                    1e3 * t_sec[0], 1e3 * t_sec[1], 1e3 * t_sec[2], 1e3 * t_sec[3], (unsigned long long)batches);
         // updates into tiles are always flushed by the tile's own panel task, so nothing can be left
         if (S.pending_total != 0)
             fatal("scheduler finished with %llu queued updates", (unsigned long long)S.pending_total);
