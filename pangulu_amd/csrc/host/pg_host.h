@@ -283,6 +283,9 @@ struct Solver
     std::vector<slot_t *> slot_of;         // per non-diagonal block: owned / received slot, nullptr otherwise
     std::vector<slot_t *> diag_lower, diag_upper;
     std::vector<i32> remain;               // per non-diagonal block (reference: nondiag_remain_task_count)
+    // per non-diagonal block: ranks (bit r) that run at least one update with this block as an operand.  A finished block is
+    // forwarded to exactly those ranks (nproc <= 64; empty = the reference's rule: every owner in the process row / column)
+    std::vector<u64> consumers;
     std::vector<i32> remain_diag;          // per level
     std::vector<i32> remain0, remain_diag0; // pristine copies (gstrf may be called once per init, kept for checks)
     i64 rank_remain_task = 0, rank_remain_task0 = 0;

@@ -400,6 +400,8 @@ struct Sched
         u64 ub = P.first_after_diag_csr[level], ue = P.rowptr[level + 1]; // U blocks of block row `level`
         slot_t *u_for_diag = nullptr;
         u64 u = ub;
+        // ranks that run an update with this block (pg_preprocess.cpp, forwarding rule); all ones = the reference's rule
+        const u64 wanted = S.consumers.empty() ? ~0ull : S.consumers[P.csr_to_csc[pos]];
         for (u64 r = pos + 1; r < re; r++)
         {
             u32 bcol = P.colidx[r];
@@ -419,7 +421,7 @@ struct Sched
                     }
                 }
             }
-            else if (do_sends)
+            else if (do_sends && ((wanted >> target) & 1ull))
             {
                 send_once(L, target);
             }
@@ -438,7 +440,7 @@ struct Sched
                     queue_update(brow, brow, level, S.diag_lower[brow], L, u_for_diag, ~0ull);
                 }
             }
-            else if (do_sends)
+            else if (do_sends && ((wanted >> target) & 1ull))
             {
                 send_once(L, target);
             }
@@ -454,6 +456,7 @@ struct Sched
         u64 pos = (u64)(std::lower_bound(P.rowidx.begin() + (i64)cb, P.rowidx.begin() + (i64)ce, level) - P.rowidx.begin());
         u64 lb = P.first_after_diag[level], le = P.colptr[level + 1]; // L blocks of block column `level`
         u64 l = lb;
+        const u64 wanted = S.consumers.empty() ? ~0ull : S.consumers[pos];
         for (u64 c = pos + 1; c < ce; c++)
         {
             u32 brow = P.rowidx[c];
@@ -472,7 +475,7 @@ struct Sched
                     }
                 }
             }
-            else if (do_sends)
+            else if (do_sends && ((wanted >> target) & 1ull))
             {
                 send_once(U, target);
             }
@@ -491,7 +494,7 @@ struct Sched
                     queue_update(bcol, bcol, level, S.diag_lower[bcol], l_for_diag, U, ~0ull);
                 }
             }
-            else if (do_sends)
+            else if (do_sends && ((wanted >> target) & 1ull))
             {
                 send_once(U, target);
             }

@@ -501,6 +501,17 @@ void preprocess(Solver &S, const CscMatrix &A)
     // ---- dependency counters (src/pangulu_preprocessing.c:132-207, 443-556) ---------------------------
     S.remain.assign(nblk, 0);
     S.remain_diag.assign(nbk, 0);
+    // Forwarding rule.  The reference sends a finished L(br,k) to every rank that owns a block of block row br right of
+    // column k, and U(k,bc) down its block column (src/pangulu_numeric.c:452-517,535-600) -- whether or not that rank has an
+    // update that uses it.  Under 2D block-cyclic ownership nearly every such rank does; under the subtree mapping most do
+    // not (the partner operand lives in a sibling subtree, i.e. is structurally absent): two ranks exchanged gigabytes of
+    // blocks nobody read.  Every rank therefore computes, for every block, the set of ranks that really consume it, and both
+    // the sender (pg_numeric.cpp send_to_consumers) and the receive count below follow that set.
+    // PANGULU_AMD_REFERENCE_FORWARDING=1 (or more than 64 ranks) keeps the reference's rule.
+    const bool consumer_rule = S.nproc > 1 && S.nproc <= 64 && !getenv("PANGULU_AMD_REFERENCE_FORWARDING");
+    S.consumers.clear();
+    if (consumer_rule)
+        S.consumers.assign(nblk, 0);
     // every structurally possible update L(a,k) * U(k,b) -> (a,b): a in Lcol(k), b in Lcol(k) (mirror)
     // counted on the destination if I own it, and on each remote operand once per update of mine.
     i64 my_ssssm = 0;
@@ -523,6 +534,20 @@ void preprocess(Solver &S, const CscMatrix &A)
                 {
                     u32 a = P.rowidx[la];
                     bool dst_mine;
+                    if (consumer_rule && (a == b || pos[a] >= 0))
+                    {
+                        const int od = a == b ? S.owner(b, b) : S.owner(a, b);
+                        if (S.owner(a, k) != od)
+                        {
+#pragma omp atomic
+                            S.consumers[la] |= 1ull << od;
+                        }
+                        if (S.owner(k, b) != od)
+                        {
+#pragma omp atomic
+                            S.consumers[ukb] |= 1ull << od;
+                        }
+                    }
                     if (a == b)
                     {
                         dst_mine = S.owner(b, b) == me;
@@ -602,7 +627,8 @@ void preprocess(Solver &S, const CscMatrix &A)
             }
             else
             {
-                bool sent_to_me = (br > bc) ? (last_owned_col[br] > (i64)bc) : (last_owned_row[bc] > (i64)br);
+                bool sent_to_me = consumer_rule ? ((S.consumers[t] >> me) & 1ull) != 0
+                                                : ((br > bc) ? (last_owned_col[br] > (i64)bc) : (last_owned_row[bc] > (i64)br));
                 if (sent_to_me)
                     my_recv++;
             }
@@ -673,7 +699,8 @@ void preprocess(Solver &S, const CscMatrix &A)
                 u32 br = P.rowidx[t];
                 if (S.owner(br, bc) == me)
                     continue;
-                bool sent_to_me = (br > bc) ? (last_owned_col[br] > (i64)bc) : (last_owned_row[bc] > (i64)br);
+                bool sent_to_me = consumer_rule ? ((S.consumers[t] >> me) & 1ull) != 0
+                                                : ((br > bc) ? (last_owned_col[br] > (i64)bc) : (last_owned_row[bc] > (i64)br));
                 if (sent_to_me)
                     need_cnt[classify(P.nnz[t])]++;
             }
