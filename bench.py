@@ -341,7 +341,10 @@ def main():
                 "workload": workload, "n": int(info["n"]), "nnz": int(info["nnz"]), "nb": int(info["nb"]),
                 "ordering": "built-in nested dissection (geometric)" if args.ordering == "nd" else "identity",
                 "symbolic_nnz": int(info["symbolic_nnz"]), "flop": int(info["flop"]),
-                "parallelism": "2D block-cyclic %dx%d" % grid(world) + (" above subtrees of the block elimination tree mapped to single ranks" if world > 1 else ""),
+                "parallelism": ("2D block-cyclic %dx%d" % grid(world)) if world == 1 else
+                               ("subtrees of the block elimination tree mapped to single ranks (proportional mapping); separators above them: %s"
+                                % {"path": "on the rank of their heaviest child", "rank0": "on rank 0",
+                                   "cyclic": "2D block-cyclic %dx%d" % grid(world)}[os.environ.get("PANGULU_AMD_SEPARATOR_MAP", "path")]),
                 # what is really in use: ipc / rccl fall back to host staging on all ranks when their self-test fails
                 "transport": effective_transport,
                 "transport_tried": tried, "comm_nranks": world if world > 1 else 0, "comm_init_s": round(comm_init_s, 2),

@@ -213,15 +213,43 @@ void assign_subtrees(Solver &S)
                 stack.push_back(c);
         }
     }
-    // Experimental (PANGULU_AMD_TOP_COLUMNS_ON_RANK0=K, default 0 = off): the last K block columns -- the top of the tree, a
-    // chain of levels with one or two diagonal blocks each, where a 2D block-cyclic map makes every level several round trips
-    // between ranks -- go to rank 0 with their whole panels.  Trades balance for latency.  On two ranks sharing one GPU (the
-    // only multi-rank configuration the builder can run) it changed nothing: 159-168 vs 163-172 ms.
-    if (const char *tk = getenv("PANGULU_AMD_TOP_COLUMNS_ON_RANK0"))
+    // The separators above the mapped subtrees (PANGULU_AMD_SEPARATOR_MAP).  Left 2D block-cyclic ("cyclic", the reference's
+    // rule and round 1's choice) every level of a separator costs several dependent hops between ranks -- diagonal block to the
+    // panel owners, panels to the update owners, updated diagonal back -- about 1.4 ms per level on two ranks for kernels
+    // that take 0.3 ms: 152 ms per factorisation of the bench matrix on two ranks sharing a GPU against 44 on one.
+    //   "path" (default): a separator goes, with its whole panels, to the rank that owns its heaviest child -- proportional
+    //   mapping carried up the tree.  Each child subtree hands its border panels over once; inside a separator nothing hops.
+    //   The chain of separators along the heaviest path ends on one rank: for tall-skinny trees (2D-like problems, where the
+    //   subtrees hold the work and the top is a latency chain) that is what one wants; a 3D problem whose top separator holds
+    //   most of the flops would rather split that separator's updates ("cyclic").
+    //   "rank0": all of them on rank 0 (97 ms in the same two-rank run; "path" measured below).
     {
-        const long K = atol(tk);
-        for (u32 k = nbk; k-- > 0 && (long)(nbk - k) <= K;)
-            S.home[k] = 0;
+        const char *sm = getenv("PANGULU_AMD_SEPARATOR_MAP");
+        const std::string mode = sm ? sm : "path";
+        if (mode == "rank0")
+        {
+            for (u32 k = 0; k < nbk; k++)
+                if (S.home[k] < 0)
+                    S.home[k] = 0;
+        }
+        else if (mode == "path")
+        {
+            for (u32 k = 0; k < nbk; k++) // (children have smaller indices: they are placed by the time k is)
+                if (S.home[k] < 0)
+                {
+                    int best = -1;
+                    double w = -1;
+                    for (u32 c : kids[k])
+                        if (S.home[c] >= 0 && sub[c] > w)
+                        {
+                            w = sub[c];
+                            best = S.home[c];
+                        }
+                    S.home[k] = best >= 0 ? best : 0;
+                }
+        }
+        else if (mode != "cyclic")
+            fatal("PANGULU_AMD_SEPARATOR_MAP must be path, cyclic or rank0");
     }
     if (S.rank == 0 && getenv("PANGULU_AMD_TRACE"))
     {

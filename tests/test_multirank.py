@@ -26,13 +26,16 @@ def free_port():
     return p
 
 
-def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transport="host", repeat=False):
+def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transport="host", repeat=False, separators="cyclic"):
+    """`separators`: PANGULU_AMD_SEPARATOR_MAP of the run.  The product's default is "path" (a separator follows its heaviest
+    child: on the small test matrices that often leaves nothing to exchange); the transport tests use the reference's 2D
+    block-cyclic separators, test_separator_maps covers the others."""
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1", PANGULU_TEST_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   PANGULU_TEST_REPEAT="1" if repeat else "0")
+                   PANGULU_TEST_REPEAT="1" if repeat else "0", PANGULU_AMD_SEPARATOR_MAP=separators)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), spec, str(nb), out_path, vtype, platform],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -77,6 +80,26 @@ def test_multirank_matches_single_rank(tmp_path, world, spec, nb):
         assert float(z["residual"]) < 4e-16  # the reference printed 1.4e-16 at 2 and 4 ranks, nb=4
 
 
+@pytest.mark.parametrize("separators", ["path", "rank0"])
+@pytest.mark.parametrize("world,spec,nb", [(2, "shell_20x16", 24), (4, "shell_40x40", 32), (3, "fem27_9", 16), (4, "kkt6", 16)])
+def test_separator_maps(tmp_path, world, spec, nb, separators):
+    """The separators above the mapped subtrees on the rank of their heaviest child (the default) / all on rank 0: same factors
+    as one rank, bytes sent = bytes received, every update ran somewhere."""
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, separators=separators)
+    z = np.load(out)
+    mat = GENS[spec]()
+    n = len(z["L_ptr"]) - 1
+    ref = factorize(mat, nb, oracle_library("r64"))
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
+    assert int(z["flop"]) == ref["info"]["flop"]
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
+    assert float(z["residual"]) < 1e-12
+    assert sum(z["sent"]) == sum(z["recv"])
+    assert sum(z["tasks"]) == ref["info"]["ntask_ssssm"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (4, "poisson8", 32), (3, "shell_8x7", 24)])
 def test_multirank_on_the_gpu_host_staged(tmp_path, world, spec, nb):
@@ -92,6 +115,25 @@ def test_multirank_on_the_gpu_host_staged(tmp_path, world, spec, nb):
     U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
     assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
     assert float(z["residual"]) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("separators", ["path", "rank0"])
+@pytest.mark.parametrize("world,spec,nb", [(2, "shell_40x40", 128), (4, "shell_40x40", 256), (3, "fem27_9", 128)])
+def test_separator_maps_on_the_gpu(tmp_path, world, spec, nb, separators):
+    """The default separator mapping (and "rank0") with the HIP back-end and the peer-copy transport, dense paths engaged."""
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, platform="hip", transport="ipc", separators=separators)
+    z = np.load(out)
+    mat = GENS[spec]()
+    n = len(z["L_ptr"]) - 1
+    ref = factorize(mat, nb, oracle_library("r64"), ordering="nd")
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
+    assert float(z["residual"]) < 1e-12
+    assert sum(z["sent"]) == sum(z["recv"])
+    assert sum(z["tasks"]) == ref["info"]["ntask_ssssm"]
 
 
 @pytest.mark.gpu
