@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- numeric factorisation GFLOP/s (pangulu_gstrf, R64) on N MI355X, one process per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+With --gpus N > 1 and no RANK in the environment this process starts N rank processes itself -- fresh children of
+`python -m torch.distributed.run`, created before anything here has touched a GPU -- relays rank 0's JSON line and exits
+non-zero if any rank did.  Started by a launcher (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) it is one rank:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -9,18 +13,26 @@ A "step" is one complete pangulu_gstrf of the workload matrix.  Between steps th
 device-side snapshot (pangulu_amd_reset_numeric, un-timed), so every timed step starts with its inputs resident in
 HBM; each step is bracketed by a barrier + device synchronise on both sides and the slowest rank's time counts.
 value = F / t with F = sum_k (c_k + 2 c_k^2) the reference's structural flop count (src/pangulu_kernel_interface.c:4-176,
-computed once from the symbolic pattern outside the timed region).
+computed once from the symbolic pattern outside the timed region).  The SAME matrix at every N: strong scaling.
 
-Workload (BASELINE.json configs[1]): "SuiteSparse ldoor (n=952K, nnz=42M) R64, nb=256".  ldoor is not in the image and
-there is no network, so unless --mtx points at a MatrixMarket file the run uses the deterministic stand-in
-pangulu_amd.matrices.shell(398, 398): a two-layer structural shell with 3 unknowns per node, n = 950 424,
-~50 M entries, diagonally dominant -- the same class (thin-walled structure, ~45-55 entries per row) and size.
+Workload: BASELINE.json's north-star matrix is SuiteSparse Serena (n = 1.39 M, nnz = 64 M; R64, nb = 256).  It is not in
+the image and there is no network, so unless --mtx points at a MatrixMarket / .lid file the run uses the deterministic
+Serena-class stand-in pangulu_amd.matrices.fem27(112): a 27-point (trilinear FEM) stencil on a 112^3 grid, n = 1 404 928,
+37.3 M entries, diagonally dominant -- the same class (3D solid, dense top separators) and size.  `--workload shell` is the
+ldoor-class stand-in of BASELINE configs[1] (shell(398,398), n = 950 424), the default of rounds 1-2.
 Ordering: built-in geometric nested dissection (stated in the JSON line; F depends on it).
+
+The line's residual and factor_check (the reference's two criteria, examples/example.c:304-364 and
+src/pangulu_numeric.c:1082-1341) are taken from the factors of the LAST TIMED step, in the timed configuration; kernel
+times come from one extra, un-timed factorisation with every launch on one stream between two events (no queueing).
+cpu_baseline legs (the oracle = CPU restatement of the reference's CPU platform, sampled) run in child processes after
+the GPU steps, so nothing they do can take the GPU result with it.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,15 +43,17 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (v_mfma_f64_16x16x4: 64 cycles per 2048 flop per SIMD)
+XGMI_LINK_GBS = 153.0     # one xGMI link per GPU pair
+CPU_GFLOPS_GUESS = 8.0    # one core of the oracle with OpenBLAS inside SSSSM, for sizing the sample only
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="shell", choices=["shell", "fem27", "poisson", "kkt"])
-    ap.add_argument("--size", type=int, nargs="*", default=None, help="generator size arguments (shell: nx ny)")
+    ap.add_argument("--workload", default="fem27", choices=["shell", "fem27", "poisson", "kkt"])
+    ap.add_argument("--size", type=int, nargs="*", default=None, help="generator size arguments (fem27: n [ny nz]; shell: nx ny)")
     ap.add_argument("--mtx", default=None, help="matrix file to factorise instead of the synthetic stand-in: MatrixMarket (.mtx) or the "
                                                 "reference's binary .lid (examples/example.c:112-163)")
     ap.add_argument("--rhs", default=None, help="right-hand side file (examples/example.c:167-243); default b = A*1")
@@ -48,32 +62,47 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
-    ap.add_argument("--cpu-sample-stride", type=int, default=6,
-                    help="CPU baseline: execute every k-th task of each kernel class of the SAME factorisation (about 15 s of one core at 6)")
+    ap.add_argument("--cpu-sample-stride", type=int, default=0,
+                    help="CPU baseline: execute every k-th task of each kernel class of the SAME factorisation (0: sized for about "
+                         "12 s of one core from the structural flop count)")
+    ap.add_argument("--cpu-leg-timeout", type=int, default=900, help="seconds a cpu_baseline child may take before it is given up")
     ap.add_argument("--transport", default=os.environ.get("PANGULU_AMD_TRANSPORT", "auto"), choices=["auto", "host", "rccl", "ipc"],
                     help="block exchange for --gpus > 1: auto = rccl (ncclSend/ncclRecv per ordered pair over xGMI), else ipc (the "
                          "consumer pulls each record out of the owner's HBM arena with one peer copy), else host-staged TCP: each is "
                          "verified by a self-test at start-up and all ranks fall back together; the line says what ran")
-    return ap.parse_args()
+    # internal: one rank of a cpu_baseline leg (started by run_cpu_leg below)
+    ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-leg-port", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-leg-stride", type=int, default=1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def default_sizes(args):
+    if args.size:
+        return list(args.size)
+    return {"shell": [398, 398], "fem27": [112], "poisson": [64], "kkt": [40]}[args.workload]
 
 
 def make_matrix(args, M):
     if args.mtx:
         n, cp, ri, va, co = M.read_matrix(args.mtx)
         return (n, cp, ri, va, co), "file:%s" % os.path.basename(args.mtx)
-    size = args.size
+    size = default_sizes(args)
     if args.workload == "shell":
-        nx, ny = (size + [None, None])[:2] if size else (398, 398)
+        nx, ny = (size + [None])[:2]
         ny = ny or nx
         return M.shell(nx, ny), "ldoor-class stand-in: shell(%d,%d) 2 layers x 3 dofs" % (nx, ny)
     if args.workload == "fem27":
-        s = size or [64]
-        return M.fem27(*s), "Serena-class stand-in: fem27(%s)" % ",".join(map(str, s))
+        return M.fem27(*size), "Serena-class stand-in: fem27(%s)" % ",".join(map(str, size))
     if args.workload == "poisson":
-        s = size or [64]
-        return M.poisson3d(*s), "poisson3d(%s)" % ",".join(map(str, s))
-    s = size or [40]
-    return M.kkt(s[0]), "nlpkkt-class stand-in: kkt(%d)" % s[0]
+        return M.poisson3d(*size), "poisson3d(%s)" % ",".join(map(str, size))
+    return M.kkt(size[0]), "nlpkkt-class stand-in: kkt(%d)" % size[0]
+
+
+def workload_key(args):
+    if args.mtx:
+        return "file:%s" % os.path.basename(args.mtx)
+    return "%s(%s) nb=%d %s" % (args.workload, ",".join(map(str, default_sizes(args))), args.nb, args.ordering)
 
 
 def kernel_source_hash():
@@ -96,6 +125,16 @@ def grid(world):
     return p, world // p
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def find_openblas():
     """The CPU baseline's SSSSM uses OpenBLAS dgemm like the reference (…0100000.c:317-327) when scipy's bundled
     library is present; otherwise the oracle's own triple loop."""
@@ -111,52 +150,176 @@ def find_openblas():
     return None
 
 
-def cpu_baseline(args, pa, M, mat, workload):
-    """Oracle (CPU restatement of the reference's CPU platform, OpenBLAS dgemm inside SSSSM like the reference) timed on one
-    host core on a bounded sample of the SAME factorisation: same matrix, ordering and nb; every k-th task of each kernel
-    class is executed (in the scheduler's order), the others are only released.  A kernel's time depends on the patterns
-    of its operands, not on their values, so the sample is a 1/k cut through all levels of the elimination tree.
-    value = structural flops of the executed tasks / their time.  Reported beside the GPU number; not a target."""
+def free_port(lo=20000, hi=28000):
+    """A port in a range the solver's own listeners (base + rank, + 64 per transport attempt) can share, free right now."""
+    import random
+    import socket
+
+    rng = random.Random(os.getpid() * 7919 + int(time.time()))
+    for _ in range(200):
+        p = rng.randrange(lo, hi, 1024 // 4)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", p))
+            return p
+        except OSError:
+            continue
+        finally:
+            s.close()
+    return lo + 1234
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: N fresh rank processes before this process has made any GPU call
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    port = free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line:
+        print(line, flush=True)
+    if rc != 0:
+        return rc
+    return 0 if line else 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cpu_baseline: the oracle on a bounded sample of the SAME factorisation, in child processes
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_leg_main(args):
+    """One rank of a cpu_baseline leg (child process; never touches the GPU): the checker's build of the host routed to the
+    oracle's CPU operators (oracle/pangulu_oracle.c, OpenBLAS dgemm inside SSSSM like the reference), `--cpu-leg` ranks x 1
+    compute thread over the host-staged transport (the reference example's configuration, examples/example.c:284).  Every
+    k-th task of each kernel class is executed in the scheduler's order, the others are only released: a kernel's time
+    depends on the patterns of its operands, not on their values, so the sample is a 1/k cut through all levels of the
+    elimination tree.  Rank 0 prints one JSON object."""
+    import pangulu_amd as pa
+    from pangulu_amd import _lib
+    from pangulu_amd import matrices as M
     from tests.helpers import library_for, oracle_library
 
+    R = args.cpu_leg
+    rank = int(os.environ.get("PG_CPU_LEG_RANK", "0"))
     blas = find_openblas()
     if blas:
         os.environ["PANGULU_ORACLE_BLAS"] = blas
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-    n, cp, ri, va, co = mat
+    os.environ.setdefault("PANGULU_AMD_RECV_BUDGET_GB", "16")  # receive bins are host memory here
     tlib = library_for(oracle_library("r64"))  # the checker's build of the host, routed to the CPU restatement
     tlib.pangulu_amd_test_set_task_sampling.argtypes = [ctypes.c_int]
-    stride = max(1, args.cpu_sample_stride)
+    if R > 1:
+        assert tlib.pangulu_amd_comm_init(rank, R, b"127.0.0.1", args.cpu_leg_port, _lib.TRANSPORT_HOST, None) == 0
+    if rank == 0:
+        mat, workload = make_matrix(args, M)
+        n, cp, ri, va, co = mat
+    else:
+        n, cp, ri, va, co, workload = 0, None, None, None, None, ""
+    stride = max(1, args.cpu_leg_stride)
     tlib.pangulu_amd_test_set_task_sampling(stride)
-    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=args.nb, ordering=args.ordering, coords=co if args.ordering == "nd" else None,
-                        nthread=max(1, os.cpu_count() or 1), lib=tlib)
+    nthreads = max(1, (os.cpu_count() or 1) // R)
+    h = pa.pangulu_init(n, len(va) if va is not None else 0, cp, ri, va, nb=args.nb, ordering=args.ordering,
+                        coords=co if args.ordering == "nd" else None, nthread=nthreads, lib=tlib)
     t0 = time.time()
     pa.pangulu_gstrf(h)
     dt = time.time() - t0
     info = h.info()
-    pa.pangulu_finalize(h)
-    tlib.pangulu_amd_test_set_task_sampling(1)
+    # sums / maxima over the ranks through the library's own reductions
+    v = np.array([dt, info["time_numeric_platform"]], dtype=np.float64)
+    if R > 1:
+        tlib.pangulu_amd_comm_allreduce_max_f64(v.ctypes.data_as(ctypes.c_void_p), 2)
+    fl = np.array([info["sampled_flop"] if stride > 1 else 0.0, float(info["sampled_tasks"])], dtype=np.float64)
     ntask = info["ntask_getrf"] + info["ntask_tstrf"] + info["ntask_gessm"] + info["ntask_ssssm"]
-    fsample = info["sampled_flop"] if stride > 1 else float(info["flop"])
+    tot = np.array([float(ntask)], dtype=np.float64)
+    if R > 1:
+        # (no sum reduction in the C API: gather through max of one-hot slots)
+        slots = np.zeros(3 * R, dtype=np.float64)
+        slots[3 * rank:3 * rank + 3] = [fl[0], fl[1], tot[0]]
+        tlib.pangulu_amd_comm_allreduce_max_f64(slots.ctypes.data_as(ctypes.c_void_p), 3 * R)
+        fl = np.array([slots[0::3].sum(), slots[1::3].sum()])
+        tot = np.array([slots[2::3].sum()])
+    pa.pangulu_finalize(h)
+    if R > 1:
+        tlib.pangulu_amd_comm_finalize()
+    if rank == 0:
+        fsample = fl[0] if stride > 1 else float(info["flop"])
+        print(json.dumps({"cpu_leg": R, "stride": stride, "wall_s": float(v[0]), "platform_s": float(v[1]), "sampled_flop": fsample,
+                          "sampled_tasks": int(fl[1]) if stride > 1 else int(tot[0]), "tasks": int(tot[0]), "flop": float(info["flop"]),
+                          "blas": "OpenBLAS (scipy bundle)" if blas else "oracle triple loop", "workload": workload}), flush=True)
+
+
+def run_cpu_leg(args, R, rank, port, stride):
+    """Start this rank's child of an R-rank cpu_baseline leg; returns the Popen (rank 0's stdout carries the result)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(R), "--cpu-leg-port", str(port), "--cpu-leg-stride", str(stride),
+           "--workload", args.workload, "--nb", str(args.nb), "--ordering", args.ordering]
+    if args.size:
+        cmd += ["--size"] + [str(s) for s in args.size]
+    if args.mtx:
+        cmd += ["--mtx", args.mtx]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PANGULU_AMD_HOST_THREADS")}
+    env["PG_CPU_LEG_RANK"] = str(rank)
+    env["HIP_VISIBLE_DEVICES"] = ""  # the child is CPU only
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+
+
+def finish_cpu_leg(proc, timeout, want_result):
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": "cpu_baseline child exceeded %d s" % timeout}
+    if proc.returncode != 0:
+        return {"error": "cpu_baseline child failed (%d): %s" % (proc.returncode, (err or "")[-300:])}
+    if not want_result:
+        return None
+    for ln in reversed(out.strip().splitlines()):
+        if ln.startswith('{"cpu_leg"'):
+            return json.loads(ln)
+    return {"error": "cpu_baseline child printed no result"}
+
+
+def leg_summary(res, cores, workload):
+    """value = structural flops of the executed tasks / the time spent inside the platform calls that ran them (max over the
+    ranks); the wall time of the sampled run -- scheduling and release of the skipped tasks and, for R > 1, the exchange of
+    ALL blocks included -- is stated beside it."""
+    if res is None or "error" in res:
+        return {"value": None, "unit": "GFLOP/s", "cores": cores, "kind": "port", "sample": (res or {}).get("error", "not run")}
+    k = res["stride"]
     return {
-        "value": fsample / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
-        "sample": "same matrix, ordering and nb as the GPU line (%s): every %d%s task of each kernel class, %d of %d tasks, "
-                  "%.3e of %.3e structural flops, %.1f s; 1 rank x 1 compute thread (= R x 1 at R = 1 GPU), SSSSM GEMM: %s" % (
-                      workload, stride, "th" if stride > 3 else ("st", "nd", "rd")[stride - 1] if stride <= 3 else "th",
-                      info["sampled_tasks"] if stride > 1 else ntask, ntask, fsample, float(info["flop"]), dt,
-                      "OpenBLAS (scipy bundle)" if blas else "oracle triple loop"),
+        "value": res["sampled_flop"] / max(res["platform_s"], 1e-9) / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+        "wall_value": res["sampled_flop"] / max(res["wall_s"], 1e-9) / 1e9,
+        "sample": "same matrix, ordering and nb as the GPU line (%s): every %d%s task of each kernel class, %d of %d tasks, %.3e of %.3e "
+                  "structural flops; %d rank(s) x 1 compute thread (examples/example.c:284), host-staged exchange; time base = seconds "
+                  "inside the operator calls of the executed tasks, max over ranks (%.1f s; whole sampled run incl. release of the "
+                  "skipped tasks%s: %.1f s); SSSSM GEMM: %s" % (
+                      workload, k, "th" if k > 3 else ("st", "nd", "rd")[k - 1], res["sampled_tasks"], res["tasks"], res["sampled_flop"],
+                      res["flop"], cores, res["platform_s"], " and exchange of all blocks" if cores > 1 else "", res["wall_s"], res["blas"]),
     }
 
 
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    if args.cpu_leg:
+        return cpu_leg_main(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus and "RANK" in os.environ:
         args.gpus = world
-    if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one process per GPU)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # completion signals by polling instead of interrupts (must be set before the runtime starts): the scheduler and launcher
     # threads wait on hundreds of short events per factorisation; measured 44.2 ms (all 40 steps within 43.8-44.8) against
@@ -172,22 +335,23 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the numeric factorisation has no CPU fallback")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
     lib = _lib.load("r64")
     nthreads = args.host_threads or max(1, (os.cpu_count() or 1) // max(1, world))
     os.environ["PANGULU_AMD_HOST_THREADS"] = str(nthreads)
 
+    tried, comm_init_s, base_port = [], 0.0, 0
     if world > 1:
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         base_port = int(os.environ.get("MASTER_PORT", "29500")) + 23
-        if base_port + world >= 32768:  # keep the solver's listeners (base_port + rank) out of the ephemeral port range
+        if base_port + 1024 >= 32768:  # keep the solver's listeners (base_port + rank, + 64 per attempt) out of the ephemeral port range
             base_port = 20000 + (base_port * 7) % 8000
         # auto: rccl first (north star: MPI point-to-point -> RCCL send/recv over xGMI); it self-tests on every pair and all
         # ranks agree on the outcome; if it is not there the same ranks try peer copies, then host staging
         order = {"auto": ["rccl", "ipc", "host"], "rccl": ["rccl"], "ipc": ["ipc"], "host": ["host"]}[args.transport]
         codes = {"host": _lib.TRANSPORT_HOST, "rccl": _lib.TRANSPORT_RCCL, "ipc": _lib.TRANSPORT_IPC}
         t_comm = time.time()
-        tried = []
         for k, name in enumerate(order):
             rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port + 64 * k, codes[name], None)
             assert rc == 0
@@ -198,19 +362,18 @@ def main():
             lib.pangulu_amd_comm_finalize()  # (all ranks saw the same fall-back: they all move on to the next one)
         comm_init_s = time.time() - t_comm
 
-    if world == 1:
-        tried, comm_init_s = [], 0.0
     if rank == 0:
         mat, workload = make_matrix(args, M)
         n, cp, ri, va, coords = mat
     else:
-        n, cp, ri, va, coords, workload = 0, None, None, None, None, ""
+        mat, n, cp, ri, va, coords, workload = None, 0, None, None, None, None, ""
     t0 = time.time()
     h = pa.pangulu_init(n, len(va) if va is not None else 0, cp, ri, va, nb=args.nb, ordering=args.ordering,
                         coords=coords if args.ordering == "nd" else None, nthread=nthreads)
     t_init = time.time() - t0
     # what is really in use: ipc / rccl fall back to host staging on all ranks together when their self-test fails
     effective_transport = {0: "host", 1: "rccl", 2: "ipc"}[lib.pangulu_amd_comm_transport()] if world > 1 else "none"
+    rccl_nranks = int(lib.pangulu_amd_comm_rccl_ranks()) if world > 1 else 0
     assert lib.pangulu_amd_snapshot(h.ref) == 0
     info0 = h.info()
     flop = float(info0["flop"])
@@ -225,7 +388,8 @@ def main():
         return time.perf_counter() - t
 
     # structural flop counting of MFMA-path updates costs an extra pass per task: off in the timed steps (F comes from
-    # the symbolic pattern), on in the profile pass below
+    # the symbolic pattern), on in the profile pass below.  tests/test_gpu_env_switches.py runs the parity cases in this
+    # configuration too, and the line's residual / factor_check come from the last TIMED step.
     lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 0)
     for _ in range(args.warmup):
         one_step()
@@ -234,7 +398,7 @@ def main():
     times = []
     for s in range(args.steps):
         times.append(one_step())
-        if s + 1 < args.steps or not args.no_profile_pass:
+        if s + 1 < args.steps:
             lib.pangulu_amd_reset_numeric(h.ref)
     # max over ranks of the summed step time
     tsum = np.array([sum(times)], dtype=np.float64)
@@ -244,17 +408,34 @@ def main():
     info = h.info()
     used = ctypes.c_size_t(0)
     lib.pangulu_platform_0201001_get_device_memory_usage(ctypes.byref(used))  # records + receive bins + mirror pool + snapshot
-    stats_timed = pa.hip_stats(lib, reset=True)
 
-    default_workload = (not args.mtx and args.workload == "shell" and not args.size and args.nb == 256 and args.ordering == "nd")
-    # one extra, un-timed factorisation with per-launch hipEvents to attribute time to kernels
+    # the two correctness criteria of the reference on the factors the last timed step left on the device(s)
+    factor_check = pa.factor_check(h) if args.steps > 0 else None   # ||L(U 1) - A 1|| / ||A 1||  (src/pangulu_numeric.c:1082-1341)
+    residual = None
+    if args.steps > 0:
+        if rank == 0:
+            b = M.read_rhs(args.rhs, n) if args.rhs else M.rhs_of_ones(n, cp, ri, va)
+        else:
+            b = None
+        x = pa.pangulu_gstrs(h, b)                                  # ||Ax - b|| / ||b||, b = A*1 (examples/example.c:252-264,304-364)
+        if rank == 0:
+            residual = M.relative_residual(n, cp, ri, va, x, b)
+    pa.hip_stats(lib, reset=True)
+
+    # one extra, un-timed factorisation with per-launch hipEvents to attribute time to kernels: every launch on the ONE main
+    # stream (side streams and the records stream off), so that an event pair brackets its kernel and nothing else
     roofline = None
     kernels = {}
-    if not args.no_profile_pass:
+    if not args.no_profile_pass and args.steps > 0:
+        lib.pangulu_amd_reset_numeric(h.ref)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_PROFILE, 1)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 1)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_TWO_STREAMS, 0)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_RECORDS_STREAM, 0)
         one_step()
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_PROFILE, 0)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_TWO_STREAMS, 1)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_RECORDS_STREAM, 1)
         st = pa.hip_stats(lib, reset=True)
         for name, v in st.items():
             if v["launches"]:
@@ -266,7 +447,7 @@ def main():
                 if name == "ssssm_dense_mfma":
                     kernels[name]["GFLOP_executed"] = round(v["mfma_flops_executed"] / 1e9, 2)
         task_classes = ("getrf", "tstrf", "gessm", "ssssm_sparse", "ssssm_dense_mfma")
-        if kernels:
+        if any(k in kernels for k in task_classes):
             # the dominant kernel among the task classes (mirror maintenance -- densify, sparsify, remote LU images -- is listed
             # in `kernels` and counted in the denominator of share_of_kernel_time, but has no algorithmic bytes or flops)
             dom = max((k for k in kernels if k in task_classes), key=lambda k: kernels[k]["ms"])
@@ -283,55 +464,75 @@ def main():
                 ach = v["alg_bytes"] / sec / 1e9
                 roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roofline["this_rank_only"] = world > 1
             # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process, so the value comes
             # from a committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass (tools/profile_recipe.sh; FETCH_SIZE doubled as
-            # MI355X_MICROARCH.md prescribes for gfx950) -- but ONLY if that pass profiled this build's kernels: the file
-            # records a hash of the kernel sources, anything else leaves `traffic` null
+            # MI355X_MICROARCH.md prescribes for gfx950) -- but ONLY if that pass profiled this build's kernels on this
+            # workload: the file records the workload and a hash of the kernel sources, anything else leaves `traffic` null
             rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_tiled_f64_kernel",
                             "tstrf": "trsm_dense_direct_f64_kernel<16>", "gessm": "trsm_dense_direct_f64_kernel<16>",
                             "ssssm_sparse": "ssssm_sparse_kernel<false>"}.get(dom)
-            tfile = os.path.join(ROOT, "profiles", "hbm_traffic_default_workload.json")
-            if world == 1 and default_workload and rocprof_name and os.path.exists(tfile):
-                tj = json.load(open(tfile))
-                if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get(rocprof_name):
+            tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if world == 1 and rocprof_name and os.path.exists(tfile):
+                tj = json.load(open(tfile)).get(workload_key(args))
+                if tj and tj.get("kernel_source_hash") == kernel_source_hash() and tj.get(rocprof_name):
                     roofline["traffic"] = tj[rocprof_name]["hbm_bytes_per_launch"]
-                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass of this build, %s)" % tj.get("profile", "profiles/")
+                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass of this build on this workload, %s)" % tj.get("profile", "profiles/")
                 else:
-                    roofline["traffic_note"] = "no PMC pass of this build committed (kernel sources changed since %s)" % tj.get("profile", "the last one")
+                    roofline["traffic_note"] = "no PMC pass of this build on this workload committed (profiles/hbm_traffic.json)"
             roofline["avg_launch_us"] = kernels[dom]["avg_launch_us"]
             roofline["share_of_kernel_time"] = kernels[dom]["ms"] / sum(k["ms"] for k in kernels.values())
-            # whole-factorisation bound of SURVEY.md §8d: T* = sum over tasks of max(bytes_t / 8 TB/s, flop_t / 78.6 TF), from the
-            # task list's structure alone (pg_model.cpp); single-rank handles
-            if world == 1:
-                lib.pangulu_amd_model_roofline(h.ref, HBM_PEAK_GBS, FP64_PEAK_TFLOPS)
-                mi = h.info()
-                t_star = mi["model_tmin_hbm_bound"] + mi["model_tmin_fp_bound"]
-                roofline["model_T_star_ms"] = 1e3 * t_star
-                roofline["model_T_star_over_t_gstrf"] = 1e3 * t_star / ms_per_step
-                roofline["model_split_ms"] = {"hbm_bound_tasks": 1e3 * mi["model_tmin_hbm_bound"], "mfma_bound_tasks": 1e3 * mi["model_tmin_fp_bound"]}
-                roofline["model_alg_GB"] = mi["model_bytes_total"] / 1e9
+            roofline["kernel_times"] = "hipEvent pairs around each launch with every launch on one stream (no queueing inside a pair)"
+    # Whole-factorisation bound of SURVEY.md §8d for THIS rank count: T*_r = sum over the tasks rank r runs of max(bytes_t / 8 TB/s,
+    # flop_t / 78.6 TF), from the symbolic pattern alone (pg_model.cpp, evaluated by every rank at init); T*(N) = max_r (T*_r +
+    # bytes rank r sends to its busiest peer / 153 GB/s).  At N = 1 this is round 2's model_T_star.
+    model = {
+        "T_star_ms": 1e3 * info0["model_ranks_tstar_max"], "T_star_over_t_gstrf": 1e3 * info0["model_ranks_tstar_max"] / ms_per_step if ms_per_step else None,
+        "sum_over_ranks_ms": 1e3 * info0["model_ranks_tstar_sum"],
+        "split_ms": {"hbm_bound_tasks": 1e3 * info0["model_ranks_tstar_hbm"], "mfma_bound_tasks": 1e3 * info0["model_ranks_tstar_fp"]},
+        "alg_GB": info0["model_ranks_bytes_total"] / 1e9,
+        "rank_flop_share_max_over_mean": info0["model_rank_flop_share"], "rank_T_star_share_max_over_mean": info0["model_rank_time_share"],
+        "link_term_ms_max": 1e3 * info0["model_comm_seconds_max"], "sent_GB": info0["model_sent_bytes_total"] / 1e9,
+        "critical_path_ms": 1e3 * info0["model_critical_path"], "critical_path_tasks": int(info0["model_critical_path_tasks"]),
+        "peaks": {"hbm_GBs": HBM_PEAK_GBS, "fp64_TFLOPs": FP64_PEAK_TFLOPS, "xgmi_link_GBs": XGMI_LINK_GBS},
+    }
+    if roofline is not None:
+        roofline["model_T_star_ms"] = model["T_star_ms"]
+        roofline["model_T_star_over_t_gstrf"] = model["T_star_over_t_gstrf"]
+        roofline["model_split_ms"] = model["split_ms"]
+        roofline["model_alg_GB"] = model["alg_GB"]
 
-    # end-to-end check of the last factorisation: ||Ax-b||/||b|| with b = A*1 (examples/example.c:252-264,304-364)
-    residual = None
-    if rank == 0:
-        b = M.read_rhs(args.rhs, n) if args.rhs else M.rhs_of_ones(n, cp, ri, va)
-    else:
-        b = None
-    x = pa.pangulu_gstrs(h, b)
-    if rank == 0:
-        residual = M.relative_residual(n, cp, ri, va, x, b)
     pa.pangulu_finalize(h)
     if world > 1:
+        lib.pangulu_amd_comm_barrier()
         lib.pangulu_amd_comm_finalize()
 
-    # the CPU baseline runs LAST: measured before the GPU steps it left them 15 % slower (72 instead of 61 ms per step
-    # after ten seconds of host-only work with the device idle, whatever the warm-up count; cause not isolated)
+    # cpu_baseline LAST, in child processes (measured before the GPU steps, ten seconds of host-only work left them 15 %
+    # slower).  N = 1: one rank x one thread.  N > 1: R = N ranks x one thread (every rank starts its own child; SURVEY §8d,
+    # examples/example.c:284) and then 1 x 1 on rank 0.
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, pa, M, mat, workload)
+    if not args.no_cpu_baseline:
+        stride = args.cpu_sample_stride or max(1, int(round(flop / (CPU_GFLOPS_GUESS * 1e9 * 12.0))))
+        legs = {}
+        if world > 1:
+            p = run_cpu_leg(args, world, rank, base_port + 512, stride)
+            res = finish_cpu_leg(p, args.cpu_leg_timeout, rank == 0)
+            if rank == 0:
+                legs["ranks_x_1"] = leg_summary(res, world, workload)
+        if rank == 0:
+            p = run_cpu_leg(args, 1, 0, 0, stride)
+            legs["1_x_1"] = leg_summary(finish_cpu_leg(p, args.cpu_leg_timeout, True), 1, workload)
+            # the contract's object = the leg with as many ranks as GPUs; the other one beside it
+            main_leg = legs.get("ranks_x_1") or legs["1_x_1"]
+            cpu = dict(main_leg)
+            cpu["cpu_model"] = cpu_model_name()
+            cpu["host_cores"] = os.cpu_count()
+            if world > 1:
+                cpu["one_rank_x_one_thread"] = legs["1_x_1"]
 
     if rank == 0:
-        value = flop / (ms_per_step / 1e3) / 1e9
+        value = flop / (ms_per_step / 1e3) / 1e9 if ms_per_step else 0.0
+        sep_map = os.environ.get("PANGULU_AMD_SEPARATOR_MAP", "group")
         line = {
             "metric": "numeric factorisation GFLOP/s (pangulu_gstrf, R64)",
             "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -341,23 +542,29 @@ def main():
                 "workload": workload, "n": int(info["n"]), "nnz": int(info["nnz"]), "nb": int(info["nb"]),
                 "ordering": "built-in nested dissection (geometric)" if args.ordering == "nd" else "identity",
                 "symbolic_nnz": int(info["symbolic_nnz"]), "flop": int(info["flop"]),
-                "parallelism": ("2D block-cyclic %dx%d" % grid(world)) if world == 1 else
-                               ("subtrees of the block elimination tree mapped to single ranks (proportional mapping); separators above them: %s"
-                                % {"path": "on the rank of their heaviest child", "rank0": "on rank 0",
-                                   "cyclic": "2D block-cyclic %dx%d" % grid(world)}[os.environ.get("PANGULU_AMD_SEPARATOR_MAP", "path")]),
+                "parallelism": ("one rank") if world == 1 else
+                               {"group": "proportional mapping of the block elimination tree with rank groups that shrink down the tree: subtrees whose group "
+                                         "is one rank live on it whole, heavy separators 2D block-cyclic over their group's p x q grid (all %d ranks: %dx%d), "
+                                         "light ones on the least loaded rank of their group" % ((world,) + grid(world)),
+                                "path": "subtrees on single ranks; separators on the rank of their heaviest child", "rank0": "subtrees on single ranks; separators on rank 0",
+                                "cyclic": "subtrees on single ranks; separators 2D block-cyclic %dx%d" % grid(world)}.get(sep_map, sep_map),
                 # what is really in use: ipc / rccl fall back to host staging on all ranks when their self-test fails
-                "transport": effective_transport,
-                "transport_tried": tried, "comm_nranks": world if world > 1 else 0, "comm_init_s": round(comm_init_s, 2),
+                "transport": effective_transport, "transport_tried": tried,
+                "rccl_nranks": rccl_nranks,   # ranks whose RCCL communicators passed the start-up self-test (from the library)
+                "visible_gpus": ndev, "comm_init_s": round(comm_init_s, 2),
                 "blocks": int(info["nblocks_nondiag"]),
-                "tasks": {"getrf": int(info["ntask_getrf"]), "tstrf": int(info["ntask_tstrf"]), "gessm": int(info["ntask_gessm"]),
-                          "ssssm": int(info["ntask_ssssm"])},
+                "rank_flop_share": model["rank_flop_share_max_over_mean"],
+                "tasks_rank0": {"getrf": int(info["ntask_getrf"]), "tstrf": int(info["ntask_tstrf"]), "gessm": int(info["ntask_gessm"]),
+                                "ssssm": int(info["ntask_ssssm"])},
             },
-            "residual": residual,
+            "residual": residual, "factor_check": factor_check,
+            "checked": "residual and factor_check are from the factors of the last timed step (timed configuration)",
             "init_s": round(t_init, 2),
             "hbm_used_GB": round(used.value / 1e9, 2), "owned_records_GB": round(info["owned_bytes"] / 1e9, 2),
             "host_sched_s_last_step": round(info["time_numeric_host_sched"], 4),
             "batches_per_step": int(info["batches"]),
             "roofline": roofline,
+            "model": model,
             "kernels": kernels,
             "cpu_baseline": cpu,
         }

@@ -32,6 +32,9 @@ extern "C"
     void pangulu_amd_comm_finalize(void);
     /* transport in effect (RCCL falls back to HOST on all ranks together when its self-test fails) */
     int pangulu_amd_comm_transport(void);
+    /* ranks whose RCCL communicators were created and passed the start-up self-test (a 1 MiB pattern over every directed
+     * pair); 0 when the data plane in effect is not RCCL */
+    int pangulu_amd_comm_rccl_ranks(void);
     int pangulu_amd_comm_rank(void);
     int pangulu_amd_comm_size(void);
 
@@ -88,10 +91,33 @@ extern "C"
         /* checker's build with task sampling on (oracle/pangulu_amd_test_hooks.h); 0 in the product */
         double sampled_flop;                  /* structural flops of the tasks that were executed                      */
         unsigned long long sampled_tasks;
+        double time_numeric_platform;         /* seconds inside the platform's hybrid_batched calls (compute thread or launcher) */
+        /* Structure-only model of the WHOLE factorisation for this handle's rank count, evaluated by every rank at
+         * pangulu_init from the replicated symbolic pattern (HBM 8 TB/s, 78.6 TFLOP/s, 153 GB/s per xGMI link unless
+         * PANGULU_AMD_MODEL_HBM_GBS / _FP_TFLOPS / _LINK_GBS say otherwise):
+         *   T*_r = sum over the tasks rank r runs of max(bytes_t / BW, flop_t / P);  comm_r = max over peers of the bytes
+         *   rank r sends to that peer / link rate (one xGMI link per pair);  T*(N) = max_r (T*_r + comm_r). */
+        double model_ranks_tstar_max;         /* T*(N), seconds                                                         */
+        double model_ranks_tstar_sum;         /* sum_r T*_r (= the single-rank T*)                                      */
+        double model_ranks_tstar_hbm, model_ranks_tstar_fp; /* the sum split into HBM-bound and MFMA-bound tasks         */
+        double model_ranks_bytes_total;       /* algorithmic bytes of all tasks                                         */
+        double model_rank_flop_share;         /* max_r flop_r / mean_r flop_r (1 = perfectly balanced)                  */
+        double model_rank_time_share;         /* max_r T*_r / mean_r T*_r                                               */
+        double model_comm_seconds_max;        /* max_r comm_r                                                           */
+        double model_sent_bytes_total;        /* bytes of block records forwarded between ranks                         */
+        double model_critical_path;           /* longest dependent chain of tasks, each at its own T*_t, seconds        */
+        unsigned long long model_critical_path_tasks; /* ... and its length in tasks                                    */
     } pangulu_amd_info_t;
     void pangulu_amd_get_info(void **pangulu_handle, pangulu_amd_info_t *out);
     /* evaluate T* = sum_t max(bytes_t / BW, flop_t / P) over this rank's task list (structure only) */
     void pangulu_amd_model_roofline(void **pangulu_handle, double hbm_gbytes_per_s, double fp_tflops);
+    /* rank that owns block (brow, bcol) under the handle's mapping (the reference: (brow mod p) q + (bcol mod q),
+     * src/pangulu.c:83-90; here subtrees on single ranks, heavy separators block-cyclic over their rank group); -1 outside
+     * the block grid */
+    int pangulu_amd_block_owner(void **pangulu_handle, sparse_index_t brow, sparse_index_t bcol);
+    /* per-rank figures of the structure-only model above: arrays of info.nproc entries (any may be NULL);
+     * returns the number of ranks */
+    int pangulu_amd_rank_model(void **pangulu_handle, double *tstar_seconds, double *flop, double *comm_seconds);
 
     /* ---- repeated factorisations (bench.py) ---------------------------------------------------------- */
     /* gstrf overwrites the matrix with its factors.  snapshot() keeps a pristine device-side copy of this rank's
@@ -114,6 +140,11 @@ extern "C"
     /* y = L*(U*x) with the (downloaded) factors of a single-rank run, in the permuted ordering; used for the
      * reference's factor check ||L(U.1) - A.1|| / ||A.1|| (src/pangulu_numeric.c:1082-1341) */
     int pangulu_amd_apply_lu(void **pangulu_handle, const calculate_type *x, calculate_type *y);
+    /* The reference's numeric check after pangulu_gstrf, || L (U 1) - A 1 ||_2 / || A 1 ||_2 with A the reordered (and, with
+     * scaling on, scaled) matrix (pangulu_numeric_check, src/pangulu_numeric.c:1082-1341), evaluated on the factors where
+     * they are: on the device-resident records (no download), any number of ranks (collective: every rank calls it, every
+     * rank gets the value), all four value types.  Returns 0 on success, 1 if the handle has not been factorised. */
+    int pangulu_amd_factor_check(void **pangulu_handle, double *relative_error);
 
 #ifdef __cplusplus
 }

@@ -245,6 +245,11 @@ extern "C"
     /*   PANGULU_HIP_OPT_XCD_SWIZZLE (default 1): map workgroup ids so that the workgroups of one update queue / one
      *     destination / one solve run on the same XCD and share its L2 (0: hardware round-robin order). */
 #define PANGULU_HIP_OPT_XCD_SWIZZLE 12
+    /*   PANGULU_HIP_OPT_RECORDS_STREAM (default 1; environment PANGULU_HIP_RECORDS_STREAM at start-up): the sparsify jobs
+     *     that bring the sparse records of finished blocks up to date run on their own stream beside the next kernels;
+     *     0 keeps them on the main stream.  bench.py's profile pass turns it (and TWO_STREAMS) off so that the hipEvent
+     *     pair around a launch brackets that kernel and nothing else. */
+#define PANGULU_HIP_OPT_RECORDS_STREAM 13
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an
@@ -275,6 +280,14 @@ extern "C"
     void pangulu_platform_0201001_block_trsv(pangulu_inblock_idx nb, int upper, pangulu_uint64_t nlevel, const pangulu_uint64_t *level_ptr,
                                              const pangulu_hip_solve_row_t *rows, pangulu_storage_slot_t *const *blk_slots,
                                              const pangulu_exblock_idx *blk_bcol, calculate_type *x, pangulu_uint64_t xlen);
+    /* Optional: y[dst segment] += A_blk * x[src segment] for a list of device-resident block records, in one launch (one
+     * workgroup per block, floating-point atomics on y).  `x` and `y` are HOST vectors of `xlen` values (nb per block
+     * row / column); y is read, updated and written back.  csr[i] != 0: the record is an upper diagonal half (CSR, diagonal
+     * first).  The native host builds the reference's factor check ||L(U.1) - A.1|| / ||A.1|| from it
+     * (src/pangulu_numeric.c:1082-1341) without downloading the factors. */
+    void pangulu_platform_0201001_block_spmv_add(pangulu_inblock_idx nb, pangulu_uint64_t nblk, pangulu_storage_slot_t *const *slots,
+                                                 const pangulu_exblock_idx *src_seg, const pangulu_exblock_idx *dst_seg, const int *csr,
+                                                 const calculate_type *x, calculate_type *y, pangulu_uint64_t xlen);
     /* Optional: keep the calling thread (and threads it creates afterwards) on the CPUs of the NUMA node the device hangs off
      * while enable = 1, restore its previous affinity mask with enable = 0 (the reference pins its threads as well,
      * src/pangulu_thread.c:3-12).  The native host calls it around pangulu_init / gstrf / gstrs.  Returns 0 when the mask

@@ -22,6 +22,10 @@ extern "C"
      * the others (a bounded sample of the same matrix / ordering / nb); pangulu_amd_info_t.sampled_flop / sampled_tasks
      * say what ran.  1 = everything (default). */
     void pangulu_amd_test_set_task_sampling(int stride);
+    /* the subtree-to-rank mapping and the per-rank structure model for `size` ranks evaluated in one process: the next
+     * pangulu_init must run with PANGULU_AMD_ANALYSIS_ONLY=1 (no block records, nothing to factorise); <= 1 restores
+     * the single-rank world.  tests/test_mapping.py checks the per-rank flop shares with it. */
+    void pangulu_amd_test_set_analysis_ranks(int size);
     /* the host's priority heap driven by a push/pop script, and its symbolic phase on a bare pattern: compared with the
      * reference's own src/pangulu_task.c / src/pangulu_symbolic.c (oracle/ref/ref_pin.c) in tests/test_reference_pin.py */
     long long pangulu_amd_test_heap_script(long long nscript, const long long *script, const void *tasks, void *out);

@@ -77,6 +77,18 @@ class Info(ctypes.Structure):
         ("batches", ctypes.c_ulonglong),
         ("sampled_flop", ctypes.c_double),
         ("sampled_tasks", ctypes.c_ulonglong),
+        ("time_numeric_platform", ctypes.c_double),
+        ("model_ranks_tstar_max", ctypes.c_double),
+        ("model_ranks_tstar_sum", ctypes.c_double),
+        ("model_ranks_tstar_hbm", ctypes.c_double),
+        ("model_ranks_tstar_fp", ctypes.c_double),
+        ("model_ranks_bytes_total", ctypes.c_double),
+        ("model_rank_flop_share", ctypes.c_double),
+        ("model_rank_time_share", ctypes.c_double),
+        ("model_comm_seconds_max", ctypes.c_double),
+        ("model_sent_bytes_total", ctypes.c_double),
+        ("model_critical_path", ctypes.c_double),
+        ("model_critical_path_tasks", ctypes.c_ulonglong),
     ]
 
     def as_dict(self):
@@ -148,6 +160,7 @@ def load(vtype="r64", test_hooks=False):
     lib.pangulu_amd_comm_allreduce_max_f64.restype = None
     lib.pangulu_amd_comm_finalize.restype = None
     lib.pangulu_amd_comm_transport.restype = ctypes.c_int
+    lib.pangulu_amd_comm_rccl_ranks.restype = ctypes.c_int
     lib.pangulu_amd_comm_rank.restype = ctypes.c_int
     lib.pangulu_amd_comm_size.restype = ctypes.c_int
     if test_hooks:
@@ -169,6 +182,10 @@ def load(vtype="r64", test_hooks=False):
     lib.pangulu_amd_get_info.restype = None
     lib.pangulu_amd_model_roofline.argtypes = [vpp, ctypes.c_double, ctypes.c_double]
     lib.pangulu_amd_model_roofline.restype = None
+    lib.pangulu_amd_block_owner.argtypes = [vpp, ctypes.c_uint32, ctypes.c_uint32]
+    lib.pangulu_amd_block_owner.restype = ctypes.c_int
+    lib.pangulu_amd_rank_model.argtypes = [vpp, vp, vp, vp]
+    lib.pangulu_amd_rank_model.restype = ctypes.c_int
     lib.pangulu_amd_owned_block_count.argtypes = [vpp]
     lib.pangulu_amd_owned_block_count.restype = ctypes.c_longlong
     lib.pangulu_amd_owned_block.argtypes = [
@@ -184,6 +201,8 @@ def load(vtype="r64", test_hooks=False):
     lib.pangulu_amd_get_perm.restype = ctypes.POINTER(ctypes.c_uint32)
     lib.pangulu_amd_apply_lu.argtypes = [vpp, vp, vp]
     lib.pangulu_amd_apply_lu.restype = ctypes.c_int
+    lib.pangulu_amd_factor_check.argtypes = [vpp, ctypes.POINTER(ctypes.c_double)]
+    lib.pangulu_amd_factor_check.restype = ctypes.c_int
 
     lib.pangulu_platform_0201001_set_option.argtypes = [ctypes.c_int, ctypes.c_longlong]
     lib.pangulu_platform_0201001_set_option.restype = ctypes.c_int
@@ -212,6 +231,7 @@ HIP_OPT_TRSM_DENSE_PERMILLE = 9
 HIP_OPT_TWO_STREAMS = 10
 HIP_OPT_SMALL_LAUNCH_TASKS = 11
 HIP_OPT_XCD_SWIZZLE = 12
+HIP_OPT_RECORDS_STREAM = 13
 
 ORDER_IDENTITY, ORDER_ND, ORDER_USER = 0, 1, 2
 TRANSPORT_HOST, TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1, 2

@@ -72,6 +72,7 @@ void bind_builtin_hip(Platform &p)
     p.marker_done = pangulu_platform_0201001_marker_done;
     p.marker_wait = pangulu_platform_0201001_marker_wait;
     p.block_trsv = pangulu_platform_0201001_block_trsv;
+    p.block_spmv_add = pangulu_platform_0201001_block_spmv_add;
     p.bind_near_device = pangulu_platform_0201001_bind_near_device;
 }
 
@@ -181,6 +182,10 @@ extern "C"
         return 0;
     }
 
+    // Mapping and models for `size` ranks evaluated in ONE process: the next pangulu_init must run with
+    // PANGULU_AMD_ANALYSIS_ONLY=1 (no records, no exchange); size <= 1 restores the single-rank world.
+    void pangulu_amd_test_set_analysis_ranks(int size) { set_fake_world(size); }
+
     // bench.py's cpu_baseline leg: run every stride-th task of each kernel class only (pg_numeric.cpp)
     void pangulu_amd_test_set_task_sampling(int stride) { g_task_sample_stride = stride < 1 ? 1 : stride; }
 
@@ -279,6 +284,7 @@ extern "C"
     void pangulu_amd_comm_finalize(void) { set_world(nullptr); }
     int pangulu_amd_rccl_unique_id(void *out128) { return rccl_make_unique_id(out128); }
     int pangulu_amd_comm_transport(void) { return world()->transport; }
+    int pangulu_amd_comm_rccl_ranks(void) { return world()->rccl_ranks(); }
     int pangulu_amd_comm_rank(void) { return world()->rank; }
     int pangulu_amd_comm_size(void) { return world()->size; }
 
@@ -511,7 +517,13 @@ extern "C"
         t0 = wall_seconds();
         build_block_pattern(S->sym, S->nb, S->pat);
         S->info.nblocks_nondiag = S->pat.colptr[S->nbk];
+        {
+            const char *ao = getenv("PANGULU_AMD_ANALYSIS_ONLY");
+            S->analysis_only = ao && atoi(ao) != 0;
+        }
+        build_structure_model(*S); // weights for the mapping, from the symbolic pattern (every rank the same)
         preprocess(*S, S->Aperm);
+        compute_rank_model(*S);    // per-rank T*, flop shares, link term, critical path under the mapping just made
         // the element-level pattern is only needed to build the records
         S->sym.idx = std::vector<u32>();
         S->sym.ptr = std::vector<u64>();
@@ -529,6 +541,8 @@ extern "C"
             exit(1);
         }
         Solver *S = (Solver *)*pangulu_handle;
+        if (S->analysis_only)
+            fatal("PANGULU_AMD_ANALYSIS_ONLY handle: pattern, mapping and models only, nothing to factorise");
         NearDevice near(active_platform());
         numeric_factorize(*S);
     }
@@ -691,6 +705,16 @@ extern "C"
 #endif
     }
 
+    int pangulu_amd_factor_check(void **pangulu_handle, double *relative_error)
+    {
+        Solver *S = (Solver *)*pangulu_handle;
+        if (!S->factored)
+            return 1;
+        NearDevice near(active_platform());
+        *relative_error = factor_check(*S);
+        return 0;
+    }
+
     int pangulu_amd_snapshot(void **pangulu_handle)
     {
         Solver *S = (Solver *)*pangulu_handle;
@@ -739,6 +763,31 @@ extern "C"
         S->factored = false;
         S->host_values_current = plat.host_memory;
         return 0;
+    }
+
+    int pangulu_amd_block_owner(void **pangulu_handle, sparse_index_t brow, sparse_index_t bcol)
+    {
+        Solver *S = (Solver *)*pangulu_handle;
+        if (brow >= S->nbk || bcol >= S->nbk)
+            return -1;
+        return S->owner(brow, bcol);
+    }
+
+    int pangulu_amd_rank_model(void **pangulu_handle, double *tstar_seconds, double *flop, double *comm_seconds)
+    {
+        Solver *S = (Solver *)*pangulu_handle;
+        const StructureModel &M = S->smodel;
+        const int np = (int)M.rank_flop.size();
+        for (int r = 0; r < np; r++)
+        {
+            if (tstar_seconds)
+                tstar_seconds[r] = M.rank_time_hbm[(size_t)r] + M.rank_time_fp[(size_t)r];
+            if (flop)
+                flop[r] = M.rank_flop[(size_t)r];
+            if (comm_seconds)
+                comm_seconds[r] = M.rank_comm_s[(size_t)r];
+        }
+        return np;
     }
 
     void pangulu_amd_model_roofline(void **pangulu_handle, double hbm_gbytes_per_s, double fp_tflops)

@@ -43,10 +43,24 @@ Comm *world()
     return g_world;
 }
 
+// checker's build only (pangulu_amd_test_set_analysis_ranks): a one-process stand-in for a group of `size` ranks, good for
+// PANGULU_AMD_ANALYSIS_ONLY handles -- the mapping and the models depend on the rank COUNT, not on any exchange
+void set_fake_world(int size)
+{
+    set_world(nullptr);
+    if (size > 1)
+    {
+        LoopbackComm *c = new LoopbackComm();
+        c->size = size;
+        g_world = c;
+    }
+}
+
 void set_world(Comm *c)
 {
-    if (g_world)
+    if (g_world && !g_world->abandoned)
         delete g_world;
+    // (an abandoned object is leaked on purpose: its helper thread, stuck inside RCCL, still holds `this`)
     g_world = c;
 }
 

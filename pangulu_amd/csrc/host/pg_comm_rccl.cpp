@@ -145,8 +145,11 @@ struct RcclComm : SocketComm
             {
                 ok = false;
                 fprintf(stderr, "[PanguLU-AMD] rank %d: RCCL initialisation did not finish within %d s\n", rank, timeout_s);
-                // the helper thread is abandoned inside RCCL; leak the future so its destructor does not join
+                // the helper thread is abandoned inside RCCL; leak the future so its destructor does not join, and this
+                // object with it (set_world() checks `abandoned`): the thread still reads the ids and writes the communicator
+                // tables if ncclCommInitRank ever returns
                 new std::future<bool>(std::move(fut));
+                abandoned = true;
             }
         }
         // all ranks must agree (over TCP, which works regardless)
@@ -267,6 +270,8 @@ struct RcclComm : SocketComm
             }
         }
     }
+
+    int rccl_ranks() const override { return rccl_ok ? size : 0; }
 
     void isend_block(slot_t *s, const BlockHeader &h, int dst) override
     {

@@ -75,6 +75,8 @@ struct Platform
     int (*bind_near_device)(int) = nullptr;
     void (*block_trsv)(pangulu_inblock_idx, int, pangulu_uint64_t, const pangulu_uint64_t *, const pangulu_hip_solve_row_t *, slot_t *const *,
                        const pangulu_exblock_idx *, val_t *, pangulu_uint64_t) = nullptr;
+    void (*block_spmv_add)(pangulu_inblock_idx, pangulu_uint64_t, slot_t *const *, const pangulu_exblock_idx *, const pangulu_exblock_idx *, const int *,
+                           const val_t *, val_t *, pangulu_uint64_t) = nullptr;
 };
 Platform &active_platform();               // built-in HIP unless the test hook replaced it
 bool platform_is_builtin_hip();
@@ -230,9 +232,15 @@ public:
     // transports that copy straight between arenas map their peers' here (pg_comm_ipc.cpp)
     virtual void register_arena(char *const * /*chunks*/, size_t /*nchunks*/, size_t /*chunk_bytes*/, size_t /*total_bytes*/) {}
     u64 sent_bytes = 0, recv_bytes_total = 0;
+    // ranks whose RCCL communicators passed the start-up self-test (0: the data plane is not RCCL)
+    virtual int rccl_ranks() const { return 0; }
+    // true: a helper thread of this object was abandoned inside a library call (RCCL start-up that never returned) and may
+    // still touch the object: set_world() then leaks it instead of deleting it
+    bool abandoned = false;
 };
 Comm *world();             // never null: a 1-rank loopback by default
 void set_world(Comm *c);   // takes ownership
+void set_fake_world(int size); // checker's build: analysis-only handles for a rank count without the ranks
 Comm *make_socket_comm(int rank, int size, const char *addr, int base_port, int transport, const void *nccl_id);
 int rccl_make_unique_id(void *out128); // 0 on success; librccl.so is loaded lazily
 Comm *make_rccl_comm(int rank, int size, const char *addr, int base_port, const void *nccl_id);
@@ -261,6 +269,23 @@ struct TaskModel // SURVEY.md §8d algorithmic bytes / flops of the rank's tasks
     double bytes[5] = {0, 0, 0, 0, 0};
     double flop[5] = {0, 0, 0, 0, 0};
     u64 count[5] = {0, 0, 0, 0, 0};
+};
+
+// Structure-only model of the whole factorisation, evaluated by every rank at pangulu_init from the replicated symbolic
+// pattern (pg_model.cpp): per-task algorithmic bytes / structural flops of SURVEY.md §8d for ALL tasks, whoever runs them.
+// It weighs the block elimination tree for the subtree-to-rank mapping and gives T* per rank for any number of ranks.
+struct StructureModel
+{
+    double hbm_bytes_per_s = 8e12, fp_flops_per_s = 78.6e12, link_bytes_per_s = 153e9;
+    std::vector<u16> lcount;            // per lower block (BlockPattern::lcolptr order) and in-block column: entries
+    // per block column c: T* seconds / structural flops of the tasks that EXECUTE in column c under a column-wise mapping:
+    // GETRF(c), the panel solves of column c and row c, and every update whose destination (i, j) has min(i, j) = c
+    std::vector<double> col_time, col_flop;
+    // after the mapping: per rank
+    std::vector<double> rank_time_hbm, rank_time_fp, rank_flop, rank_bytes, rank_comm_s;
+    std::vector<double> sent_bytes;     // [from * nproc + to]
+    double critical_path_s = 0;
+    u64 critical_path_tasks = 0;
 };
 
 struct Solver
@@ -301,19 +326,34 @@ struct Solver
     // statistics
     pangulu_amd_info_t info;
     TaskModel model;
+    StructureModel smodel;
     // Ownership.  The reference is purely 2D block-cyclic (src/pangulu.c:83-90, owner = (br mod p) q + (bc mod q)).  Here
     // the panels (diagonal block, L column, U row) of every block column inside a SUBTREE of the block elimination
     // tree that was given to one rank belong to that rank (home[min(br,bc)] >= 0): disjoint subtrees are independent
     // computations, so the bottom of the tree -- where most levels are -- runs without any exchange and in lock-step
     // batches per rank; only the top of the tree (home < 0) is 2D block-cyclic.  Filled by assign_subtrees().
     std::vector<int> home;
+    // ... or, home < 0 and grp non-empty: the column's blocks are 2D block-cyclic over the p x q grid of a rank GROUP
+    // [lo, lo + p q) (proportional mapping: the groups shrink down the tree); grp empty: over the grid of all ranks
+    struct Group
+    {
+        unsigned short lo, p, q;
+    };
+    std::vector<Group> grp;
+    bool analysis_only = false; // PANGULU_AMD_ANALYSIS_ONLY=1: pattern, mapping, counters and models only -- no records, no gstrf
     int owner(u32 br, u32 bc) const
     {
         if (!home.empty())
         {
-            const int h = home[br < bc ? br : bc];
+            const u32 c = br < bc ? br : bc;
+            const int h = home[c];
             if (h >= 0)
                 return h;
+            if (!grp.empty())
+            {
+                const Group &g = grp[c];
+                return (int)(g.lo + (br % g.p) * g.q + (bc % g.q));
+            }
         }
         return (int)((br % (u32)p) * (u32)q + (bc % (u32)q));
     }
@@ -325,7 +365,10 @@ void preprocess(Solver &S, const CscMatrix &Aperm);       // records, counters, 
 void numeric_factorize(Solver &S);                        // the hot path
 void download_factors(Solver &S);                         // device -> host mirror of owned values
 void triangular_solve(Solver &S, val_t *rhs_permuted);    // forward + backward block sweeps (host kernels)
+double factor_check(Solver &S);                           // ||L(U 1) - A 1|| / ||A 1|| on the factors where they are (pg_check.cpp; collective)
 void compute_task_model(Solver &S, double hbm_bytes_per_s, double fp_flops_per_s); // pg_model.cpp: T* of SURVEY.md §8d
+void build_structure_model(Solver &S);   // pg_model.cpp: column counts per lower block + per-column work (before the mapping)
+void compute_rank_model(Solver &S);      // pg_model.cpp: per-rank T*, flop shares, link term, critical path (after preprocess)
 double task_structural_flop(u32 nb, const task_t &t);
 // Checker's build only (oracle/pangulu_amd_test_hooks.h): execute every stride-th task of each kernel class and skip the
 // rest -- a bounded, representative sample of the SAME factorisation for bench.py's cpu_baseline leg.  1 = everything.

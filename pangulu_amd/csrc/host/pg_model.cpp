@@ -203,4 +203,347 @@ void compute_task_model(Solver &S, double hbm_bytes_per_s, double fp_flops_per_s
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same model for ALL tasks of the factorisation, from the replicated symbolic pattern alone (any number of ranks).
+//
+// The symbolic pattern is symmetric, so the pattern of U(k, j) is the transpose of L(j, k) and every closed form above
+// needs nothing but the column counts of the lower blocks of block column k:
+//   cnt_B[c] = entries of column c of lower block B = L(i, k)   (diagonal block: diagonal entry included)
+//   nl_c = cnt_diag[c] - 1  (strictly lower entries of column c of the diagonal block)  = nu_c - 1
+//   GETRF(k)            sum_c nl_c (1 + 2 nl_c)
+//   TSTRF  L(i,k)       sum_c cnt_B[c] (1 + 2 nl_c)
+//   GESSM  U(k,j)       sum_c 2 cnt_{L(j,k)}[c] nl_c
+//   SSSSM  (i,j) from k 2 sum_c cnt_{L(i,k)}[c] cnt_{L(j,k)}[c]
+// (tests/test_abi_and_host.py checks these against compute_task_model on single-rank handles: identical sums.)
+// ---------------------------------------------------------------------------------------------------------
+namespace
+{
+
+struct TaskCost
+{
+    double bytes, flop;
+};
+
+// walks every task of the factorisation once, level by level; fn(cls, level, brow, bcol, cost) is called from an OpenMP
+// region (parallel over levels) -- callers accumulate with atomics or per-thread state
+template <typename F>
+void for_every_task(const Solver &S, F &&fn)
+{
+    const BlockPattern &P = S.pat;
+    const u32 nb = S.nb, nbk = S.nbk;
+    const double sv = (double)sizeof(val_t);
+    const u16 *lcount = S.smodel.lcount.data();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (i64 kk = 0; kk < (i64)nbk; kk++)
+    {
+        const u32 k = (u32)kk;
+        const u64 l0 = P.lcolptr[k], l1 = P.lcolptr[k + 1];
+        // the diagonal block is the first lower block of its column
+        const u16 *cd = lcount + (size_t)l0 * nb;
+        const double nnzL = P.diag_lower_nnz[k], nnzU = P.diag_upper_nnz[k];
+        {
+            double fl = 0;
+            for (u32 c = 0; c < nb; c++)
+                if (cd[c])
+                {
+                    const double nl = (double)cd[c] - 1.0;
+                    fl += nl * (1.0 + 2.0 * nl);
+                }
+            fn(PANGULU_TASK_GETRF, k, k, k, TaskCost{(2 * sv + 2) * (nnzL + nnzU) + 8.0 * (nb + 1), fl});
+        }
+        for (u64 a = l0 + 1; a < l1; a++)
+        {
+            const u32 i = P.lrowidx[a];
+            const u16 *ca = lcount + (size_t)a * nb;
+            const double nnzB = P.lnnz[a];
+            double ft = 0, fg = 0;
+            for (u32 c = 0; c < nb; c++)
+                if (ca[c])
+                {
+                    const double nl = cd[c] ? (double)cd[c] - 1.0 : 0.0;
+                    ft += (double)ca[c] * (1.0 + 2.0 * nl);
+                    fg += 2.0 * (double)ca[c] * nl;
+                }
+            fn(PANGULU_TASK_TSTRF, k, i, k, TaskCost{(2 * sv + 6) * nnzB + (sv + 2) * nnzU + 8.0 * (nb + 1), ft});
+            fn(PANGULU_TASK_GESSM, k, k, i, TaskCost{(2 * sv + 2) * nnzB + (sv + 2) * nnzL + 8.0 * (nb + 1), fg});
+        }
+        // updates C(i, j) -= L(i, k) U(k, j), i and j over the off-diagonal lower blocks of column k
+        for (u64 b = l0 + 1; b < l1; b++)
+        {
+            const u32 j = P.lrowidx[b];
+            const u16 *cb = lcount + (size_t)b * nb;
+            for (u64 a = l0 + 1; a < l1; a++)
+            {
+                const u32 i = P.lrowidx[a];
+                double nnz_c;
+                if (i == j)
+                    nnz_c = (double)P.diag_lower_nnz[i] + P.diag_upper_nnz[i];
+                else
+                {
+                    const u64 bd = P.find(i, j);
+                    if (bd == ~0ull)
+                        continue;
+                    nnz_c = P.nnz[bd];
+                }
+                const u16 *ca = lcount + (size_t)a * nb;
+                double fl = 0;
+                for (u32 c = 0; c < nb; c++)
+                    fl += (double)((u32)ca[c] * (u32)cb[c]);
+                fn(PANGULU_TASK_SSSSM, k, i, j, TaskCost{(sv + 2) * ((double)P.lnnz[a] + P.lnnz[b]) + (2 * sv + 2) * nnz_c + 12.0 * (nb + 1), 2.0 * fl});
+            }
+        }
+    }
+}
+
+inline void atomic_add(double &dst, double v)
+{
+#pragma omp atomic
+    dst += v;
+}
+
+} // namespace
+
+void build_structure_model(Solver &S)
+{
+    StructureModel &M = S.smodel;
+    if (const char *e = getenv("PANGULU_AMD_MODEL_HBM_GBS"))
+        M.hbm_bytes_per_s = 1e9 * atof(e);
+    if (const char *e = getenv("PANGULU_AMD_MODEL_FP_TFLOPS"))
+        M.fp_flops_per_s = 1e12 * atof(e);
+    if (const char *e = getenv("PANGULU_AMD_MODEL_LINK_GBS"))
+        M.link_bytes_per_s = 1e9 * atof(e);
+    const BlockPattern &P = S.pat;
+    const Symbolic &sym = S.sym;
+    const u32 nb = S.nb, nbk = S.nbk, n = S.n;
+    if (nb > 65535)
+        return;
+    M.lcount.assign((size_t)P.lcolptr[nbk] * nb, 0);
+#pragma omp parallel
+    {
+        std::vector<i64> local_of(nbk, -1);
+#pragma omp for schedule(dynamic, 2)
+        for (i64 bc_ = 0; bc_ < (i64)nbk; bc_++)
+        {
+            const u32 bc = (u32)bc_;
+            const u64 l0 = P.lcolptr[bc], l1 = P.lcolptr[bc + 1];
+            for (u64 t = l0; t < l1; t++)
+                local_of[P.lrowidx[t]] = (i64)t;
+            const u32 j0 = bc * nb, j1 = std::min(n, j0 + nb);
+            for (u32 j = j0; j < j1; j++)
+                for (u64 p = sym.ptr[j]; p < sym.ptr[j + 1]; p++)
+                    M.lcount[(size_t)local_of[sym.idx[p] / nb] * nb + (j - j0)]++;
+            for (u64 t = l0; t < l1; t++)
+                local_of[P.lrowidx[t]] = -1;
+        }
+    }
+    M.col_time.assign(nbk, 0.0);
+    M.col_flop.assign(nbk, 0.0);
+    const double bw = M.hbm_bytes_per_s, peak = M.fp_flops_per_s;
+    for_every_task(S, [&](int, u32, u32 brow, u32 bcol, const TaskCost &c)
+                   {
+                       const u32 col = std::min(brow, bcol);
+                       atomic_add(M.col_time[col], std::max(c.bytes / bw, c.flop / peak));
+                       atomic_add(M.col_flop[col], c.flop); });
+}
+
+void compute_rank_model(Solver &S)
+{
+    StructureModel &M = S.smodel;
+    const BlockPattern &P = S.pat;
+    const u32 nb = S.nb, nbk = S.nbk;
+    const int np = S.nproc;
+    if (M.lcount.empty())
+        return;
+    M.rank_time_hbm.assign((size_t)np, 0.0);
+    M.rank_time_fp.assign((size_t)np, 0.0);
+    M.rank_flop.assign((size_t)np, 0.0);
+    M.rank_bytes.assign((size_t)np, 0.0);
+    M.rank_comm_s.assign((size_t)np, 0.0);
+    M.sent_bytes.assign((size_t)np * np, 0.0);
+    const double bw = M.hbm_bytes_per_s, peak = M.fp_flops_per_s;
+    // per-task times kept for the critical path below: panel tasks per block, updates folded into their destination
+    const u64 nblk = P.colptr[nbk];
+    std::vector<float> t_panel(nblk, 0.f), t_getrf(nbk, 0.f);
+    for_every_task(S, [&](int cls, u32 level, u32 brow, u32 bcol, const TaskCost &c)
+                   {
+                       (void)level;
+                       const int r = S.owner(brow, bcol);
+                       const double a = c.bytes / bw, b = c.flop / peak;
+                       if (a >= b)
+                           atomic_add(M.rank_time_hbm[(size_t)r], a);
+                       else
+                           atomic_add(M.rank_time_fp[(size_t)r], b);
+                       atomic_add(M.rank_flop[(size_t)r], c.flop);
+                       atomic_add(M.rank_bytes[(size_t)r], c.bytes);
+                       if (cls == PANGULU_TASK_GETRF)
+                           t_getrf[brow] = (float)std::max(a, b);
+                       else if (cls != PANGULU_TASK_SSSSM)
+                           t_panel[P.find(brow, bcol)] = (float)std::max(a, b); });
+    // bytes forwarded between ranks: every finished block goes once to each rank that runs an update with it
+    // (Solver::consumers), a diagonal block's halves to the ranks that run panel solves against them
+    if (np > 1)
+    {
+        for (u32 bc = 0; bc < nbk; bc++)
+            for (u64 t = P.colptr[bc]; t < P.colptr[bc + 1]; t++)
+            {
+                const u32 br = P.rowidx[t];
+                const int o = S.owner(br, bc);
+                const double bytes = (double)record_bytes(nb, P.nnz[t], br > bc);
+                u64 to = S.consumers.empty() ? 0ull : S.consumers[t];
+                if (S.consumers.empty())
+                {
+                    // the reference's rule: the whole process row / column that owns blocks behind it
+                    if (br > bc)
+                        for (u64 r = P.rowptr[br]; r < P.rowptr[br + 1]; r++)
+                        {
+                            if (P.colidx[r] > bc)
+                                to |= 1ull << S.owner(br, P.colidx[r]);
+                        }
+                    else
+                        for (u64 c = P.colptr[bc]; c < P.colptr[bc + 1]; c++)
+                            if (P.rowidx[c] > br)
+                                to |= 1ull << S.owner(P.rowidx[c], bc);
+                }
+                to &= ~(1ull << o);
+                for (int r = 0; r < np && r < 64; r++)
+                    if ((to >> r) & 1ull)
+                        M.sent_bytes[(size_t)o * np + r] += bytes;
+            }
+        for (u32 k = 0; k < nbk; k++)
+        {
+            const int o = S.owner(k, k);
+            u64 to_u = 0, to_l = 0;
+            for (u64 t = P.first_after_diag[k]; t < P.colptr[k + 1]; t++)
+                to_u |= 1ull << S.owner(P.rowidx[t], k);
+            for (u64 t = P.first_after_diag_csr[k]; t < P.rowptr[k + 1]; t++)
+                to_l |= 1ull << S.owner(k, P.colidx[t]);
+            for (int r = 0; r < np && r < 64; r++)
+                if (r != o)
+                {
+                    if ((to_u >> r) & 1ull)
+                        M.sent_bytes[(size_t)o * np + r] += (double)record_bytes(nb, P.diag_upper_nnz[k], false);
+                    if ((to_l >> r) & 1ull)
+                        M.sent_bytes[(size_t)o * np + r] += (double)record_bytes(nb, P.diag_lower_nnz[k], false);
+                }
+        }
+    }
+    double tsum = 0, tmax = 0, tworst = 0, fsum = 0, fmax = 0, cmax = 0, sent = 0, thbm = 0, tfp = 0, bsum = 0;
+    for (int r = 0; r < np; r++)
+    {
+        double c = 0;
+        for (int q = 0; q < np; q++)
+        {
+            c = std::max(c, M.sent_bytes[(size_t)r * np + q] / M.link_bytes_per_s);
+            sent += M.sent_bytes[(size_t)r * np + q];
+        }
+        M.rank_comm_s[(size_t)r] = c;
+        const double t = M.rank_time_hbm[(size_t)r] + M.rank_time_fp[(size_t)r];
+        tsum += t;
+        thbm += M.rank_time_hbm[(size_t)r];
+        tfp += M.rank_time_fp[(size_t)r];
+        bsum += M.rank_bytes[(size_t)r];
+        tmax = std::max(tmax, t);
+        tworst = std::max(tworst, t + c);
+        fsum += M.rank_flop[(size_t)r];
+        fmax = std::max(fmax, M.rank_flop[(size_t)r]);
+        cmax = std::max(cmax, c);
+    }
+    S.info.model_ranks_tstar_max = tworst;
+    S.info.model_ranks_tstar_sum = tsum;
+    S.info.model_ranks_tstar_hbm = thbm;
+    S.info.model_ranks_tstar_fp = tfp;
+    S.info.model_ranks_bytes_total = bsum;
+    S.info.model_rank_flop_share = fsum > 0 ? fmax / (fsum / np) : 1.0;
+    S.info.model_rank_time_share = tsum > 0 ? tmax / (tsum / np) : 1.0;
+    S.info.model_comm_seconds_max = cmax;
+    S.info.model_sent_bytes_total = sent;
+
+    // Critical path of the block task graph with every task at its own T*_t (a lower bound on any schedule's makespan
+    // however many devices there are): levels ascending; a block's updates may run concurrently once both operands are
+    // final, its panel task starts when the last of them is done.
+    {
+        std::vector<float> ready(nblk, 0.f), fin(nblk, 0.f), ready_d(nbk, 0.f), fin_d(nbk, 0.f);
+        std::vector<u32> depth(nblk, 0), depth_rd(nbk, 0), depth_r(nblk, 0), depth_d(nbk, 0);
+        const double svd = (double)sizeof(val_t);
+        const u16 *lcount = M.lcount.data();
+        for (u32 k = 0; k < nbk; k++)
+        {
+            fin_d[k] = ready_d[k] + t_getrf[k];
+            depth_d[k] = depth_rd[k] + 1;
+            const u64 l0 = P.lcolptr[k], l1 = P.lcolptr[k + 1];
+            // panel solves of column k and row k
+            for (u64 a = l0 + 1; a < l1; a++)
+            {
+                const u32 i = P.lrowidx[a];
+                const u64 bl = P.find(i, k), bu = P.find(k, i);
+                fin[bl] = std::max(ready[bl], fin_d[k]) + t_panel[bl];
+                depth[bl] = std::max(depth_r[bl], depth_d[k]) + 1;
+                fin[bu] = std::max(ready[bu], fin_d[k]) + t_panel[bu];
+                depth[bu] = std::max(depth_r[bu], depth_d[k]) + 1;
+            }
+            const i64 nl = (i64)(l1 - l0) - 1;
+            // updates generated by level k (destinations are distinct blocks: safe in parallel)
+#pragma omp parallel for schedule(dynamic, 4) if (nl > 8)
+            for (i64 bi = 0; bi < nl; bi++)
+            {
+                const u64 b = l0 + 1 + (u64)bi;
+                const u32 j = P.lrowidx[b];
+                const u16 *cb = lcount + (size_t)b * nb;
+                const u64 bu = P.find(k, j);
+                for (u64 a = l0 + 1; a < l1; a++)
+                {
+                    const u32 i = P.lrowidx[a];
+                    const u64 bl = P.find(i, k);
+                    double nnz_c;
+                    u64 bd = ~0ull;
+                    if (i == j)
+                        nnz_c = (double)P.diag_lower_nnz[i] + P.diag_upper_nnz[i];
+                    else
+                    {
+                        bd = P.find(i, j);
+                        if (bd == ~0ull)
+                            continue;
+                        nnz_c = P.nnz[bd];
+                    }
+                    const u16 *ca = lcount + (size_t)a * nb;
+                    double fl = 0;
+                    for (u32 c = 0; c < nb; c++)
+                        fl += (double)((u32)ca[c] * (u32)cb[c]);
+                    const double by = (svd + 2) * ((double)P.lnnz[a] + P.lnnz[b]) + (2 * svd + 2) * nnz_c + 12.0 * (nb + 1);
+                    const float t = (float)std::max(by / bw, 2.0 * fl / peak);
+                    const float done = std::max(fin[bl], fin[bu]) + t;
+                    const u32 dp = std::max(depth[bl], depth[bu]) + 1;
+                    if (i == j)
+                    {
+                        ready_d[i] = std::max(ready_d[i], done);
+                        depth_rd[i] = std::max(depth_rd[i], dp);
+                    }
+                    else
+                    {
+                        ready[bd] = std::max(ready[bd], done);
+                        depth_r[bd] = std::max(depth_r[bd], dp);
+                    }
+                }
+            }
+        }
+        float cp = 0;
+        u32 dmax = 0;
+        for (u32 k = 0; k < nbk; k++)
+        {
+            cp = std::max(cp, fin_d[k]);
+            dmax = std::max(dmax, depth_d[k]);
+        }
+        for (u64 b = 0; b < nblk; b++)
+        {
+            cp = std::max(cp, fin[b]);
+            dmax = std::max(dmax, depth[b]);
+        }
+        M.critical_path_s = cp;
+        M.critical_path_tasks = dmax;
+        S.info.model_critical_path = cp;
+        S.info.model_critical_path_tasks = dmax;
+    }
+    M.lcount = std::vector<u16>(); // (51 MB for the Serena-class matrix: only needed until here)
+}
+
 } // namespace pg

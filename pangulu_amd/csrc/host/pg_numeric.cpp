@@ -1053,6 +1053,7 @@ void numeric_factorize(Solver &S)
     // host time the scheduler itself needed: with the launcher thread, the time until the last batch was handed over
     S.info.time_numeric_host_sched = sch.async_launch ? sch.t_sched : S.info.time_numeric - sch.t_platform;
     S.info.batches = sch.batches;
+    S.info.time_numeric_platform = sch.t_platform;
     S.info.sent_bytes = comm->sent_bytes;
     S.info.recv_bytes = comm->recv_bytes_total;
     S.factored = true;

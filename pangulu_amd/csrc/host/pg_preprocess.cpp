@@ -7,7 +7,9 @@
 // Unlike the reference (rank 0 builds everything and ships it), every rank derives its own records from the
 // replicated symbolic pattern, in parallel, and uploads them with one copy.
 #include <algorithm>
+#include <cmath>
 #include <queue>
+#include <string>
 #include <omp.h>
 
 #include "pg_host.h"
@@ -145,27 +147,54 @@ void transpose_inblock(u32 nb, const pangulu_inblock_ptr *cp, const pangulu_inbl
 
 } // namespace
 
-// Proportional mapping of the block elimination tree: split the tree from the top until no remaining subtree carries
-// more than 1/(subtrees_per_rank * nproc) of the work, give every remaining subtree to one rank (largest first, to the
-// least loaded rank); the nodes split off on the way stay with the 2D block-cyclic rule.  Deterministic: every rank
-// computes the same map from the same block pattern.
+// Mapping of the block elimination tree onto the ranks (multi-rank runs).  Deterministic: every rank computes the same map
+// from the same block pattern and the same structure model.
+//
+// Weights: col_time[c] of the structure model (pg_model.cpp) -- the T* seconds (max of algorithmic bytes / HBM rate and
+// structural flops / MFMA rate per task) of everything that EXECUTES in block column c when a column's panels live on
+// one rank: GETRF(c), the solves of column c and row c, and every update whose destination (i, j) has min(i, j) = c.  (Round
+// 2 weighed a column by its task COUNT: a 256 x 256 dense update and a five-entry one counted the same.)
+//
+// PANGULU_AMD_SEPARATOR_MAP=group (default since round 3): PROPORTIONAL mapping with rank GROUPS that shrink down the
+// tree (subtree-to-subcube).  The root's group is all ranks; the children of a node share their parent's group in
+// proportion to their subtree weights (recursive bisection of the group, heaviest child first to the lighter half); a
+// subtree whose group is one rank lives on that rank whole -- diagonal blocks, L columns, U rows -- and runs without any
+// exchange.  A block column whose group has several ranks is a separator.  If its own work is heavy (at least
+// PANGULU_AMD_DISTRIBUTE_US microseconds of T*, default 1000, or 5 % of a rank's fair share of the whole factorisation)
+// its blocks are distributed 2D BLOCK-CYCLIC over the group's p x q grid -- the reference's rule, owner(i, j) =
+// (i mod p) q + (j mod q) (src/pangulu.c:83-90, src/pangulu_common.h:135), applied inside the group: on 3D problems the top
+// separators ARE the factorisation and have to be shared.  A light separator goes, with its panels, to the least loaded
+// rank of its group: every level of a distributed separator costs dependent hops between ranks, which only pays when
+// there is work to share.
+// Other values: "path" (round 2's default: a separator follows the rank of its heaviest child), "cyclic" (every
+// separator 2D block-cyclic over ALL ranks), "rank0".  PANGULU_AMD_SUBTREE_MAP=0: pure 2D block-cyclic, the reference.
 void assign_subtrees(Solver &S)
 {
     S.home.clear();
+    S.grp.clear();
     const char *env = getenv("PANGULU_AMD_SUBTREE_MAP");
     if (S.nproc <= 1 || (env && atoi(env) == 0))
         return;
     const BlockPattern &P = S.pat;
     const u32 nbk = S.nbk, NONE = 0xFFFFFFFFu;
+    const int np = S.nproc;
     std::vector<u32> parent(nbk, NONE);
-    std::vector<double> sub(nbk, 0.0);
+    std::vector<double> own(nbk, 0.0), sub(nbk, 0.0);
     std::vector<std::vector<u32>> kids(nbk);
+    const bool have_model = S.smodel.col_time.size() == nbk;
     double total = 0;
     for (u32 k = 0; k < nbk; k++)
     {
-        const double nl = (double)(P.colptr[k + 1] - P.first_after_diag[k]);
-        const double nu = (double)(P.rowptr[k + 1] - P.first_after_diag_csr[k]);
-        sub[k] += 1.0 + nl + nu + nl * nu; // panel tasks + updates released by level k
+        if (have_model)
+            own[k] = S.smodel.col_time[k];
+        else
+        {
+            const double nl = (double)(P.colptr[k + 1] - P.first_after_diag[k]);
+            const double nu = (double)(P.rowptr[k + 1] - P.first_after_diag_csr[k]);
+            own[k] = 1.0 + nl + nu + nl * nu; // (nb > 65535: no structure model; task counts as in round 2)
+        }
+        total += own[k];
+        sub[k] += own[k];
         if (P.first_after_diag[k] < P.colptr[k + 1])
             parent[k] = P.rowidx[P.first_after_diag[k]];
         if (parent[k] != NONE)
@@ -173,34 +202,15 @@ void assign_subtrees(Solver &S)
             sub[parent[k]] += sub[k]; // (parent > k: its own term is added when the loop gets there)
             kids[parent[k]].push_back(k);
         }
-        else
-            total += sub[k];
     }
-    const char *per_env = getenv("PANGULU_AMD_SUBTREES_PER_RANK");
-    const double per_rank = per_env ? atof(per_env) : 8.0;
-    const double target = total / (per_rank * (double)S.nproc);
-    auto cmp = [&](u32 a, u32 b)
-    { return sub[a] < sub[b] || (sub[a] == sub[b] && a > b); };
-    std::priority_queue<u32, std::vector<u32>, decltype(cmp)> pq(cmp);
-    for (u32 k = 0; k < nbk; k++)
-        if (parent[k] == NONE)
-            pq.push(k);
+    const char *sm = getenv("PANGULU_AMD_SEPARATOR_MAP");
+    const std::string mode = sm ? sm : "group";
     S.home.assign(nbk, -1);
-    while (!pq.empty() && sub[pq.top()] > target)
-    {
-        u32 k = pq.top();
-        pq.pop(); // stays block-cyclic
-        for (u32 c : kids[k])
-            pq.push(c);
-    }
-    std::vector<double> load((size_t)S.nproc, 0.0);
+    std::vector<double> load((size_t)np, 0.0);
     std::vector<u32> stack;
-    size_t nsub = 0;
-    while (!pq.empty())
+    size_t nsub = 0, ndist = 0;
+    auto whole_subtree_to = [&](u32 root, int r)
     {
-        u32 root = pq.top();
-        pq.pop();
-        int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
         load[(size_t)r] += sub[root];
         nsub++;
         stack.assign(1, root);
@@ -212,20 +222,151 @@ void assign_subtrees(Solver &S)
             for (u32 c : kids[k])
                 stack.push_back(c);
         }
-    }
-    // The separators above the mapped subtrees (PANGULU_AMD_SEPARATOR_MAP).  Left 2D block-cyclic ("cyclic", the reference's
-    // rule and round 1's choice) every level of a separator costs several dependent hops between ranks -- diagonal block to the
-    // panel owners, panels to the update owners, updated diagonal back -- about 1.4 ms per level on two ranks for kernels
-    // that take 0.3 ms: 152 ms per factorisation of the bench matrix on two ranks sharing a GPU against 44 on one.
-    //   "path" (default): a separator goes, with its whole panels, to the rank that owns its heaviest child -- proportional
-    //   mapping carried up the tree.  Each child subtree hands its border panels over once; inside a separator nothing hops.
-    //   The chain of separators along the heaviest path ends on one rank: for tall-skinny trees (2D-like problems, where the
-    //   subtrees hold the work and the top is a latency chain) that is what one wants; a 3D problem whose top separator holds
-    //   most of the flops would rather split that separator's updates ("cyclic").
-    //   "rank0": all of them on rank 0 (97 ms in the same two-rank run; "path" measured below).
+    };
+    if (mode == "group")
     {
-        const char *sm = getenv("PANGULU_AMD_SEPARATOR_MAP");
-        const std::string mode = sm ? sm : "path";
+        const char *de = getenv("PANGULU_AMD_DISTRIBUTE_US");
+        const double heavy_abs = have_model ? 1e-6 * (de ? atof(de) : 1000.0) : 1e300;
+        const double heavy_rel = 0.05 * total / np;
+        S.grp.assign(nbk, Solver::Group{0, 1, 1});
+        struct Work
+        {
+            std::vector<u32> nodes; // roots of the subtrees that share the group
+            int lo, cnt;
+        };
+        std::vector<Work> todo;
+        {
+            Work w;
+            for (u32 k = 0; k < nbk; k++)
+                if (parent[k] == NONE)
+                    w.nodes.push_back(k);
+            w.lo = 0;
+            w.cnt = np;
+            todo.push_back(std::move(w));
+        }
+        while (!todo.empty())
+        {
+            Work w = std::move(todo.back());
+            todo.pop_back();
+            if (w.nodes.empty())
+                continue;
+            if (w.cnt == 1)
+            {
+                for (u32 k : w.nodes)
+                    whole_subtree_to(k, w.lo);
+                continue;
+            }
+            if (w.nodes.size() == 1)
+            {
+                // a separator (or a chain link of one): place its own column, hand the group on to its children
+                const u32 k = w.nodes[0];
+                if (own[k] >= heavy_abs || own[k] >= heavy_rel)
+                {
+                    int p = (int)std::sqrt((double)w.cnt);
+                    while (w.cnt % p)
+                        p--;
+                    S.grp[k] = Solver::Group{(unsigned short)w.lo, (unsigned short)p, (unsigned short)(w.cnt / p)};
+                    for (int r = w.lo; r < w.lo + w.cnt; r++)
+                        load[(size_t)r] += own[k] / w.cnt;
+                    ndist++;
+                }
+                else
+                {
+                    int best = w.lo;
+                    for (int r = w.lo; r < w.lo + w.cnt; r++)
+                        if (load[(size_t)r] < load[(size_t)best])
+                            best = r;
+                    S.home[k] = best;
+                    load[(size_t)best] += own[k];
+                }
+                Work next;
+                next.nodes = kids[k];
+                next.lo = w.lo;
+                next.cnt = w.cnt;
+                todo.push_back(std::move(next));
+                continue;
+            }
+            // several subtrees share the group
+            std::sort(w.nodes.begin(), w.nodes.end(), [&](u32 a, u32 b)
+                      { return sub[a] > sub[b] || (sub[a] == sub[b] && a < b); });
+            double wsum = 0;
+            for (u32 k : w.nodes)
+                wsum += sub[k];
+            const double ideal0 = wsum > 0 ? sub[w.nodes[0]] / wsum * w.cnt : 0.0; // ranks the heaviest subtree deserves
+            Work h[2];
+            if (ideal0 >= (double)w.cnt - 0.5)
+            {
+                // the rest deserves less than half a rank: whole subtrees on the least loaded ranks of the group, the heavy
+                // one keeps the whole group (many tiny trees beside the main one: padding rows, small components)
+                for (size_t t = 1; t < w.nodes.size(); t++)
+                {
+                    int best = w.lo;
+                    for (int r = w.lo; r < w.lo + w.cnt; r++)
+                        if (load[(size_t)r] < load[(size_t)best])
+                            best = r;
+                    whole_subtree_to(w.nodes[t], best);
+                }
+                h[0].nodes.assign(1, w.nodes[0]);
+                h[0].lo = w.lo;
+                h[0].cnt = w.cnt;
+            }
+            else if (ideal0 >= 1.0)
+            {
+                // proportional: the heaviest subtree gets its share of the ranks (rounded), the others share the rest
+                const int c0 = std::max(1, std::min(w.cnt - 1, (int)std::floor(ideal0 + 0.5)));
+                h[0].nodes.assign(1, w.nodes[0]);
+                h[0].lo = w.lo;
+                h[0].cnt = c0;
+                h[1].nodes.assign(w.nodes.begin() + 1, w.nodes.end());
+                h[1].lo = w.lo + c0;
+                h[1].cnt = w.cnt - c0;
+            }
+            else
+            {
+                // every subtree is worth less than one rank: bisect the group, heaviest first to the half that is lighter
+                // per rank
+                h[0].lo = w.lo;
+                h[0].cnt = (w.cnt + 1) / 2;
+                h[1].lo = w.lo + h[0].cnt;
+                h[1].cnt = w.cnt - h[0].cnt;
+                double wt[2] = {0, 0};
+                for (u32 k : w.nodes)
+                {
+                    const int side = (wt[0] / h[0].cnt <= wt[1] / h[1].cnt) ? 0 : 1;
+                    h[side].nodes.push_back(k);
+                    wt[side] += sub[k];
+                }
+            }
+            todo.push_back(std::move(h[1]));
+            todo.push_back(std::move(h[0]));
+        }
+    }
+    else
+    {
+        // legacy maps: split the tree from the top until no remaining subtree carries more than 1/(8 nproc) of the work,
+        // give every remaining subtree to the least loaded rank, then place the separators split off on the way
+        const char *per_env = getenv("PANGULU_AMD_SUBTREES_PER_RANK");
+        const double per_rank = per_env ? atof(per_env) : 8.0;
+        const double target = total / (per_rank * (double)np);
+        auto cmp = [&](u32 a, u32 b)
+        { return sub[a] < sub[b] || (sub[a] == sub[b] && a > b); };
+        std::priority_queue<u32, std::vector<u32>, decltype(cmp)> pq(cmp);
+        for (u32 k = 0; k < nbk; k++)
+            if (parent[k] == NONE)
+                pq.push(k);
+        while (!pq.empty() && sub[pq.top()] > target)
+        {
+            u32 k = pq.top();
+            pq.pop(); // stays block-cyclic
+            for (u32 c : kids[k])
+                pq.push(c);
+        }
+        while (!pq.empty())
+        {
+            u32 root = pq.top();
+            pq.pop();
+            whole_subtree_to(root, (int)(std::min_element(load.begin(), load.end()) - load.begin()));
+        }
         if (mode == "rank0")
         {
             for (u32 k = 0; k < nbk; k++)
@@ -249,14 +390,15 @@ void assign_subtrees(Solver &S)
                 }
         }
         else if (mode != "cyclic")
-            fatal("PANGULU_AMD_SEPARATOR_MAP must be path, cyclic or rank0");
+            fatal("PANGULU_AMD_SEPARATOR_MAP must be group, path, cyclic or rank0");
     }
     if (S.rank == 0 && getenv("PANGULU_AMD_TRACE"))
     {
         size_t top = 0;
         for (int h : S.home)
             top += h < 0;
-        fprintf(stderr, "[pangulu_amd trace] subtree mapping: %zu subtrees over %d ranks, %zu of %u block columns stay block-cyclic\n", nsub, S.nproc, top, nbk);
+        fprintf(stderr, "[pangulu_amd trace] mapping '%s': %zu whole subtrees over %d ranks, %zu of %u block columns distributed block-cyclic (%zu over rank groups)\n",
+                mode.c_str(), nsub, np, top, nbk, ndist);
     }
 }
 
@@ -321,10 +463,15 @@ void preprocess(Solver &S, const CscMatrix &A)
         off[i + 1] = place(record_bytes(nb, P.diag_upper_nnz[k], false));
     }
     st.arena_bytes = cursor ? cursor : 64;
+    S.info.nblocks_owned = st.owned.size();
+    S.info.owned_bytes = st.arena_bytes;
+    const bool analysis_only = S.analysis_only;
+    if (analysis_only)
+        st.arena_bytes = 64; // no records: mapping, counters and models only (PANGULU_AMD_ANALYSIS_ONLY)
     if (posix_memalign((void **)&st.harena, 64, st.arena_bytes) != 0)
         fatal("host arena allocation of %zu bytes failed", st.arena_bytes);
     memset(st.harena, 0, st.arena_bytes);
-    if (plat.host_memory)
+    if (plat.host_memory || analysis_only)
     {
         st.darena = st.harena;
     }
@@ -340,7 +487,7 @@ void preprocess(Solver &S, const CscMatrix &A)
     S.slot_of.assign(nblk, nullptr);
     S.diag_lower.assign(nbk, nullptr);
     S.diag_upper.assign(nbk, nullptr);
-    for (size_t i = 0; i < owned_bidx.size(); i++)
+    for (size_t i = 0; i < owned_bidx.size() && !analysis_only; i++)
     {
         u64 b = owned_bidx[i];
         u32 br = P.rowidx[b];
@@ -355,7 +502,7 @@ void preprocess(Solver &S, const CscMatrix &A)
         bind_record(s, nb, P.nnz[b], st.harena + off[i], st.device_ptr(off[i]), br > bc, false);
         S.slot_of[b] = &s;
     }
-    for (size_t d = 0; d < owned_diag.size(); d++)
+    for (size_t d = 0; d < owned_diag.size() && !analysis_only; d++)
     {
         u32 k = owned_diag[d];
         size_t i = owned_bidx.size() + 2 * d;
@@ -373,20 +520,17 @@ void preprocess(Solver &S, const CscMatrix &A)
         S.diag_lower[k] = &lo;
         S.diag_upper[k] = &up;
     }
-    S.info.nblocks_owned = st.owned.size();
-    S.info.owned_bytes = st.arena_bytes;
-
     // ---- patterns: one sweep per block column over the symbolic lower pattern ------------------------
     // lower block (br, bc), br > bc, is needed by its owner (CSC + CSR view) and by the owner of the upper
     // block (bc, br), whose CSC is the transpose.
-#pragma omp parallel
+#pragma omp parallel if (!analysis_only)
     {
         std::vector<i64> local_of(nbk, -1);      // block row -> position in this column's lower block list
         std::vector<std::vector<pangulu_inblock_idx>> tmp_ri;
         std::vector<std::vector<pangulu_inblock_ptr>> tmp_cp;
         std::vector<u32> cursor_nnz;
 #pragma omp for schedule(dynamic, 2)
-        for (i64 bc_ = 0; bc_ < (i64)nbk; bc_++)
+        for (i64 bc_ = 0; bc_ < (analysis_only ? (i64)0 : (i64)nbk); bc_++)
         {
             u32 bc = (u32)bc_;
             u64 l0 = P.lcolptr[bc], l1 = P.lcolptr[bc + 1];
@@ -487,7 +631,7 @@ void preprocess(Solver &S, const CscMatrix &A)
     // ---- values: scatter the permuted A into the owned patterns (zero elsewhere) ----------------------
     // (the reference's pangulu_convert_block_fill_value_to_struct, src/pangulu_conversion.c:241-350)
 #pragma omp parallel for schedule(dynamic, 256)
-    for (i64 j_ = 0; j_ < (i64)n; j_++)
+    for (i64 j_ = 0; j_ < (analysis_only ? (i64)0 : (i64)n); j_++)
     {
         u32 j = (u32)j_, bj = j / nb, c = j % nb;
         for (u64 p = A.colptr[j]; p < A.colptr[j + 1]; p++)
@@ -699,7 +843,7 @@ void preprocess(Solver &S, const CscMatrix &A)
     // ---- receive bins (src/pangulu_preprocessing.c:319-366) -------------------------------------------
     st.bins.clear();
     st.bins.resize(7);
-    if (S.nproc > 1)
+    if (S.nproc > 1 && !analysis_only)
     {
         // six size classes by nnz, as the reference: tiny, one entry per row/col x4, ~1% .. full
         u64 full = (u64)nb * nb;
@@ -780,7 +924,7 @@ void preprocess(Solver &S, const CscMatrix &A)
     }
 
     // ---- upload -------------------------------------------------------------------------------------------
-    if (!plat.host_memory)
+    if (!plat.host_memory && !analysis_only)
     {
         for (size_t c = 0; c < st.dchunks.size(); c++)
             plat.memcpy_(st.dchunks[c], st.harena + c * st.dchunk_bytes, st.chunk_len(c), 0);
@@ -796,7 +940,7 @@ void preprocess(Solver &S, const CscMatrix &A)
             plat.prepare_blocks((pangulu_inblock_idx)nb, offdiag.size(), offdiag.data());
         }
     }
-    if (world()->size > 1)
+    if (world()->size > 1 && !analysis_only)
         world()->register_arena(st.dchunks.data(), plat.host_memory ? 0 : st.dchunks.size(), st.dchunk_bytes, st.arena_bytes); // (collective)
     S.host_values_current = true;
 }

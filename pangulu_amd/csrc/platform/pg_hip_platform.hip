@@ -1615,6 +1615,51 @@ __global__ __launch_bounds__(256) void block_trsv_gather_kernel(const SolveBlkD 
     }
 }
 
+// y_dst += A x_src for a list of blocks (factor check: t = U 1, then y = L t): one workgroup per block, 16 lanes per
+// column (CSC record) or row (CSR record: upper diagonal half), floating-point atomics on y
+struct SpmvBlkD
+{
+    const u32 *ptr;
+    const u16 *idx;
+    const val_t *val;
+    u32 src, dst;
+    u32 csr, pad_;
+};
+__global__ __launch_bounds__(256) void block_spmv_add_kernel(const SpmvBlkD *__restrict__ blks, int nb, const val_t *__restrict__ x, val_t *__restrict__ y)
+{
+    const SpmvBlkD B = blks[blockIdx.x];
+    const val_t *xs = x + (size_t)B.src * nb;
+    val_t *yd = y + (size_t)B.dst * nb;
+    const int sub = threadIdx.x >> 4, l16 = threadIdx.x & 15, nsub = blockDim.x >> 4;
+    for (int c = sub; c < nb; c += nsub)
+    {
+        const u32 p0 = ptr0(B.ptr, c), p1 = B.ptr[c + 1];
+        if (p0 == p1)
+            continue;
+        if (!B.csr)
+        {
+            const val_t xc = xs[c];
+            for (u32 p = p0 + l16; p < p1; p += 16)
+                v_atomic_add(&yd[B.idx[p]], v_mul(B.val[p], xc));
+        }
+        else
+        {
+            val_t part = v_make(0);
+            for (u32 p = p0 + l16; p < p1; p += 16)
+            {
+                const val_t m = v_mul(B.val[p], xs[B.idx[p]]);
+#ifdef PANGULU_COMPLEX
+                part.re += m.re;
+                part.im += m.im;
+#else
+                part += m;
+#endif
+            }
+            v_atomic_add(&yd[c], part); // (16 partial sums per row)
+        }
+    }
+}
+
 // the diagonal halves of the level's block rows: one wavefront per row, the segment in LDS
 template <bool UPPER>
 __global__ __launch_bounds__(64) void block_trsv_level_kernel(const SolveRowD *__restrict__ rows, int nb, val_t *__restrict__ x)
@@ -3430,6 +3475,14 @@ extern "C"
             reset_block_states();
             return 0;
         }
+        case PANGULU_HIP_OPT_RECORDS_STREAM:
+        {
+            ensure_ready();
+            std::lock_guard<std::mutex> g(B.mutex);
+            join_records(B.stream); // (jobs already on the records stream are joined before the switch takes effect)
+            B.opt_records_stream = value;
+            return 0;
+        }
         default:
             return 1;
         }
@@ -3505,6 +3558,44 @@ extern "C"
         HIP_CHECK(hipFree(d_rows));
         HIP_CHECK(hipFree(d_blks));
         HIP_CHECK(hipFree(d_x));
+    }
+
+    void pangulu_platform_0201001_block_spmv_add(pangulu_inblock_idx nb, pangulu_uint64_t nblk, pangulu_storage_slot_t *const *slots,
+                                                 const pangulu_exblock_idx *src_seg, const pangulu_exblock_idx *dst_seg, const int *csr,
+                                                 const calculate_type *x, calculate_type *y, pangulu_uint64_t xlen)
+    {
+        ensure_ready();
+        std::lock_guard<std::mutex> g(B.mutex);
+        HIP_CHECK(hipSetDevice(B.device));
+        join_records(B.stream); // the sparse records of finished blocks are written on the records stream
+        std::vector<SpmvBlkD> hb(std::max<size_t>((size_t)nblk, 1));
+        for (size_t i = 0; i < (size_t)nblk; i++)
+        {
+            const slot_t *s = slots[i];
+            hb[i].ptr = csr[i] ? s->d_rowpointer : s->d_columnpointer;
+            hb[i].idx = csr[i] ? s->d_columnindex : s->d_rowindex;
+            hb[i].val = s->d_value;
+            hb[i].src = src_seg[i];
+            hb[i].dst = dst_seg[i];
+            hb[i].csr = csr[i] ? 1u : 0u;
+            hb[i].pad_ = 0;
+        }
+        SpmvBlkD *d_blks = nullptr;
+        val_t *d_x = nullptr, *d_y = nullptr;
+        HIP_CHECK(hipMalloc((void **)&d_blks, sizeof(SpmvBlkD) * hb.size()));
+        HIP_CHECK(hipMalloc((void **)&d_x, sizeof(val_t) * (size_t)xlen));
+        HIP_CHECK(hipMalloc((void **)&d_y, sizeof(val_t) * (size_t)xlen));
+        HIP_CHECK(hipMemcpyAsync(d_blks, hb.data(), sizeof(SpmvBlkD) * hb.size(), hipMemcpyHostToDevice, B.stream));
+        HIP_CHECK(hipMemcpyAsync(d_x, x, sizeof(val_t) * (size_t)xlen, hipMemcpyHostToDevice, B.stream));
+        HIP_CHECK(hipMemcpyAsync(d_y, y, sizeof(val_t) * (size_t)xlen, hipMemcpyHostToDevice, B.stream));
+        if (nblk)
+            hipLaunchKernelGGL(block_spmv_add_kernel, dim3((unsigned)nblk), dim3(256), 0, B.stream, d_blks, (int)nb, d_x, d_y);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(y, d_y, sizeof(val_t) * (size_t)xlen, hipMemcpyDeviceToHost, B.stream));
+        HIP_CHECK(hipStreamSynchronize(B.stream));
+        HIP_CHECK(hipFree(d_blks));
+        HIP_CHECK(hipFree(d_x));
+        HIP_CHECK(hipFree(d_y));
     }
 
     void *pangulu_platform_0201001_get_stream(void)

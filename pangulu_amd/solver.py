@@ -175,6 +175,16 @@ def factors_as_scipy(h):
     return L.tocsc(), U.tocsc()
 
 
+def factor_check(h):
+    """||L(U 1) - A 1||_2 / ||A 1||_2 on the factors where they are (the reference's pangulu_numeric_check,
+    src/pangulu_numeric.c:1082-1341); collective over the ranks."""
+    out = ctypes.c_double(0.0)
+    rc = h.lib.pangulu_amd_factor_check(h.ref, ctypes.byref(out))
+    if rc != 0:
+        raise RuntimeError("pangulu_amd_factor_check: the handle has not been factorised")
+    return float(out.value)
+
+
 def hip_stats(h_or_lib, reset=False):
     lib = h_or_lib.lib if isinstance(h_or_lib, Handle) else h_or_lib
     st = _lib.HipStats()

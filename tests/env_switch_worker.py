@@ -1,6 +1,7 @@
 """Child process of tests/test_gpu_env_switches.py: one mid-size factorisation on the HIP back-end with whatever back-end
 environment switches the parent set (they are read once per process), compared with the oracle.  Prints one JSON line."""
 import json
+import os
 import sys
 
 from pangulu_amd import matrices as M
@@ -11,12 +12,15 @@ from tests.helpers import factorize, lu_check, max_rel_diff, oracle_library
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "shell"
     mat = M.shell(60, 60) if which == "shell" else M.fem27(20)
-    gpu = factorize(mat, 256, "hip")
+    # PG_TEST_HIP_OPTIONS="6=0,3=0": back-end options (include/pangulu_platform.h) on top of the test defaults, e.g. the
+    # configuration bench.py times (COUNT_FLOPS = 0, PROFILE = 0)
+    opts = {int(k): int(v) for k, v in (kv.split("=") for kv in os.environ.get("PG_TEST_HIP_OPTIONS", "").split(",") if kv)}
+    gpu = factorize(mat, 256, "hip", hip_options=opts)
     ref = factorize(mat, 256, oracle_library("r64"))
     st = gpu["hip_stats"]
     print(json.dumps({
         "dL": max_rel_diff(gpu["L"], ref["L"]), "dU": max_rel_diff(gpu["U"], ref["U"]),
-        "residual": gpu["residual"], "lu_check": lu_check(mat, gpu),
+        "residual": gpu["residual"], "lu_check": lu_check(mat, gpu), "factor_check_device": gpu["factor_check"],
         "flop_counted": sum(v["flops"] for v in st.values()), "flop": gpu["info"]["flop"],
         "dense_updates": st["ssssm_dense_mfma"]["tasks"], "dense_solves": st["tstrf"]["dense_path_tasks"],
         "getrf_launches": st["getrf"]["launches"]}))

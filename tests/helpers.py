@@ -57,6 +57,7 @@ def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_fa
     if platform == "hip":
         out["hip_stats"] = pa.hip_stats(lib)
     out["perm"] = pa.permutation(h)
+    out["factor_check"] = pa.factor_check(h)  # the reference's numeric check on the factors where they are (device / host)
     if keep_factors:
         out["L"], out["U"] = pa.factors_as_scipy(h)
     if solve:
