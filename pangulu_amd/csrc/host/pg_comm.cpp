@@ -30,6 +30,7 @@ struct LoopbackComm : Comm
     bool probe_block(BlockHeader &, int &) override { return false; }
     void recv_block(slot_t *, const BlockHeader &, int) override {}
     void flush_sends() override {}
+    bool set_send_gate(Marker *) override { return true; } // nothing is ever sent (PANGULU_AMD_FORCE_MULTI_LOOP on one rank)
 };
 
 Comm *g_world = nullptr;

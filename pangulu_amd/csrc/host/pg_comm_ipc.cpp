@@ -219,7 +219,7 @@ struct IpcComm : SocketComm
     }
 
     // announcements can wait for a marker in the sender thread (the data itself never moves on this side)
-    bool set_send_gate(void *marker) override
+    bool set_send_gate(Marker *marker) override
     {
         if (!ipc_ok || !active_platform().marker_wait)
             return false;

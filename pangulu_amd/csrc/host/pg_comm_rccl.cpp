@@ -273,6 +273,33 @@ struct RcclComm : SocketComm
 
     int rccl_ranks() const override { return rccl_ok ? size : 0; }
 
+    // The ncclSend of a record is issued by the SENDER THREAD (SocketComm::sender_loop -> pass_gate), right before the
+    // announcement is written: per destination the sends are issued in announcement order, this communicator's send side is
+    // used by that one thread only, and the compute thread -- which posts under the scheduler's mutex -- never enters RCCL.
+    // Gate: instead of waiting on the host for the marker behind the producing kernels, the send stream waits for it
+    // (hipStreamWaitEvent: a Platform marker is a hipEvent_t on the back-end's stream): the transfer starts the moment the
+    // record is final, no host thread in between.
+    bool set_send_gate(Marker *marker) override
+    {
+        if (!rccl_ok)
+            return false;
+        send_gate = marker;
+        return true;
+    }
+
+    void pass_gate(SendReq &r, void *ev) override
+    {
+        if (!r.dev_ptr)
+        {
+            SocketComm::pass_gate(r, ev);
+            return;
+        }
+        HIPC(hipSetDevice(device));
+        if (ev)
+            HIPC(hipStreamWaitEvent(send_stream[(size_t)r.dst], (hipEvent_t)ev, 0));
+        NCCLC(R.Send(r.dev_ptr, r.dev_bytes, NCCL_CHAR, 1, send_comm[(size_t)r.dst], send_stream[(size_t)r.dst]));
+    }
+
     void isend_block(slot_t *s, const BlockHeader &h, int dst) override
     {
         if (!rccl_ok)
@@ -280,11 +307,9 @@ struct RcclComm : SocketComm
             SocketComm::isend_block(s, h, dst);
             return;
         }
-        // the caller has synchronised the compute stream: the record behind d_value is final
-        size_t bytes = h.bytes_lo;
-        post_announcement(dst, 1, h); // (never blocks; per-destination order = order of the ncclSends below)
-        HIPC(hipSetDevice(device));
-        NCCLC(R.Send((const char *)s->d_value - 32, bytes, NCCL_CHAR, 1, send_comm[(size_t)dst], send_stream[(size_t)dst]));
+        // (without a gate the caller has synchronised the compute stream: the record behind d_value is final)
+        const size_t bytes = h.bytes_lo;
+        post_announcement(dst, 1, h, (const char *)s->d_value - 32, bytes); // (never blocks)
         sent_bytes += bytes;
     }
 

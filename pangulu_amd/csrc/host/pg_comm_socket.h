@@ -83,9 +83,11 @@ struct SocketComm : Comm
         BlockHeader h;
         const char *payload;
         size_t payload_bytes;
-        void *gate = nullptr; // Platform marker that must have completed before this request leaves
+        Marker *gate = nullptr; // must have been recorded and have completed before this request leaves
+        const void *dev_ptr = nullptr; // device-to-device transports: the record in the owner's HBM (pg_comm_rccl.cpp)
+        size_t dev_bytes = 0;
     };
-    void *send_gate = nullptr;
+    Marker *send_gate = nullptr;
     std::deque<SendReq> sendq;
     std::mutex qmutex;
     std::condition_variable qcv, qdrained;
@@ -215,8 +217,20 @@ struct SocketComm : Comm
                 r = sendq.front();
                 sendq.pop_front();
             }
+            void *ev = nullptr;
             if (r.gate)
-                active_platform().marker_wait(r.gate); // (requests of one queue share ascending markers: mostly a no-op)
+            {
+                // the launcher thread records the marker when it reaches that point of the launch order
+                int spins = 0;
+                while (!(ev = r.gate->ev.load(std::memory_order_acquire)))
+                {
+                    if (++spins > 64)
+                        usleep(5);
+                    else
+                        std::this_thread::yield();
+                }
+            }
+            pass_gate(r, ev);
             {
                 std::lock_guard<std::mutex> g(wmutex[(size_t)r.dst]);
                 write_all(fd[(size_t)r.dst], &r.f, sizeof(Frame));
@@ -232,10 +246,19 @@ struct SocketComm : Comm
         }
     }
 
+    // Sender thread, before a request is written to its socket: by default wait, on the host, until the marker behind the
+    // producing kernels has completed (requests of one queue share ascending markers: mostly a no-op).  The RCCL transport
+    // overrides it: the wait becomes a stream dependency of the ncclSend it issues here.
+    virtual void pass_gate(SendReq & /*r*/, void *ev)
+    {
+        if (ev)
+            active_platform().marker_wait(ev);
+    }
+
     // header-only block frame through the sender thread: the compute thread posts it while holding the scheduler's
     // mutex and must never block on a full socket (the peer's receive thread may be waiting for ITS scheduler mutex,
     // held by a compute thread that is itself writing to us)
-    void post_announcement(int dst, u32 tag, const BlockHeader &h)
+    void post_announcement(int dst, u32 tag, const BlockHeader &h, const void *dev_ptr = nullptr, size_t dev_bytes = 0)
     {
         SendReq r;
         r.dst = dst;
@@ -244,6 +267,8 @@ struct SocketComm : Comm
         r.payload = nullptr;
         r.payload_bytes = 0;
         r.gate = send_gate;
+        r.dev_ptr = dev_ptr;
+        r.dev_bytes = dev_bytes;
         {
             std::lock_guard<std::mutex> g(qmutex);
             sendq.push_back(r);

@@ -199,6 +199,14 @@ struct BlockHeader // the 32-byte record header as it travels (src/pangulu_commu
 };
 static_assert(sizeof(BlockHeader) == 32, "record header is 32 bytes");
 
+// "Everything queued on the back-end up to a point of the scheduler's program order" as a handle that can be handed out
+// BEFORE the platform has recorded it: with the launcher thread (pg_numeric.cpp) the platform calls trail the scheduler,
+// and the launcher records the event (Platform::marker_record) when it gets there, in launch order.  `ev` is null until then.
+struct Marker
+{
+    std::atomic<void *> ev{nullptr};
+};
+
 class Comm
 {
 public:
@@ -224,10 +232,10 @@ public:
     virtual void recv_blocks_finish() {}
     // make sure everything posted has left (called before the slot memory may be reused / at the end)
     virtual void flush_sends() = 0;
-    // Blocks posted from now on may only leave once `marker` (Platform::marker_record) has completed; nullptr = at once.
-    // Returns false when the transport cannot defer (host staging copies the values at post time): the caller then
-    // has to drain the device itself before posting.
-    virtual bool set_send_gate(void * /*marker*/) { return false; }
+    // Blocks posted from now on may only leave once `marker` has been recorded (by the launcher thread, possibly later) and
+    // has completed; nullptr = at once.  Returns false when the transport cannot defer (host staging copies the values at
+    // post time): the caller then has to drain the launcher and the device itself before posting.
+    virtual bool set_send_gate(Marker * /*marker*/) { return false; }
     // collective: the device arena holding every record this rank owns (nullptr: records live in host memory);
     // transports that copy straight between arenas map their peers' here (pg_comm_ipc.cpp)
     virtual void register_arena(char *const * /*chunks*/, size_t /*nchunks*/, size_t /*chunk_bytes*/, size_t /*total_bytes*/) {}

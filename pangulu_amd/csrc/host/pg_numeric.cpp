@@ -19,6 +19,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <thread>
 #include <unistd.h>
 
@@ -148,20 +149,25 @@ struct Sched
     // multi-rank without draining the device after every batch: receive slots are handed back, and finished blocks
     // announced, once a marker recorded behind the kernels that use / produce them has completed
     bool use_markers = false;
-    void *last_marker = nullptr; // marker behind the most recent platform call (recorded on demand)
+    Marker *last_marker = nullptr; // marker behind the most recent platform call (created on demand)
+    std::deque<std::unique_ptr<Marker>> markers; // all markers of this factorisation (the transport's sender thread keeps pointers)
     struct Retired
     {
         slot_t *s;
-        void *marker;
+        Marker *marker;
     };
     std::deque<Retired> retired;
     double t_platform = 0, t_sched = 0;
     u64 batches = 0;
     bool multi;
-    // Single-rank runs on a device: the platform calls (descriptor building and launches) cost about as much host time
+    // Runs on a device: the platform calls (descriptor building and launches) cost about as much host time
     // as the scheduling itself, and nothing the scheduler does next depends on their return -- the back-end's streams
     // keep program order.  A launcher thread makes the calls in batch order while this thread releases successors and
-    // drains the next batch.  On by default (PANGULU_AMD_ASYNC_LAUNCH=0 turns it off): in round 1 the one-thread loop still
+    // drains the next batch.  Round 3: multi-rank runs too (one rank through the multi-rank loop took 70 ms against 44 ms
+    // for the bench matrix, and every rank of an N-GPU run paid that): what the scheduler needs from the device there are
+    // MARKERS -- "the blocks finished so far may be sent", "this receive slot is free again" -- and a marker is now a
+    // handle (Marker) the scheduler hands out at once while the launcher records the event behind it when it gets to that
+    // point of the launch order; the transport's sender thread and poll_retired() look at it only once it is there.  On by default (PANGULU_AMD_ASYNC_LAUNCH=0 turns it off): in round 1 the one-thread loop still
     // stayed ahead of the device; with the faster GETRF the leaf levels of the bench matrix became host-bound (the
     // device sat empty 10-19 ms of a 57 ms factorisation, mostly before the densify launch that follows a level's
     // GETRF) and the launcher thread brought 59.7-70.7 ms down to 52.0-52.4 ms on the same box.
@@ -169,12 +175,21 @@ struct Sched
     std::thread launcher;
     std::mutex lq_mutex;
     std::condition_variable lq_cv, lq_idle_cv;
-    std::deque<std::vector<task_t>> lq;
+    struct LItem
+    {
+        std::vector<task_t> tasks;
+        Marker *marker = nullptr; // non-null: record a platform marker here instead of running tasks
+    };
+    std::deque<LItem> lq;
     std::vector<std::vector<task_t>> lq_free;
+    bool forced_multi = false; // PANGULU_AMD_FORCE_MULTI_LOOP=1: one rank through the multi-rank loop (measurement aid)
     bool lq_stop = false, lq_busy = false;
 
     explicit Sched(Solver &s) : S(s), P(s.pat), plat(active_platform()), comm(world()), sent_flag((size_t)s.nproc, 0), multi(s.nproc > 1)
     {
+        if (const char *e = getenv("PANGULU_AMD_FORCE_MULTI_LOOP"))
+            forced_multi = atoi(e) != 0 && s.nproc == 1;
+        multi = multi || forced_multi;
         if (const char *e = getenv("PANGULU_AMD_LOOKAHEAD_MAX_GETRF"))
             lookahead_max_getrf = (size_t)atol(e);
         if (const char *e = getenv("PANGULU_AMD_PANEL_LOOKAHEAD"))
@@ -189,7 +204,7 @@ struct Sched
             stall_limit_s = atof(e);
         use_markers = multi && !plat.host_memory && plat.marker_record && plat.marker_done && plat.marker_wait && !getenv("PANGULU_AMD_SYNC_EVERY_BATCH");
         const char *al = getenv("PANGULU_AMD_ASYNC_LAUNCH");
-        async_launch = !multi && !plat.host_memory && !(al && atoi(al) == 0);
+        async_launch = !plat.host_memory && !(al && atoi(al) == 0) && (!multi || use_markers);
         if (async_launch)
             launcher = std::thread([this]()
                                    { launcher_loop(); });
@@ -217,18 +232,27 @@ struct Sched
                        { return lq_stop || !lq.empty(); });
             if (lq.empty())
                 return; // (stop requested and nothing left)
-            std::vector<task_t> tasks = std::move(lq.front());
+            LItem item = std::move(lq.front());
             lq.pop_front();
             lq_busy = true;
             lk.unlock();
-            double t0 = wall_seconds();
-            plat.hybrid_batched((pangulu_inblock_idx)S.nb, tasks.size(), tasks.data());
-            double dt = wall_seconds() - t0;
+            double dt = 0;
+            if (item.marker)
+                item.marker->ev.store(plat.marker_record(), std::memory_order_release);
+            else
+            {
+                double t0 = wall_seconds();
+                plat.hybrid_batched((pangulu_inblock_idx)S.nb, item.tasks.size(), item.tasks.data());
+                dt = wall_seconds() - t0;
+            }
             lk.lock();
             t_platform += dt;
             lq_busy = false;
-            tasks.clear();
-            lq_free.push_back(std::move(tasks));
+            if (!item.marker)
+            {
+                item.tasks.clear();
+                lq_free.push_back(std::move(item.tasks));
+            }
             if (lq.empty())
                 lq_idle_cv.notify_all();
         }
@@ -559,9 +583,12 @@ struct Sched
             copy.assign(tasks.begin(), tasks.end());
             {
                 std::lock_guard<std::mutex> g(lq_mutex);
-                lq.push_back(std::move(copy));
+                LItem item;
+                item.tasks = std::move(copy);
+                lq.push_back(std::move(item));
             }
             lq_cv.notify_one();
+            last_marker = nullptr;
             return;
         }
         double t0 = wall_seconds();
@@ -570,11 +597,34 @@ struct Sched
         last_marker = nullptr;
     }
 
-    void *current_marker()
+    // a marker behind every platform call issued so far (in the scheduler's order); with the launcher thread the event
+    // behind it is recorded when the launcher gets there
+    Marker *current_marker()
     {
-        if (!last_marker)
-            last_marker = plat.marker_record();
+        if (last_marker)
+            return last_marker;
+        markers.emplace_back(new Marker());
+        last_marker = markers.back().get();
+        if (async_launch)
+        {
+            {
+                std::lock_guard<std::mutex> g(lq_mutex);
+                LItem item;
+                item.marker = last_marker;
+                lq.push_back(std::move(item));
+            }
+            lq_cv.notify_one();
+        }
+        else
+            last_marker->ev.store(plat.marker_record(), std::memory_order_release);
         return last_marker;
+    }
+
+    // the device has finished everything the scheduler has issued (launcher included)
+    void drain_device()
+    {
+        drain_launcher();
+        plat.synchronize();
     }
 
     // a receive slot whose last consumer has been queued on the device: back to its bin once that work is done
@@ -590,8 +640,11 @@ struct Sched
 
     void poll_retired()
     {
-        while (!retired.empty() && plat.marker_done(retired.front().marker))
+        while (!retired.empty())
         {
+            void *ev = retired.front().marker->ev.load(std::memory_order_acquire);
+            if (!ev || !plat.marker_done(ev))
+                break;
             S.storage.recycle(retired.front().s);
             retired.pop_front();
         }
@@ -636,7 +689,7 @@ struct Sched
                     {
                         if (!synced)
                         {
-                            plat.synchronize();
+                            drain_device();
                             synced = true;
                         }
                         retire(S.slot_of[b]);
@@ -730,7 +783,7 @@ struct Sched
             // finished blocks are about to be announced: either the transport holds the announcements back until a
             // marker behind this batch has completed, or the device is drained here
             if (!(use_markers && comm->set_send_gate(current_marker())))
-                plat.synchronize();
+                drain_device();
         }
         SEC(2)
         // (3) successor release
@@ -1030,7 +1083,7 @@ void numeric_factorize(Solver &S)
         }
     }
     S.host_values_current = plat.host_memory;
-    if (S.nproc > 1)
+    if (S.nproc > 1 || sch.forced_multi)
     {
         std::thread worker([&]()
                            { sch.compute_loop(); });
