@@ -27,6 +27,12 @@ src/pangulu_numeric.c:1082-1341) are taken from the factors of the LAST TIMED st
 times come from one extra, un-timed factorisation with every launch on one stream between two events (no queueing).
 cpu_baseline legs (the oracle = CPU restatement of the reference's CPU platform, sampled) run in child processes after
 the GPU steps, so nothing they do can take the GPU result with it.
+
+Process layout: every rank process is a SUPERVISOR that never touches the GPU.  It starts the GPU worker (this file with
+--gpu-worker) as a fresh child, and if that fails -- a transport that passes its start-up self-test and then stalls or
+crashes: the RCCL plane has never run on real links in the builder's hands -- every rank's supervisor starts a new worker
+with the next transport of the order rccl -> ipc -> host (workers end behind a common barrier, so the ranks agree on
+success).  Then the cpu_baseline children, then rank 0 prints the one JSON line.
 """
 import argparse
 import ctypes
@@ -70,6 +76,11 @@ def parse_args(argv=None):
                     help="block exchange for --gpus > 1: auto = rccl (ncclSend/ncclRecv per ordered pair over xGMI), else ipc (the "
                          "consumer pulls each record out of the owner's HBM arena with one peer copy), else host-staged TCP: each is "
                          "verified by a self-test at start-up and all ranks fall back together; the line says what ran")
+    ap.add_argument("--worker-timeout", type=int, default=2400, help="seconds a GPU worker may take before its supervisor gives it up")
+    # internal: the GPU part of one rank (started by the supervisor below)
+    ap.add_argument("--gpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--last-attempt", action="store_true", help=argparse.SUPPRESS)
     # internal: one rank of a cpu_baseline leg (started by run_cpu_leg below)
     ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-leg-port", type=int, default=0, help=argparse.SUPPRESS)
@@ -309,12 +320,106 @@ def leg_summary(res, cores, workload):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# supervisor: one per rank, never touches the GPU
+# ---------------------------------------------------------------------------------------------------------------------
+DONE_MARK = "__PG_WORKER_DONE__"
+RC_TRANSPORT_UNAVAILABLE = 3
+
+
+def passthrough_args(args):
+    out = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--nb", str(args.nb),
+           "--ordering", args.ordering, "--host-threads", str(args.host_threads)]
+    if args.size:
+        out += ["--size"] + [str(x) for x in args.size]
+    if args.mtx:
+        out += ["--mtx", args.mtx]
+    if args.rhs:
+        out += ["--rhs", args.rhs]
+    if args.no_profile_pass:
+        out.append("--no-profile-pass")
+    return out
+
+
+def supervisor(args):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    args.gpus = world
+    order = {"auto": ["rccl", "ipc", "host"], "rccl": ["rccl"], "ipc": ["ipc"], "host": ["host"]}[args.transport] if world > 1 else ["none"]
+    line, meta, attempts = None, None, []
+    for k, tr in enumerate(order):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpu-worker", "--transport", tr if tr != "none" else "auto", "--attempt", str(k)] + passthrough_args(args)
+        if k + 1 == len(order):
+            cmd.append("--last-attempt")
+        t0 = time.time()
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+        done, line, meta = False, None, None
+        try:
+            out, _ = proc.communicate(timeout=args.worker_timeout)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            out, _ = proc.communicate()
+            sys.stderr.write("[bench.py] rank %d: GPU worker with transport %s exceeded %d s\n" % (rank, tr, args.worker_timeout))
+        for ln in (out or "").splitlines():
+            if ln.startswith('{"metric"'):
+                line = json.loads(ln)
+            elif ln.startswith('{"pg_worker"'):
+                meta = json.loads(ln)["pg_worker"]
+            elif ln.strip() == DONE_MARK:
+                done = True
+            elif ln.strip():
+                sys.stderr.write(ln + "\n")
+        attempts.append({"transport": tr, "rc": proc.returncode, "done": done, "s": round(time.time() - t0, 1)})
+        if done and (rank != 0 or line is not None):
+            break
+        sys.stderr.write("[bench.py] rank %d: GPU worker with transport %s did not finish (rc %s)%s\n" % (
+            rank, tr, proc.returncode, "; trying the next transport" if k + 1 < len(order) else ""))
+        line = None
+    if line is None and rank == 0 or meta is None:
+        sys.exit(1)
+
+    # cpu_baseline LAST, in child processes (measured before the GPU steps, ten seconds of host-only work left them 15 %
+    # slower).  N = 1: one rank x one thread.  N > 1: R = N ranks x one thread (every rank starts its own child; SURVEY §8d,
+    # examples/example.c:284) and then 1 x 1 on rank 0.
+    cpu = None
+    if not args.no_cpu_baseline:
+        flop = float(meta["flop"])
+        stride = args.cpu_sample_stride or max(1, int(round(flop / (CPU_GFLOPS_GUESS * 1e9 * 12.0))))
+        legs = {}
+        if world > 1:
+            p = run_cpu_leg(args, world, rank, int(meta["base_port"]) + 700, stride)
+            res = finish_cpu_leg(p, args.cpu_leg_timeout, rank == 0)
+            if rank == 0:
+                legs["ranks_x_1"] = leg_summary(res, world, meta["workload"])
+        if rank == 0:
+            p = run_cpu_leg(args, 1, 0, 0, stride)
+            legs["1_x_1"] = leg_summary(finish_cpu_leg(p, args.cpu_leg_timeout, True), 1, meta["workload"])
+            # the contract's object = the leg with as many ranks as GPUs; the other one beside it
+            cpu = dict(legs.get("ranks_x_1") or legs["1_x_1"])
+            cpu["cpu_model"] = cpu_model_name()
+            cpu["host_cores"] = os.cpu_count()
+            if world > 1:
+                cpu["one_rank_x_one_thread"] = legs["1_x_1"]
+    if rank == 0:
+        line["cpu_baseline"] = cpu
+        line["config"]["worker_attempts"] = attempts
+        print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse_args()
     if args.cpu_leg:
         return cpu_leg_main(args)
+    if args.gpu_worker:
+        return gpu_worker_main(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
+    return supervisor(args)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the GPU part of one rank
+# ---------------------------------------------------------------------------------------------------------------------
+def gpu_worker_main(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -347,19 +452,23 @@ def main():
         base_port = int(os.environ.get("MASTER_PORT", "29500")) + 23
         if base_port + 1024 >= 32768:  # keep the solver's listeners (base_port + rank, + 64 per attempt) out of the ephemeral port range
             base_port = 20000 + (base_port * 7) % 8000
-        # auto: rccl first (north star: MPI point-to-point -> RCCL send/recv over xGMI); it self-tests on every pair and all
-        # ranks agree on the outcome; if it is not there the same ranks try peer copies, then host staging
-        order = {"auto": ["rccl", "ipc", "host"], "rccl": ["rccl"], "ipc": ["ipc"], "host": ["host"]}[args.transport]
+        # one transport per worker: the supervisors walk the order rccl (north star: MPI point-to-point -> RCCL send/recv over
+        # xGMI) -> ipc -> host.  Each device transport self-tests on every pair at start-up and all ranks agree on the outcome;
+        # if it is not there the library falls back to host staging on all ranks together -- this worker then ends (all of
+        # them do) and the supervisors start the next one, unless this was the last.
         codes = {"host": _lib.TRANSPORT_HOST, "rccl": _lib.TRANSPORT_RCCL, "ipc": _lib.TRANSPORT_IPC}
+        name = args.transport if args.transport != "auto" else "rccl"
         t_comm = time.time()
-        for k, name in enumerate(order):
-            rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port + 64 * k, codes[name], None)
-            assert rc == 0
-            got = {0: "host", 1: "rccl", 2: "ipc"}[lib.pangulu_amd_comm_transport()]
-            tried.append("%s->%s" % (name, got))
-            if got == name or k + 1 == len(order):
-                break
-            lib.pangulu_amd_comm_finalize()  # (all ranks saw the same fall-back: they all move on to the next one)
+        base_port += 128 * args.attempt
+        rc = lib.pangulu_amd_comm_init(rank, world, addr.encode(), base_port, codes[name], None)
+        assert rc == 0
+        got = {0: "host", 1: "rccl", 2: "ipc"}[lib.pangulu_amd_comm_transport()]
+        tried.append("%s->%s" % (name, got))
+        if got != name and not args.last_attempt:
+            lib.pangulu_amd_comm_barrier()
+            sys.stderr.write("[bench.py] rank %d: transport %s is not available here (self-test failed on some rank)\n" % (rank, name))
+            sys.stderr.flush()
+            os._exit(RC_TRANSPORT_UNAVAILABLE)
         comm_init_s = time.time() - t_comm
 
     if rank == 0:
@@ -507,29 +616,6 @@ def main():
         lib.pangulu_amd_comm_barrier()
         lib.pangulu_amd_comm_finalize()
 
-    # cpu_baseline LAST, in child processes (measured before the GPU steps, ten seconds of host-only work left them 15 %
-    # slower).  N = 1: one rank x one thread.  N > 1: R = N ranks x one thread (every rank starts its own child; SURVEY §8d,
-    # examples/example.c:284) and then 1 x 1 on rank 0.
-    cpu = None
-    if not args.no_cpu_baseline:
-        stride = args.cpu_sample_stride or max(1, int(round(flop / (CPU_GFLOPS_GUESS * 1e9 * 12.0))))
-        legs = {}
-        if world > 1:
-            p = run_cpu_leg(args, world, rank, base_port + 512, stride)
-            res = finish_cpu_leg(p, args.cpu_leg_timeout, rank == 0)
-            if rank == 0:
-                legs["ranks_x_1"] = leg_summary(res, world, workload)
-        if rank == 0:
-            p = run_cpu_leg(args, 1, 0, 0, stride)
-            legs["1_x_1"] = leg_summary(finish_cpu_leg(p, args.cpu_leg_timeout, True), 1, workload)
-            # the contract's object = the leg with as many ranks as GPUs; the other one beside it
-            main_leg = legs.get("ranks_x_1") or legs["1_x_1"]
-            cpu = dict(main_leg)
-            cpu["cpu_model"] = cpu_model_name()
-            cpu["host_cores"] = os.cpu_count()
-            if world > 1:
-                cpu["one_rank_x_one_thread"] = legs["1_x_1"]
-
     if rank == 0:
         value = flop / (ms_per_step / 1e3) / 1e9 if ms_per_step else 0.0
         sep_map = os.environ.get("PANGULU_AMD_SEPARATOR_MAP", "group")
@@ -566,9 +652,12 @@ def main():
             "roofline": roofline,
             "model": model,
             "kernels": kernels,
-            "cpu_baseline": cpu,
+            "cpu_baseline": None,  # (filled in by the supervisor)
         }
         print(json.dumps(line), flush=True)
+    # every rank: what the supervisor needs for the cpu_baseline legs, and the mark that this worker ended behind the final barrier
+    print(json.dumps({"pg_worker": {"flop": flop, "base_port": base_port, "workload": workload}}), flush=True)
+    print(DONE_MARK, flush=True)
 
 
 if __name__ == "__main__":

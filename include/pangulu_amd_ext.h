@@ -54,8 +54,9 @@ extern "C"
     /* perm[new] = old, length n; copied */
     void pangulu_amd_set_user_perm(const sparse_index_t *perm, sparse_index_t n);
     /* optional vertex coordinates (dim = 2 or 3, n*dim doubles, vertex-major) turn ORDER_ND into a geometric
-     * dissection; copied.  All analysis options are one-shot: the next pangulu_init consumes them and the defaults
-     * (ORDER_ND, no permutation, no coordinates, device-resident numeric phase) apply again afterwards */
+     * dissection; copied.  What belongs to ONE matrix is one-shot: the next pangulu_init consumes the user permutation and
+     * the coordinates (ORDER_USER then falls back to ORDER_ND).  The choices -- ordering kind, scaling, eager host mirror --
+     * stay as set until changed; pangulu_amd_reset_options() restores all defaults */
     void pangulu_amd_set_coordinates(const double *xyz, sparse_index_t n, int dim);
     /* 0 (default): device-resident numeric phase, factors downloaded once when gstrs / block export needs
      * them.  1: reference behaviour, every finished panel block is copied back to the host at once. */
@@ -67,6 +68,7 @@ extern "C"
      * to b and x.  Default 0 (the reference's default build has no MC64 either); environment PANGULU_AMD_SCALING
      * overrides.  A structurally singular input leaves the matrix unscaled, with a warning. */
     void pangulu_amd_set_scaling(int on);
+    void pangulu_amd_reset_options(void);
 
     /* ---- introspection -------------------------------------------------------------------------------- */
     typedef struct pangulu_amd_info_t

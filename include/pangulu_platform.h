@@ -250,6 +250,12 @@ extern "C"
      *     0 keeps them on the main stream.  bench.py's profile pass turns it (and TWO_STREAMS) off so that the hipEvent
      *     pair around a launch brackets that kernel and nothing else. */
 #define PANGULU_HIP_OPT_RECORDS_STREAM 13
+    /*   PANGULU_HIP_OPT_BACKGROUND_UPDATES (default 1; environment PANGULU_HIP_BACKGROUND_UPDATES at start-up): in a
+     *     dependency-free call (ASSUME_INDEPENDENT) that carries diagonal factorisations and updates but no panel solves --
+     *     the native scheduler's look-ahead -- the update kernels run on a background stream that the main stream does not
+     *     join at the end of the call; a later call that touches one of their destinations waits for them first.  0: the
+     *     round-2 layout (GETRFs on a side stream, everything joined at the end of the call). */
+#define PANGULU_HIP_OPT_BACKGROUND_UPDATES 14
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an

@@ -178,6 +178,7 @@ def load(vtype="r64", test_hooks=False):
     lib.pangulu_amd_set_eager_host_mirror.restype = None
     lib.pangulu_amd_set_scaling.argtypes = [ctypes.c_int]
     lib.pangulu_amd_set_scaling.restype = None
+    lib.pangulu_amd_reset_options.restype = None
     lib.pangulu_amd_get_info.argtypes = [vpp, ctypes.POINTER(Info)]
     lib.pangulu_amd_get_info.restype = None
     lib.pangulu_amd_model_roofline.argtypes = [vpp, ctypes.c_double, ctypes.c_double]
@@ -232,6 +233,7 @@ HIP_OPT_TWO_STREAMS = 10
 HIP_OPT_SMALL_LAUNCH_TASKS = 11
 HIP_OPT_XCD_SWIZZLE = 12
 HIP_OPT_RECORDS_STREAM = 13
+HIP_OPT_BACKGROUND_UPDATES = 14
 
 ORDER_IDENTITY, ORDER_ND, ORDER_USER = 0, 1, 2
 TRANSPORT_HOST, TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1, 2

@@ -301,6 +301,7 @@ extern "C"
     }
     void pangulu_amd_set_eager_host_mirror(int on) { pending_options().eager_host_mirror = on != 0; }
     void pangulu_amd_set_scaling(int on) { pending_options().scaling = on != 0; }
+    void pangulu_amd_reset_options(void) { pending_options() = Options(); }
 
     // ----------------------------------------------------------------------------------------------------
     void pangulu_init(sparse_index_t pangulu_n, sparse_pointer_t pangulu_nnz, sparse_pointer_t *csc_colptr,
@@ -351,7 +352,9 @@ extern "C"
             int dev = lr ? atoi(lr) % ndev : rank % ndev;
             plat.set_default_device(dev);
         }
-        NearDevice near(plat); // analysis + record upload from the device's NUMA node (host arena, pinned staging)
+        // (no NUMA binding here: the analysis runs on all cores with OpenMP, and pool workers created under a narrowed mask
+        // would keep it for good -- the host application's own OpenMP regions included.  Only the latency-critical threads of
+        // pangulu_gstrf / pangulu_gstrs, scheduler and launcher, are kept next to the device, for the duration of the call.)
 
         Solver *S = new Solver();
         memset(&S->info, 0, sizeof(S->info));
@@ -470,14 +473,15 @@ extern "C"
         comm->bcast(&np, sizeof(np), 0);
         S->perm.resize(np);
         comm->bcast(S->perm.data(), sizeof(u32) * np, 0);
-        // one-shot analysis options: the next pangulu_init starts from the defaults again (a stale user permutation of
-        // the same length would otherwise be applied silently)
+        // one-shot: the data that belongs to ONE matrix -- a stale user permutation or coordinate array of the same length
+        // would otherwise be applied silently to the next one (ORDER_USER falls back to the default ordering with them).
+        // Sticky until changed: the choices -- ordering kind, scaling, eager host mirror (pangulu_amd_reset_options()
+        // restores the defaults).
         opt.coords.clear();
         opt.coord_dim = 0;
         opt.user_perm.clear();
-        opt.scaling = false;
-        opt.ordering = PANGULU_AMD_ORDER_ND;
-        opt.eager_host_mirror = false;
+        if (opt.ordering == PANGULU_AMD_ORDER_USER)
+            opt.ordering = PANGULU_AMD_ORDER_ND;
         S->n = (u32)np;
         S->nbk = (S->n + S->nb - 1) / S->nb;
         S->info.n_padded = S->n;

@@ -137,6 +137,7 @@ struct Sched
     std::vector<task_t> batch, ssssm_batch, combined;
     size_t lookahead_max_getrf = 128; // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
     bool panel_lookahead_on = true;   // PANGULU_AMD_PANEL_LOOKAHEAD (0 disables)
+    bool panel_first_on = true;       // PANGULU_AMD_PANEL_FIRST (0: round 2's order, panel-tile updates inside the look-ahead call)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
     double gather_max_s = 600e-6, gather_quiet_s = 60e-6, t_gather = 0, t_idle = 0, t_work = 0;
@@ -194,6 +195,8 @@ struct Sched
             lookahead_max_getrf = (size_t)atol(e);
         if (const char *e = getenv("PANGULU_AMD_PANEL_LOOKAHEAD"))
             panel_lookahead_on = atoi(e) != 0;
+        if (const char *e = getenv("PANGULU_AMD_PANEL_FIRST"))
+            panel_first_on = atoi(e) != 0;
         if (const char *e = getenv("PANGULU_AMD_GATHER_MIN_BATCH"))
             gather_min_batch = (size_t)atol(e);
         if (const char *e = getenv("PANGULU_AMD_GATHER_MAX_US"))
@@ -720,29 +723,53 @@ struct Sched
         t_sec[i_] += now_ - t_s;           \
         t_s = now_;                        \
     }
-        // (1) every update queued on a tile of this drain runs first, as one batch
+        // A few diagonal factorisations on their own leave the device almost idle (one workgroup each): every update
+        // queued anywhere else goes into the same call (2), the back-end runs the two kinds side by side ("look-ahead")
+        bool all_getrf = true;
+        for (auto &t : batch)
+            all_getrf = all_getrf && t.kernel_id == PANGULU_TASK_GETRF;
+        const bool lookahead_shape = all_getrf && batch.size() <= lookahead_max_getrf;
+        // the panel tiles of the levels being factorised: the blocks below and right of each diagonal block
+        auto for_panel_tiles = [&](auto &&fn)
+        {
+            for (auto &t : batch)
+            {
+                const u32 k = t.task_level;
+                for (u64 b = P.first_after_diag[k]; b < P.colptr[k + 1]; b++)
+                    if (S.slot_of[b] && S.owner(P.rowidx[b], k) == S.rank)
+                        fn(tile_index(S.slot_of[b]));
+                for (u64 r = P.first_after_diag_csr[k]; r < P.rowptr[k + 1]; r++)
+                {
+                    const u64 b = P.csr_to_csc[r];
+                    if (S.slot_of[b] && S.owner(k, P.colidx[r]) == S.rank)
+                        fn(tile_index(S.slot_of[b]));
+                }
+            }
+        };
+        // (1) every update queued on a tile of this drain runs first, as one batch.  With a look-ahead call coming, the
+        // updates queued on the PANEL tiles of these levels go here too (round 3): they are what the panel solves of the next
+        // drain wait for, and keeping them out of the big look-ahead call lets the back-end run that one in the background,
+        // beside the factorisations AND the solves that follow (pangulu_platform.h, PANGULU_HIP_OPT_BACKGROUND_UPDATES).
         {
             std::lock_guard<std::mutex> g(S.info_mutex);
             for (auto &t : batch)
                 take_pending(tile_index(t.opdst));
+            if (lookahead_shape && panel_first_on && S.pending_total != 0)
+                for_panel_tiles([&](u32 tile)
+                                { take_pending(tile); });
             if (S.pending_dirty.size() > 4096)
                 rebuild_dirty_list();
         }
         run_updates_and_release_operands();
         SEC(0)
-        // (2) the panel tasks themselves.  A few diagonal factorisations on their own leave the device almost idle
-        // (one workgroup each): every update queued anywhere else goes into the same call, the back-end runs the
-        // two kinds side by side
-        bool all_getrf = S.pending_total != 0;
-        for (auto &t : batch)
-            all_getrf = all_getrf && t.kernel_id == PANGULU_TASK_GETRF;
-        const bool lookahead = all_getrf && batch.size() <= lookahead_max_getrf;
+        // (2) the panel tasks themselves
+        const bool lookahead = lookahead_shape && S.pending_total != 0;
         // A larger batch of diagonal factorisations: the updates queued on the PANEL tiles of these levels (the blocks
         // below and right of each diagonal block) do not depend on the factorisations either -- every one of them was
         // queued before the diagonal block became ready (same descendants, src/pangulu_numeric.c:436-601) -- and the
         // panel solves are what follows.  They run beside the GETRFs instead of between them and the solves; unlike the
         // flush above this creates no extra pass over any tile.
-        const bool panel_lookahead = all_getrf && !lookahead && panel_lookahead_on;
+        const bool panel_lookahead = all_getrf && !lookahead_shape && panel_lookahead_on && S.pending_total != 0;
         if (lookahead || panel_lookahead)
         {
             {
@@ -754,21 +781,8 @@ struct Sched
                     S.pending_dirty.clear();
                 }
                 else
-                {
-                    for (auto &t : batch)
-                    {
-                        const u32 k = t.task_level;
-                        for (u64 b = P.first_after_diag[k]; b < P.colptr[k + 1]; b++)
-                            if (S.slot_of[b] && S.owner(P.rowidx[b], k) == S.rank)
-                                take_pending(tile_index(S.slot_of[b]));
-                        for (u64 r = P.first_after_diag_csr[k]; r < P.rowptr[k + 1]; r++)
-                        {
-                            const u64 b = P.csr_to_csc[r];
-                            if (S.slot_of[b] && S.owner(k, P.colidx[r]) == S.rank)
-                                take_pending(tile_index(S.slot_of[b]));
-                        }
-                    }
-                }
+                    for_panel_tiles([&](u32 tile)
+                                    { take_pending(tile); });
             }
             combined.assign(batch.begin(), batch.end());
             combined.insert(combined.end(), ssssm_batch.begin(), ssssm_batch.end());

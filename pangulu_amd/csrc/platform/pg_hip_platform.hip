@@ -33,6 +33,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <unordered_set>
+#include <unordered_set>
 #include <vector>
 
 #include "../../../include/pangulu_platform.h"
@@ -1756,6 +1757,7 @@ struct EventPair
 {
     hipEvent_t a, b;
     int cls;
+    unsigned long long tag[3]; // per-launch log (PANGULU_HIP_LAUNCH_LOG): workgroups, tasks, live 128 x 128 x 16 slab steps
 };
 
 struct Backend
@@ -1775,6 +1777,18 @@ struct Backend
     hipStream_t stream_rec = nullptr;
     hipEvent_t ev_rec_fork = nullptr, ev_rec = nullptr;
     std::atomic<bool> rec_dirty{false};
+    // Background stream (round 3): in a call that carries diagonal factorisations AND updates (the scheduler's look-ahead:
+    // the GETRFs of the next level(s) together with every update queued anywhere), the updates are the trailing-matrix
+    // work of the previous level and nothing on the critical path -- next panel's updates, GETRF, panel solves -- depends
+    // on them.  They go to this stream and the main stream does NOT join at the end of the call: the solves of the next
+    // panel (the following call) run beside them instead of behind them (fem27(112): the dense solves ran ALONE on the
+    // device for 65 of 974 ms).  The destinations of the launches in flight are remembered; the first later call that
+    // touches one of them -- as destination or operand -- makes the main stream wait first (join_background).
+    hipStream_t stream_bg = nullptr;
+    hipEvent_t ev_bg_fork = nullptr, ev_bg_done = nullptr;
+    bool bg_active = false;
+    std::unordered_set<const void *> bg_tiles;
+    long long opt_background_updates = 1; // PANGULU_HIP_BACKGROUND_UPDATES=0 / option 14
     long long opt_records_stream = 1; // PANGULU_HIP_RECORDS_STREAM=0: sparsify on the main stream as before
     int nb_cfg = 0;
     // options
@@ -1856,6 +1870,11 @@ void ensure_ready()
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_rec, hipEventDisableTiming));
     if (const char *e = getenv("PANGULU_HIP_RECORDS_STREAM"))
         B.opt_records_stream = atol(e);
+    HIP_CHECK(hipStreamCreateWithFlags(&B.stream_bg, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&B.ev_bg_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&B.ev_bg_done, hipEventDisableTiming));
+    if (const char *e = getenv("PANGULU_HIP_BACKGROUND_UPDATES"))
+        B.opt_background_updates = atol(e);
     // Descriptors are written once by the host and read once per workgroup: the kernels read them straight from
     // pinned host memory (non-coherent, so the device L2 may cache them) instead of waiting for a staging copy per
     // launch (rocprofv3 showed ~1900 blit dispatches, ~50 ms, per factorisation of the bench matrix).
@@ -1925,6 +1944,20 @@ void join_records(hipStream_t s)
         B.rec_dirty.store(false, std::memory_order_release);
 }
 
+// stream s is about to touch blocks that update launches on the background stream may still be writing (or: everything
+// queued so far has to be complete behind s)
+void join_background(hipStream_t s)
+{
+    if (!B.bg_active)
+        return;
+    HIP_CHECK(hipStreamWaitEvent(s, B.ev_bg_done, 0));
+    if (s == B.stream)
+    {
+        B.bg_active = false;
+        B.bg_tiles.clear();
+    }
+}
+
 Segment acquire_segment()
 {
     Ring &r = B.ring;
@@ -1968,6 +2001,7 @@ struct LaunchTimer
     int cls;
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
+    unsigned long long tag[3] = {0, 0, 0};
     explicit LaunchTimer(int c, hipStream_t stream = nullptr) : cls(c), st(stream ? stream : B.stream)
     {
         if (B.opt_profile)
@@ -1982,23 +2016,30 @@ struct LaunchTimer
         if (B.opt_profile)
         {
             HIP_CHECK(hipEventRecord(b, st));
-            B.pending_events.push_back(EventPair{a, b, cls});
+            B.pending_events.push_back(EventPair{a, b, cls, {tag[0], tag[1], tag[2]}});
         }
     }
 };
 
 void harvest_events()
 {
+    // PANGULU_HIP_LAUNCH_LOG=<file> (with PROFILE on): one line per launch -- class, microseconds, workgroups, tasks, live slab
+    // steps -- for tuning the update kernel by launch shape (tools/launch_log_summary.py)
+    static FILE *launch_log = getenv("PANGULU_HIP_LAUNCH_LOG") ? fopen(getenv("PANGULU_HIP_LAUNCH_LOG"), "w") : nullptr;
     for (auto &p : B.pending_events)
     {
         HIP_CHECK(hipEventSynchronize(p.b));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
         B.stats.elapsed_ms[p.cls] += ms;
+        if (launch_log)
+            fprintf(launch_log, "%d %.2f %llu %llu %llu\n", p.cls, 1e3 * ms, p.tag[0], p.tag[1], p.tag[2]);
         B.event_pool.push_back(p.a);
         B.event_pool.push_back(p.b);
     }
     B.pending_events.clear();
+    if (launch_log)
+        fflush(launch_log);
 }
 
 inline u32 host_nnz(const slot_t *s, int nb) { return s->columnpointer[nb]; }
@@ -2009,6 +2050,14 @@ inline slot_t *canon_dst(slot_t *s)
     if (s->brow_pos == s->bcol_pos && s->is_upper && s->related_block)
         return s->related_block;
     return s;
+}
+
+// identity of a block for the background-stream bookkeeping (both halves of a diagonal block are one block)
+inline const void *block_key_any(const slot_t *s)
+{
+    if (s->brow_pos == s->bcol_pos && s->is_upper && s->related_block)
+        return (const void *)s->related_block->d_value;
+    return (const void *)s->d_value;
 }
 
 // Building the descriptors of a task touches, per operand, the slot struct, the last entry of its pattern pointer array and
@@ -2099,6 +2148,7 @@ void mirror_to_host(slot_t *s, int nb)
 {
     size_t bytes = sizeof(val_t) * (size_t)host_nnz(s, nb);
     join_records(B.stream);
+    join_background(B.stream);
     if (bytes)
         HIP_CHECK(hipMemcpyAsync(s->value, s->d_value, bytes, hipMemcpyDeviceToHost, B.stream));
 }
@@ -2140,11 +2190,14 @@ size_t launch_chunk_tasks()
     return chunk;
 }
 
-void launch_ssssm(int nb, task_t **list, size_t n)
+// `background`: the update kernels of this call go to the background stream (see Backend::stream_bg); their mirror jobs
+// stay on the main stream, in front of the fork
+void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
 {
     if (n == 0)
         return;
     HostTimer ht(0);
+    hipStream_t const ms = background ? B.stream_bg : B.stream; // where the update kernels of this call run
     const bool dense_ok = dense_mode_available(nb);
     size_t i = 0;
     while (i < n)
@@ -2382,12 +2435,18 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         std::stable_sort(groups_s, groups_s + gs, by_size);
         std::stable_sort(groups_d, groups_d + gd, by_size);
         commit_segment(seg);
-        if (gs && gd && B.opt_two_streams)
+        if (background)
+        {
+            // mirrors are current and the operands final from here on (main stream); the kernels run on the background stream
+            HIP_CHECK(hipEventRecord(B.ev_bg_fork, B.stream));
+            HIP_CHECK(hipStreamWaitEvent(ms, B.ev_bg_fork, 0));
+        }
+        if (gs && gd && B.opt_two_streams && !background)
             HIP_CHECK(hipEventRecord(B.ev_fork, B.stream)); // mirrors are current from here on
         if (gs)
         {
-            join_records(B.stream); // operands and destinations of the LDS kernel are sparse records
-            LaunchTimer lt(4);
+            join_records(ms); // operands and destinations of the LDS kernel are sparse records
+            LaunchTimer lt(4, ms);
             // columns per wavefront: 1 unless the grid would exceed 2^20 workgroups (more parallel waves beat fewer launches:
             // measured 176 ms vs 181 ms per factorisation of the bench matrix with an 8k-workgroup target)
             int cpw = 1;
@@ -2396,10 +2455,10 @@ void launch_ssssm(int nb, task_t **list, size_t n)
             int colblocks = (nb + SSSSM_WAVES * cpw - 1) / (SSSSM_WAVES * cpw);
             size_t lds = sizeof(val_t) * (size_t)nb * SSSSM_WAVES;
             if (B.opt_getrf_strict)
-                hipLaunchKernelGGL(ssssm_sparse_kernel<true>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, B.stream,
+                hipLaunchKernelGGL(ssssm_sparse_kernel<true>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, ms,
                                    d_groups_s, d_tasks_s, nb, cpw, B.d_flops + 4);
             else
-                hipLaunchKernelGGL(ssssm_sparse_kernel<false>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, B.stream,
+                hipLaunchKernelGGL(ssssm_sparse_kernel<false>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, ms,
                                    d_groups_s, d_tasks_s, nb, cpw, B.d_flops + 4);
             B.stats.launches[4]++;
             B.stats.tasks[4] += ns;
@@ -2408,8 +2467,8 @@ void launch_ssssm(int nb, task_t **list, size_t n)
 #if defined(PG_DENSE_UPDATES)
         if (gd)
         {
-            hipStream_t ds = B.stream;
-            const bool side = B.opt_two_streams && gs;
+            hipStream_t ds = ms;
+            const bool side = B.opt_two_streams && gs && !background;
             if (side)
             {
                 // fork: the MFMA kernel starts as soon as the mirrors are ready and runs beside the LDS kernel (both
@@ -2429,6 +2488,21 @@ void launch_ssssm(int nb, task_t **list, size_t n)
                             work[nw++] = SsssmWorkD{Gd.cdense, Gd.task_begin, Gd.task_end, Gd.atomic, Gd.slab_mask, (u32)tl, 0u};
                         }
                 LaunchTimer lt(5, ds);
+                if (B.opt_profile)
+                {
+                    unsigned long long steps = 0;
+                    for (size_t gi = 0; gi < gd; gi++)
+                    {
+                        const SsssmGroupD &Gd = groups_d[gi];
+                        const unsigned kmask = Gd.slab_mask ? Gd.slab_mask : 0xFFFFu;
+                        for (u32 t = Gd.task_begin; t < Gd.task_end; t++)
+                            for (int tl = 0; tl < tiles * tiles; tl++)
+                                steps += (unsigned long long)__builtin_popcount(live_k[(size_t)t * 4 + tl] & kmask);
+                    }
+                    lt.tag[0] = nw;
+                    lt.tag[1] = nd;
+                    lt.tag[2] = steps;
+                }
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 if (nw)
                     hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb,
@@ -2447,7 +2521,14 @@ void launch_ssssm(int nb, task_t **list, size_t n)
         }
 #endif
         HIP_CHECK(hipGetLastError());
-        release_pending_segments();
+        release_pending_segments(ms);
+    }
+    if (background)
+    {
+        HIP_CHECK(hipEventRecord(B.ev_bg_done, ms));
+        B.bg_active = true;
+        for (size_t t = 0; t < n; t++)
+            B.bg_tiles.insert(block_key_any(list[t]->opdst));
     }
 }
 
@@ -2951,6 +3032,31 @@ void process_run(int nb, task_t *tasks, size_t n, std::vector<task_t *> &getrf, 
     // workgroups, latency-bound) go to a side stream that waits only for what was queued before this run and run beside
     // the update and TSTRF/GESSM kernels; the main stream joins at the end of the run.
     // (with CU-masked bulk streams a run of GETRFs alone goes there as well: a leaf level has one workgroup per CU)
+    // blocks that update launches on the background stream may still be writing: wait before anything of this run touches them
+    if (B.bg_active)
+    {
+        bool hit = false;
+        for (size_t i = 0; i < n && !hit; i++)
+            for (const slot_t *sl : {(const slot_t *)tasks[i].opdst, (const slot_t *)tasks[i].op1, (const slot_t *)tasks[i].op2})
+                if (sl && B.bg_tiles.count(block_key_any(sl)))
+                {
+                    hit = true;
+                    break;
+                }
+        if (hit)
+            join_background(B.stream);
+    }
+    // Look-ahead call of the scheduler (diagonal factorisations + every update queued anywhere, independent of each other):
+    // the GETRFs are the critical path and stay on the main stream, the updates -- trailing-matrix work of the previous
+    // level -- go to the background stream and are NOT joined at the end: the panel solves of the next call run beside them.
+    const bool background = B.opt_background_updates && B.opt_two_streams && B.opt_assume_independent && !getrf.empty() && !ssssm.empty() &&
+                            trsm.empty() && !B.bulk_streams_masked && !B.opt_profile;
+    if (background)
+    {
+        launch_ssssm(nb, ssssm.data(), ssssm.size(), true);
+        launch_getrf(nb, getrf.data(), getrf.size(), B.stream, false);
+        return;
+    }
     bool side = B.opt_two_streams && !getrf.empty() && (!trsm.empty() || !ssssm.empty() || B.bulk_streams_masked);
     if (side)
     {
@@ -2995,6 +3101,7 @@ extern "C"
     {
         ensure_ready();
         join_records(B.stream);
+        join_background(B.stream);
         HIP_CHECK(hipStreamSynchronize(B.stream));
     }
 
@@ -3032,6 +3139,7 @@ extern "C"
         ensure_ready();
         // ordered after everything queued on the back-end stream, complete on return
         join_records(B.stream);
+        join_background(B.stream);
         HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), B.stream));
         HIP_CHECK(hipStreamSynchronize(B.stream));
     }
@@ -3043,7 +3151,10 @@ extern "C"
         // (src/pangulu_communication.c:1850,1880): use the back-end stream so later kernels are ordered behind it
         hipStream_t s = stream ? (hipStream_t)stream : B.stream;
         if (kind != 0)
+        {
             join_records(s); // (uploads of received blocks write receive slots, which no sparsify job touches)
+            join_background(s);
+        }
         HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), s));
         if (!stream)
             HIP_CHECK(hipStreamSynchronize(s)); // the source is pageable host memory the caller may reuse at once
@@ -3131,19 +3242,23 @@ extern "C"
     int pangulu_platform_0201001_bind_near_device(int enable)
     {
         static thread_local cpu_set_t saved;
-        static thread_local bool have_saved = false;
+        static thread_local int depth = 0; // bind / unbind pairs nest: only the outermost pair changes the mask
         static const bool off = getenv("PANGULU_AMD_BIND_NUMA") && atoi(getenv("PANGULU_AMD_BIND_NUMA")) == 0;
         if (off)
             return 1;
         if (!enable)
         {
-            if (!have_saved)
+            if (depth == 0)
                 return 1;
-            have_saved = false;
+            if (--depth > 0)
+                return 0; // (an outer pair is still active: stay where we are)
             return sched_setaffinity(0, sizeof(saved), &saved) == 0 ? 0 : 1;
         }
-        if (have_saved)
+        if (depth > 0)
+        {
+            depth++;
             return 0; // (nested: already there)
+        }
         cpu_set_t want;
         if (!cpus_near_device(B.device, &want))
             return 1;
@@ -3151,7 +3266,7 @@ extern "C"
             return 1;
         if (sched_setaffinity(0, sizeof(want), &want) != 0)
             return 1;
-        have_saved = true;
+        depth = 1;
         return 0;
     }
 
@@ -3321,6 +3436,7 @@ extern "C"
         hipEvent_t e = ring[next];
         next = (next + 1) % ring.size();
         join_records(B.stream); // a marker stands for "the blocks finished so far can be sent": their records included
+        join_background(B.stream); // ... and for "the slots whose last consumer has been queued may be reused": background updates too
         HIP_CHECK(hipEventRecord(e, B.stream)); // (side streams have been joined into the main stream by every call)
         return (void *)e;
     }
@@ -3475,6 +3591,9 @@ extern "C"
             reset_block_states();
             return 0;
         }
+        case PANGULU_HIP_OPT_BACKGROUND_UPDATES:
+            B.opt_background_updates = value;
+            return 0;
         case PANGULU_HIP_OPT_RECORDS_STREAM:
         {
             ensure_ready();
@@ -3499,6 +3618,7 @@ extern "C"
         std::lock_guard<std::mutex> g(B.mutex);
         HIP_CHECK(hipSetDevice(B.device));
         join_records(B.stream); // the sparse records of finished blocks are written on the records stream
+        join_background(B.stream);
         const size_t nrow = (size_t)level_ptr[nlevel];
         size_t nblk = 0;
         for (size_t r = 0; r < nrow; r++)
@@ -3568,6 +3688,7 @@ extern "C"
         std::lock_guard<std::mutex> g(B.mutex);
         HIP_CHECK(hipSetDevice(B.device));
         join_records(B.stream); // the sparse records of finished blocks are written on the records stream
+        join_background(B.stream);
         std::vector<SpmvBlkD> hb(std::max<size_t>((size_t)nblk, 1));
         for (size_t i = 0; i < (size_t)nblk; i++)
         {
@@ -3616,6 +3737,7 @@ extern "C"
         ensure_ready();
         std::lock_guard<std::mutex> g(B.mutex);
         join_records(B.stream);
+        join_background(B.stream);
         HIP_CHECK(hipStreamSynchronize(B.stream));
         harvest_events();
         unsigned long long f[16];
