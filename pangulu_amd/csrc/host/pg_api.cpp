@@ -525,9 +525,19 @@ extern "C"
             const char *ao = getenv("PANGULU_AMD_ANALYSIS_ONLY");
             S->analysis_only = ao && atoi(ao) != 0;
         }
+        const bool trace_init = getenv("PANGULU_AMD_TRACE") != nullptr && rank == 0;
+        double t1 = wall_seconds();
+        if (trace_init)
+            fprintf(stderr, "[pangulu_amd trace] init: reorder %.2f s, symbolic %.2f s, block pattern %.2f s (%d threads)\n", S->info.time_reorder,
+                    S->info.time_symbolic, t1 - t0, nthread);
         build_structure_model(*S); // weights for the mapping, from the symbolic pattern (every rank the same)
+        double t2 = wall_seconds();
         preprocess(*S, S->Aperm);
+        double t3 = wall_seconds();
         compute_rank_model(*S);    // per-rank T*, flop shares, link term, critical path under the mapping just made
+        if (trace_init)
+            fprintf(stderr, "[pangulu_amd trace] init: structure model %.2f s, records + counters + upload %.2f s, rank model + critical path %.2f s\n",
+                    t2 - t1, t3 - t2, wall_seconds() - t3);
         // the element-level pattern is only needed to build the records
         S->sym.idx = std::vector<u32>();
         S->sym.ptr = std::vector<u64>();

@@ -11,6 +11,7 @@
 // and bytes_t are §8d's: every operand record streamed once + destination values read and written once.
 // (tests/test_reference_pin.py pins the same four counts of the oracle against the reference's own counters; the sum over
 // all tasks equals info.flop.)  Single-rank handles only: the patterns of all blocks must be local.
+#include <cmath>
 #include <omp.h>
 
 #include "pg_host.h"
@@ -224,8 +225,9 @@ struct TaskCost
     double bytes, flop;
 };
 
-// walks every task of the factorisation once, level by level; fn(cls, level, brow, bcol, cost) is called from an OpenMP
-// region (parallel over levels) -- callers accumulate with atomics or per-thread state
+// walks every task of the factorisation once, level by level; fn(cls, level, brow, bcol, cost, slot) is called from an OpenMP
+// region (parallel over levels) -- callers accumulate with atomics or per-thread state.  `slot`: for an update, its
+// position bi * nl + ai among the nl x nl pairs of its level (a, b = positions of L(i,k), L(j,k) in the level's L column)
 template <typename F>
 void for_every_task(const Solver &S, F &&fn)
 {
@@ -249,7 +251,7 @@ void for_every_task(const Solver &S, F &&fn)
                     const double nl = (double)cd[c] - 1.0;
                     fl += nl * (1.0 + 2.0 * nl);
                 }
-            fn(PANGULU_TASK_GETRF, k, k, k, TaskCost{(2 * sv + 2) * (nnzL + nnzU) + 8.0 * (nb + 1), fl});
+            fn(PANGULU_TASK_GETRF, k, k, k, TaskCost{(2 * sv + 2) * (nnzL + nnzU) + 8.0 * (nb + 1), fl}, (u64)0);
         }
         for (u64 a = l0 + 1; a < l1; a++)
         {
@@ -264,8 +266,8 @@ void for_every_task(const Solver &S, F &&fn)
                     ft += (double)ca[c] * (1.0 + 2.0 * nl);
                     fg += 2.0 * (double)ca[c] * nl;
                 }
-            fn(PANGULU_TASK_TSTRF, k, i, k, TaskCost{(2 * sv + 6) * nnzB + (sv + 2) * nnzU + 8.0 * (nb + 1), ft});
-            fn(PANGULU_TASK_GESSM, k, k, i, TaskCost{(2 * sv + 2) * nnzB + (sv + 2) * nnzL + 8.0 * (nb + 1), fg});
+            fn(PANGULU_TASK_TSTRF, k, i, k, TaskCost{(2 * sv + 6) * nnzB + (sv + 2) * nnzU + 8.0 * (nb + 1), ft}, (u64)0);
+            fn(PANGULU_TASK_GESSM, k, k, i, TaskCost{(2 * sv + 2) * nnzB + (sv + 2) * nnzL + 8.0 * (nb + 1), fg}, (u64)0);
         }
         // updates C(i, j) -= L(i, k) U(k, j), i and j over the off-diagonal lower blocks of column k
         for (u64 b = l0 + 1; b < l1; b++)
@@ -289,16 +291,11 @@ void for_every_task(const Solver &S, F &&fn)
                 double fl = 0;
                 for (u32 c = 0; c < nb; c++)
                     fl += (double)((u32)ca[c] * (u32)cb[c]);
-                fn(PANGULU_TASK_SSSSM, k, i, j, TaskCost{(sv + 2) * ((double)P.lnnz[a] + P.lnnz[b]) + (2 * sv + 2) * nnz_c + 12.0 * (nb + 1), 2.0 * fl});
+                fn(PANGULU_TASK_SSSSM, k, i, j, TaskCost{(sv + 2) * ((double)P.lnnz[a] + P.lnnz[b]) + (2 * sv + 2) * nnz_c + 12.0 * (nb + 1), 2.0 * fl},
+                   (b - (l0 + 1)) * (l1 - l0 - 1) + (a - (l0 + 1)));
             }
         }
     }
-}
-
-inline void atomic_add(double &dst, double v)
-{
-#pragma omp atomic
-    dst += v;
 }
 
 } // namespace
@@ -339,11 +336,30 @@ void build_structure_model(Solver &S)
     M.col_time.assign(nbk, 0.0);
     M.col_flop.assign(nbk, 0.0);
     const double bw = M.hbm_bytes_per_s, peak = M.fp_flops_per_s;
-    for_every_task(S, [&](int, u32, u32 brow, u32 bcol, const TaskCost &c)
+    // per-thread sums, reduced afterwards: the columns of a top separator collect the updates of every level below, and
+    // hundreds of threads adding to the same words with compare-and-swap loops do not scale
+    // ... in INTEGERS (femtoseconds, flops): the mapping compares these weights and every rank must come to the same
+    // map, whatever its thread count and scheduling -- integer sums do not depend on the order of the terms
+    const int nthr = omp_get_max_threads();
+    std::vector<std::vector<i64>> part((size_t)nthr);
+    for_every_task(S, [&](int, u32, u32 brow, u32 bcol, const TaskCost &c, u64)
                    {
+                       std::vector<i64> &mine = part[(size_t)omp_get_thread_num()];
+                       if (mine.empty())
+                           mine.assign((size_t)nbk * 2, 0);
                        const u32 col = std::min(brow, bcol);
-                       atomic_add(M.col_time[col], std::max(c.bytes / bw, c.flop / peak));
-                       atomic_add(M.col_flop[col], c.flop); });
+                       mine[2 * (size_t)col] += (i64)std::llround(std::max(c.bytes / bw, c.flop / peak) * 1e15);
+                       mine[2 * (size_t)col + 1] += (i64)std::llround(c.flop); });
+    std::vector<i64> tot((size_t)nbk * 2, 0);
+    for (const auto &mine : part)
+        if (!mine.empty())
+            for (size_t k = 0; k < (size_t)nbk * 2; k++)
+                tot[k] += mine[k];
+    for (u32 k = 0; k < nbk; k++)
+    {
+        M.col_time[k] = 1e-15 * (double)tot[2 * (size_t)k];
+        M.col_flop[k] = (double)tot[2 * (size_t)k + 1];
+    }
 }
 
 void compute_rank_model(Solver &S)
@@ -361,24 +377,42 @@ void compute_rank_model(Solver &S)
     M.rank_comm_s.assign((size_t)np, 0.0);
     M.sent_bytes.assign((size_t)np * np, 0.0);
     const double bw = M.hbm_bytes_per_s, peak = M.fp_flops_per_s;
-    // per-task times kept for the critical path below: panel tasks per block, updates folded into their destination
+    // per-task times kept for the critical path below: panel tasks per block, updates per (level, pair)
     const u64 nblk = P.colptr[nbk];
     std::vector<float> t_panel(nblk, 0.f), t_getrf(nbk, 0.f);
-    for_every_task(S, [&](int cls, u32 level, u32 brow, u32 bcol, const TaskCost &c)
+    std::vector<u64> upd_off((size_t)nbk + 1, 0);
+    for (u32 k = 0; k < nbk; k++)
+    {
+        const u64 nl = P.lcolptr[k + 1] - P.lcolptr[k] - 1;
+        upd_off[k + 1] = upd_off[k] + nl * nl;
+    }
+    std::vector<float> t_upd(upd_off[nbk], -1.f); // (< 0: the pair has no destination block)
+    // (per-thread sums: with one rank every task of the factorisation would add to the same four words)
+    const int nthr = omp_get_max_threads();
+    std::vector<double> acc((size_t)nthr * np * 4, 0.0);
+    for_every_task(S, [&](int cls, u32 level, u32 brow, u32 bcol, const TaskCost &c, u64 slot)
                    {
-                       (void)level;
                        const int r = S.owner(brow, bcol);
                        const double a = c.bytes / bw, b = c.flop / peak;
-                       if (a >= b)
-                           atomic_add(M.rank_time_hbm[(size_t)r], a);
-                       else
-                           atomic_add(M.rank_time_fp[(size_t)r], b);
-                       atomic_add(M.rank_flop[(size_t)r], c.flop);
-                       atomic_add(M.rank_bytes[(size_t)r], c.bytes);
+                       double *mine = acc.data() + ((size_t)omp_get_thread_num() * np + r) * 4;
+                       mine[a >= b ? 0 : 1] += std::max(a, b);
+                       mine[2] += c.flop;
+                       mine[3] += c.bytes;
                        if (cls == PANGULU_TASK_GETRF)
                            t_getrf[brow] = (float)std::max(a, b);
-                       else if (cls != PANGULU_TASK_SSSSM)
+                       else if (cls == PANGULU_TASK_SSSSM)
+                           t_upd[upd_off[level] + slot] = (float)std::max(a, b);
+                       else
                            t_panel[P.find(brow, bcol)] = (float)std::max(a, b); });
+    for (int t = 0; t < nthr; t++)
+        for (int r = 0; r < np; r++)
+        {
+            const double *mine = acc.data() + ((size_t)t * np + r) * 4;
+            M.rank_time_hbm[(size_t)r] += mine[0];
+            M.rank_time_fp[(size_t)r] += mine[1];
+            M.rank_flop[(size_t)r] += mine[2];
+            M.rank_bytes[(size_t)r] += mine[3];
+        }
     // bytes forwarded between ranks: every finished block goes once to each rank that runs an update with it
     // (Solver::consumers), a diagonal block's halves to the ranks that run panel solves against them
     if (np > 1)
@@ -460,57 +494,46 @@ void compute_rank_model(Solver &S)
 
     // Critical path of the block task graph with every task at its own T*_t (a lower bound on any schedule's makespan
     // however many devices there are): levels ascending; a block's updates may run concurrently once both operands are
-    // final, its panel task starts when the last of them is done.
+    // final, its panel task starts when the last of them is done.  (Serial: a few operations per task.)
     {
         std::vector<float> ready(nblk, 0.f), fin(nblk, 0.f), ready_d(nbk, 0.f), fin_d(nbk, 0.f);
         std::vector<u32> depth(nblk, 0), depth_rd(nbk, 0), depth_r(nblk, 0), depth_d(nbk, 0);
-        const double svd = (double)sizeof(val_t);
-        const u16 *lcount = M.lcount.data();
+        std::vector<u64> bl_of, bu_of;
         for (u32 k = 0; k < nbk; k++)
         {
             fin_d[k] = ready_d[k] + t_getrf[k];
             depth_d[k] = depth_rd[k] + 1;
             const u64 l0 = P.lcolptr[k], l1 = P.lcolptr[k + 1];
+            const u64 nl = l1 - l0 - 1;
+            bl_of.resize(nl);
+            bu_of.resize(nl);
             // panel solves of column k and row k
-            for (u64 a = l0 + 1; a < l1; a++)
+            for (u64 a = 0; a < nl; a++)
             {
-                const u32 i = P.lrowidx[a];
+                const u32 i = P.lrowidx[l0 + 1 + a];
                 const u64 bl = P.find(i, k), bu = P.find(k, i);
+                bl_of[a] = bl;
+                bu_of[a] = bu;
                 fin[bl] = std::max(ready[bl], fin_d[k]) + t_panel[bl];
                 depth[bl] = std::max(depth_r[bl], depth_d[k]) + 1;
                 fin[bu] = std::max(ready[bu], fin_d[k]) + t_panel[bu];
                 depth[bu] = std::max(depth_r[bu], depth_d[k]) + 1;
             }
-            const i64 nl = (i64)(l1 - l0) - 1;
-            // updates generated by level k (destinations are distinct blocks: safe in parallel)
-#pragma omp parallel for schedule(dynamic, 4) if (nl > 8)
-            for (i64 bi = 0; bi < nl; bi++)
+            // updates generated by level k
+            for (u64 b = 0; b < nl; b++)
             {
-                const u64 b = l0 + 1 + (u64)bi;
-                const u32 j = P.lrowidx[b];
-                const u16 *cb = lcount + (size_t)b * nb;
-                const u64 bu = P.find(k, j);
-                for (u64 a = l0 + 1; a < l1; a++)
+                const u32 j = P.lrowidx[l0 + 1 + b];
+                const u64 bu = bu_of[b];
+                // destinations (i, j), i over the L column: walk block column j of the pattern alongside
+                u64 cur = P.colptr[j];
+                const u64 cend = P.colptr[j + 1];
+                for (u64 a = 0; a < nl; a++)
                 {
-                    const u32 i = P.lrowidx[a];
-                    const u64 bl = P.find(i, k);
-                    double nnz_c;
-                    u64 bd = ~0ull;
-                    if (i == j)
-                        nnz_c = (double)P.diag_lower_nnz[i] + P.diag_upper_nnz[i];
-                    else
-                    {
-                        bd = P.find(i, j);
-                        if (bd == ~0ull)
-                            continue;
-                        nnz_c = P.nnz[bd];
-                    }
-                    const u16 *ca = lcount + (size_t)a * nb;
-                    double fl = 0;
-                    for (u32 c = 0; c < nb; c++)
-                        fl += (double)((u32)ca[c] * (u32)cb[c]);
-                    const double by = (svd + 2) * ((double)P.lnnz[a] + P.lnnz[b]) + (2 * svd + 2) * nnz_c + 12.0 * (nb + 1);
-                    const float t = (float)std::max(by / bw, 2.0 * fl / peak);
+                    const float t = t_upd[upd_off[k] + b * nl + a];
+                    if (t < 0)
+                        continue;
+                    const u32 i = P.lrowidx[l0 + 1 + a];
+                    const u64 bl = bl_of[a];
                     const float done = std::max(fin[bl], fin[bu]) + t;
                     const u32 dp = std::max(depth[bl], depth[bu]) + 1;
                     if (i == j)
@@ -520,6 +543,10 @@ void compute_rank_model(Solver &S)
                     }
                     else
                     {
+                        while (cur < cend && P.rowidx[cur] < i)
+                            cur++;
+                        // (t >= 0 means the destination exists; i ascends with a, but U blocks (i < j) come first in the column)
+                        const u64 bd = (cur < cend && P.rowidx[cur] == i) ? cur : P.find(i, j);
                         ready[bd] = std::max(ready[bd], done);
                         depth_r[bd] = std::max(depth_r[bd], dp);
                     }

@@ -61,5 +61,6 @@ def test_bench_launches_its_own_ranks():
     assert cpu["cores"] == 2 and cpu["value"] > 0, cpu                      # R ranks x 1 thread (examples/example.c:284)
     assert cpu["one_rank_x_one_thread"]["cores"] == 1 and cpu["one_rank_x_one_thread"]["value"] > 0
     m = line["model"]
-    assert m["T_star_ms"] > 0 and m["T_star_ms"] < m["sum_over_ranks_ms"] and 1.0 <= m["rank_flop_share_max_over_mean"] < 2.0
+    # (T*(N) = max over ranks of T*_r + link term: at this size the link term is the larger part)
+    assert m["T_star_ms"] >= m["sum_over_ranks_ms"] / 2 and 1.0 <= m["rank_flop_share_max_over_mean"] < 2.0
     assert m["sent_GB"] > 0 and m["link_term_ms_max"] > 0
