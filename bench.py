@@ -555,6 +555,7 @@ def gpu_worker_main(args):
                 }
                 if name == "ssssm_dense_mfma":
                     kernels[name]["GFLOP_executed"] = round(v["mfma_flops_executed"] / 1e9, 2)
+                    kernels[name]["workgroups"] = {"dense_front_kernel": v["front_workgroups"], "general_kernel": v["general_workgroups"]}
         task_classes = ("getrf", "tstrf", "gessm", "ssssm_sparse", "ssssm_dense_mfma")
         if any(k in kernels for k in task_classes):
             # the dominant kernel among the task classes (mirror maintenance -- densify, sparsify, remote LU images -- is listed

@@ -256,6 +256,15 @@ extern "C"
      *     join at the end of the call; a later call that touches one of their destinations waits for them first.  0: the
      *     round-2 layout (GETRFs on a side stream, everything joined at the end of the call). */
 #define PANGULU_HIP_OPT_BACKGROUND_UPDATES 14
+    /*   PANGULU_HIP_OPT_FRONT_STAGES (default 2; environment PANGULU_HIP_FRONT_STAGES at start-up): (destination, 128 x 128
+     *     tile) pairs whose queued updates are all dense-front products -- every 16 x 16 piece of both operands that meets
+     *     the tile holds pattern entries -- run on the dense-front MFMA kernel (operand slabs by LDS-DMA, this many LDS
+     *     stages: 2, 3 or 4); 0 sends everything through the general MFMA kernel. */
+#define PANGULU_HIP_OPT_FRONT_STAGES 15
+    /*   PANGULU_HIP_OPT_TILES_STAGES (default 2; environment PANGULU_HIP_TILES_STAGES at start-up): the general MFMA update
+     *     kernel -- 2, 3 or 4: operand slabs by LDS-DMA with that many LDS stages, strided piece ownership of the wavefronts
+     *     (ssssm_tiles_f64_kernel); 0: round 2's kernel (register staging, contiguous 64 x 32 sub-tiles). */
+#define PANGULU_HIP_OPT_TILES_STAGES 16
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an
@@ -323,6 +332,8 @@ extern "C"
         double mfma_flops_executed; /* class 5: flops the matrix cores actually executed (16x16x16 products issued x 8192;
                                      *  structurally empty tiles are skipped); counted while COUNT_FLOPS is on */
         unsigned long long trsm_dense_tasks; /* TSTRF/GESSM tasks that took the dense MFMA path */
+        /* class 5: workgroups (destination tile x update queue) launched on the dense-front kernel / on the general MFMA kernel */
+        unsigned long long ssssm_front_workgroups, ssssm_general_workgroups;
     } pangulu_hip_stats_t;
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset);
 

@@ -107,6 +107,8 @@ class HipStats(ctypes.Structure):
         ("elapsed_ms", ctypes.c_double * 9),
         ("mfma_flops_executed", ctypes.c_double),
         ("trsm_dense_tasks", ctypes.c_ulonglong),
+        ("ssssm_front_workgroups", ctypes.c_ulonglong),
+        ("ssssm_general_workgroups", ctypes.c_ulonglong),
     ]
 
 
@@ -234,6 +236,8 @@ HIP_OPT_SMALL_LAUNCH_TASKS = 11
 HIP_OPT_XCD_SWIZZLE = 12
 HIP_OPT_RECORDS_STREAM = 13
 HIP_OPT_BACKGROUND_UPDATES = 14
+HIP_OPT_FRONT_STAGES = 15
+HIP_OPT_TILES_STAGES = 16
 
 ORDER_IDENTITY, ORDER_ND, ORDER_USER = 0, 1, 2
 TRANSPORT_HOST, TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1, 2

@@ -1,0 +1,507 @@
+// pg_hip_front.h -- the MFMA update kernel for DENSE FRONTS (R64; CR64 plane by plane): C(128 x 128 tile) -= sum_t A_t B_t where
+// every 16 x 16 piece of the operands that meets the tile holds pattern entries.
+// (included by pg_hip_platform.hip after pg_hip_dense.h; tools/microbench/front_gemm.hip times it stand-alone)
+//
+// Where it applies.  The reference's direct-gemm case (all three blocks completely full -> cuBLAS on the value arrays,
+// ...0201000.cu:827-852) generalised to tiles: on 3D problems the top separators of the elimination tree are dense fronts and
+// ARE the factorisation -- fem27(112): 81 % of the update kernel's time in launches of more than 16 000 workgroups whose
+// slabs are all live.  The general kernel (pg_hip_dense.h) pays for what such tiles do not need: occupancy tests per
+// (task, K-slab), a compacted step list per window of 16 tasks, conditional MFMAs, dummy loads for dead pieces -- and keeps
+// ONE slab of operands in flight, staged through registers (phase stamps on fem27(80): 35 % of a workgroup's time in the
+// matrix-core phase, 23 % waiting for the slab, 18 % at the two barriers, 15 % issuing the next loads).
+//
+// What it does instead.
+//  * Operand slabs go from HBM/L2 straight into LDS (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging
+//    registers, no ds_write pass), STAGES slabs deep: with S stages, S - 1 slabs are in flight while the matrix cores work
+//    on one; waits are counted (s_waitcnt vmcnt(4 (S - 2)): every wave issues exactly four DMA instructions per slab) and
+//    the barrier is a bare s_barrier -- __syncthreads() would drain the DMA queue (cdna_hip_programming.md §5).
+//  * An LDS-DMA writes 64 x 16 bytes CONTIGUOUSLY; what goes where is decided by the per-lane SOURCE address:
+//      A slab (16 columns k of 128 rows, mirror column-major): one instruction per column = 1 KiB; columns 144 doubles
+//      apart (k*16 + m covers all 32 double-banks for the two columns a half-wave reads);
+//      B slab (16 rows k of 128 columns): one instruction per 8 columns, eight lanes per column fetching its 16 consecutive
+//      k's (one 128-byte line) as pairs; lane j of column n fetches pair j ^ ((n >> 1) & 7) -- an XOR swizzle on the
+//      source side -- so that the MFMA fragment reads (a half-wave = 16 columns x 2 rows of one pair) hit 32 different
+//      double-banks.
+//  * No bookkeeping: step = (task, slab) in order, operand pointers by scalar loads from the task descriptors.
+//  * acc = -sum A B on the matrix cores' NEG field, C += acc at the end (plain read-modify-write, or floating-point
+//    atomics for a split queue).
+#pragma once
+
+#define FR_TILE 128
+#define FR_KS 16
+#define FR_LDA 144                                        // doubles between two k columns of the A image
+#define FR_STAGE_DOUBLES (FR_KS * FR_LDA + FR_TILE * FR_KS) // A image + B image of one slab: 34 816 bytes
+#define FR_THREADS 512
+
+typedef const char __attribute__((address_space(1))) *fr_gptr;
+typedef void __attribute__((address_space(3))) *fr_lptr;
+
+// STAGES: LDS stages of the operand pipeline.  PREFETCH: the MFMA fragments of k-quarter kq + 1 are read while the matrix
+// cores work on kq (12 more registers).  `unit`: consecutive workgroups that go to the same XCD (logical_block_id): 4 =
+// the tiles of one destination; 4 g = the tiles of g consecutive destinations, which share an operand in the scheduler's
+// release order (all updates of one finished L block, or of one finished U block, are queued in a row).
+template <int STAGES, bool PREFETCH>
+__global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_front_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb, const SsssmWorkD *__restrict__ work,
+                                                                     unsigned long long *__restrict__ product_counter, unsigned unit)
+{
+    __shared__ __align__(16) double lds[STAGES * FR_STAGE_DOUBLES];
+    const int tiles = nb / FR_TILE;
+    const unsigned bid = logical_block_id(unit ? unit : (unsigned)(tiles * tiles));
+    const SsssmWorkD G = work[bid];
+    const int tile = (int)G.tile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M0 = (tile % tiles) * FR_TILE, N0 = (tile / tiles) * FR_TILE;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32; // wavefront sub-tile: 64 rows x 32 columns = 4 x 2 accumulators
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ntask = (int)(G.task_end - G.task_begin);
+    const int steps_shift = nb == 256 ? 4 : 3; // nb / 16 slabs per task (dense mode: nb = 128 or 256)
+    const int steps_per_task = 1 << steps_shift;
+    const int T = ntask << steps_shift;
+    const SsssmTaskD *my_tasks = tasks + G.task_begin;
+
+    // per-lane source offsets of the DMA instructions (bytes; constant over the kernel)
+    //   A: lane l fetches rows 2l, 2l+1 of column k  ->  + (k0 + k) * nb * 8 from the scalar side
+    const unsigned a_voff = (unsigned)lane * 16u;
+    //   B: lane l = 8 c + j fetches pair j ^ ((n >> 1) & 7) of column n = 8 g + c  (g = instruction); (n >> 1) & 7 = ((8 g + c) >> 1) & 7
+    //      = (4 g + (c >> 1)) & 7: depends on g through 4 g & 7 = 4 (g & 1) only
+    const int bc = lane >> 3, bj = lane & 7;
+    unsigned b_voff[2]; // for even / odd g
+#pragma unroll
+    for (int par = 0; par < 2; par++)
+        b_voff[par] = ((unsigned)bc * (unsigned)nb + 2u * (unsigned)(bj ^ ((4 * par + (bc >> 1)) & 7))) * 8u;
+
+    auto issue = [&](int st)
+    {
+        // four DMA instructions per wave: A columns `wave`, `wave + 8`; B column groups `wave`, `wave + 8`
+        const int t = st >> steps_shift, k0 = (st & (steps_per_task - 1)) * FR_KS;
+        const fr_gptr pa = (fr_gptr)reinterpret_cast<const char *>(my_tasks[t].a.val);
+        const fr_gptr pb = (fr_gptr)reinterpret_cast<const char *>(my_tasks[t].b.val);
+        double *stage = lds + (st % STAGES) * FR_STAGE_DOUBLES;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int k = wave + 8 * h;
+            const fr_gptr src = dg_scalar_base(pa + ((size_t)(k0 + k) * nb + M0) * 8) + a_voff;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src, (fr_lptr)(stage + k * FR_LDA), 16, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int g = wave + 8 * h;
+            const fr_gptr src = dg_scalar_base(pb + ((size_t)(N0 + 8 * g) * nb + k0) * 8) + b_voff[wave & 1]; // (g & 1 = wave & 1)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src, (fr_lptr)(stage + FR_KS * FR_LDA + g * 128), 16, 0, 0);
+        }
+    };
+
+    v4f64 acc[2][4]; // [ni][mi]
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+            acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    // prologue: STAGES - 1 slabs in flight
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; p++)
+        if (p < T)
+            issue(p);
+
+    // fragment addresses inside a stage (doubles): A (k, m) at k * FR_LDA + m;  B (k, n) at A_IMAGE + n * 16 + 2 (kp ^ s(n)) + (k & 1)
+    const int a_frag = l4 * FR_LDA + wm + l15;
+    int b_frag[2][2]; // [ni][pair of the quad: l4 >> 1 picks it]: position of (k = 4 kq + l4) for kq = 0 is computed, kq adds 2 to kp
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+    {
+        const int n = wn + ni * 16 + l15;
+        b_frag[ni][0] = FR_KS * FR_LDA + n * 16 + (l4 & 1);
+        b_frag[ni][1] = (n >> 1) & 7; // swizzle of the column
+    }
+
+    for (int st = 0; st < T; st++)
+    {
+        // slab st has landed: this wave's own four instructions by the counted wait, everybody else's behind the barrier
+        const int ahead = min(STAGES - 2, T - 1 - st); // slabs issued after slab st that may stay in flight
+        if (STAGES >= 4 && ahead >= 2)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (STAGES >= 3 && ahead >= 1)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ... and every wave has finished reading the stage slab st - 1 was in: refill it
+        if (st + STAGES - 1 < T)
+            issue(st + STAGES - 1);
+        const double *sA = lds + (st % STAGES) * FR_STAGE_DOUBLES;
+#if PG_PLANES > 1
+        const bool add = my_tasks[st >> steps_shift].sign < 0; // (complex updates as four real products: A_im B_im ADDS to the real plane)
+#endif
+#if PG_PLANES > 1
+#define FR_MFMA(ni_, mi_, fb_, fa_)                                                                                        \
+    if (add)                                                                                                                \
+        acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb_, fa_, acc[ni_][mi_], 0, 0, 0);                          \
+    else                                                                                                                    \
+        acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb_, fa_, acc[ni_][mi_], 0, 0, DG_NEG_A);
+#else
+#define FR_MFMA(ni_, mi_, fb_, fa_) acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb_, fa_, acc[ni_][mi_], 0, 0, DG_NEG_A);
+#endif
+#define FR_READ(fa_, fb_, kq_)                                                                        \
+    {                                                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < 4; mi++)(fa_)[mi] = sA[a_frag + (kq_) * 4 * FR_LDA + mi * 16]; \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ni++)(fb_)[ni] = sA[b_frag[ni][0] + 2 * ((2 * (kq_) + (l4 >> 1)) ^ b_frag[ni][1])]; \
+    }
+        if (PREFETCH)
+        {
+            double fa[2][4], fb[2][2];
+            FR_READ(fa[0], fb[0], 0)
+#pragma unroll
+            for (int kq = 0; kq < FR_KS / 4; kq++)
+            {
+                if (kq + 1 < FR_KS / 4)
+                    FR_READ(fa[(kq + 1) & 1], fb[(kq + 1) & 1], kq + 1)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int mi = 0; mi < 4; mi++)
+                    {
+                        FR_MFMA(ni, mi, fb[kq & 1][ni], fa[kq & 1][mi])
+                    }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int kq = 0; kq < FR_KS / 4; kq++)
+            {
+                double fa[4], fb[2];
+                FR_READ(fa, fb, kq)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int mi = 0; mi < 4; mi++)
+                    {
+                        FR_MFMA(ni, mi, fb[ni], fa[mi])
+                    }
+            }
+        }
+#undef FR_READ
+#undef FR_MFMA
+    }
+    if (product_counter && lane == 0 && T)
+        atomicAdd(product_counter, (unsigned long long)(8 * T)); // 16 x 16 x 16 products issued by this wave
+
+    // C += acc: accumulator register r of lane l is C(M0 + wm + mi*16 + (l & 15), N0 + wn + ni*16 + 4 r + (l >> 4))
+    double __attribute__((address_space(1))) *C = (double __attribute__((address_space(1))) *)reinterpret_cast<double *>(G.cdense);
+    const unsigned c_voff = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
+#define FR_C(ni_, mi_, r_)                                                                           \
+    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((const char __attribute__((address_space(1))) *)C +                    \
+                                                                  ((size_t)(N0 + wn + (ni_) * 16 + 4 * (r_)) * nb + M0 + wm) * 8) + \
+                                                   dg_lane_offset(c_voff) + (mi_) * 128))
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+    {
+        if (G.atomic)
+        {
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    atomicAdd((double *)&FR_C(ni, mi, r), acc[ni][mi][r]);
+            continue;
+        }
+        double old[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                old[mi][r] = FR_C(ni, mi, r);
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                FR_C(ni, mi, r) = old[mi][r] + acc[ni][mi][r];
+    }
+#undef FR_C
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same pipeline for tiles with STRUCTURAL ZEROS (round 3: the general MFMA update kernel).
+//
+// What the profile of the round-2 kernel said (fem27(112), PANGULU_HIP_LAUNCH_LOG): its launches process LIVE SLAB STEPS
+// (a 128 x 128 x 16 product with at least one live piece on either side) at the rate a full slab would take at 93 % of the
+// f64 MFMA peak -- whatever is inside: only 55 % of the 16 x 16 x 16 products of those steps are live.  A step costs one
+// memory round trip (one slab in flight per workgroup, two workgroups per CU) plus a barrier at which everybody waits for
+// the wavefront with the most products: with contiguous 64 x 32 sub-tiles per wavefront that one has 5.8 of 8 on average
+// where the mean is 3.5 (fill patterns are made of contiguous ranges of rows and columns).
+//  * Pipeline: LDS-DMA, STAGES deep, as above.  Pieces that are structurally empty are not fetched: their lanes (A: eight
+//    lanes per 16-row piece of a column) or their whole instruction (B: half a 16-column piece) read 16 bytes from the
+//    start of the mirror instead -- an L2 hit that lands in a part of the image no MFMA reads -- so that every wave still
+//    issues exactly four DMA instructions per step and the waits stay counted.
+//  * Ownership: wavefront w owns the pieces (row piece 2 mi + (w & 1), column piece (w >> 1) + 4 ni), mi < 4, ni < 2 -- the
+//    same 4 + 2 fragment reads per k-quarter as a contiguous sub-tile, but a contiguous range of live rows or columns is
+//    spread over all wavefronts (simulated on fem27(40)'s patterns: busiest wavefront 4.7 products per step instead of 5.8).
+//  * Bookkeeping as in round 2: per window of 16 queued updates one (task, K-slab) pair per thread is tested against the
+//    occupancy maps carried by the task descriptors and the live ones are compacted into a step list in LDS; the pipeline
+//    drains between windows (queues longer than 16 are rare: the scheduler flushes them level by level).
+// ---------------------------------------------------------------------------------------------------------------
+#define TL_WINDOW 16
+template <int STAGES>
+__global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb, const SsssmWorkD *__restrict__ work,
+                                                                     unsigned long long *__restrict__ product_counter, unsigned unit)
+{
+    __shared__ __align__(16) double lds[STAGES * FR_STAGE_DOUBLES];
+    __shared__ u32 s_step[TL_WINDOW * 16]; // live steps of the window in order: task << 20 | slab << 16 | bbits << 8 | abits
+    __shared__ u32 s_cnt[FR_THREADS / 64];
+    __shared__ unsigned long long s_pa[TL_WINDOW], s_pb[TL_WINDOW];
+#if PG_PLANES > 1
+    __shared__ double s_sign[TL_WINDOW];
+#endif
+    const int tiles = nb / FR_TILE;
+    const unsigned bid = logical_block_id(unit ? unit : (unsigned)(tiles * tiles));
+    const SsssmWorkD G = work[bid];
+    const int tile = (int)G.tile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M0 = (tile % tiles) * FR_TILE, N0 = (tile / tiles) * FR_TILE;
+    const int wr = wave & 1, wc = wave >> 1; // row pieces 2 mi + wr, column pieces wc + 4 ni
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ntask = (int)(G.task_end - G.task_begin);
+    const int nslab = nb / FR_KS;
+    const SsssmTaskD *my_tasks = tasks + G.task_begin;
+
+    const unsigned a_voff = (unsigned)lane * 16u;
+    const int a_piece = lane >> 3; // the 16-row piece this lane's 16 bytes of an A column belong to
+    const int bc = lane >> 3, bj = lane & 7;
+    unsigned b_voff[2];
+#pragma unroll
+    for (int par = 0; par < 2; par++)
+        b_voff[par] = ((unsigned)bc * (unsigned)nb + 2u * (unsigned)(bj ^ ((4 * par + (bc >> 1)) & 7))) * 8u;
+
+    v4f64 acc[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+            acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    unsigned touched = 0, nprod = 0;
+
+    // fragment addresses inside a stage (doubles)
+    const int a_frag = l4 * FR_LDA + wr * 16 + l15; // + kq * 4 * FR_LDA + mi * 32
+    int b_frag[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+    {
+        const int n = (wc + 4 * ni) * 16 + l15;
+        b_frag[ni][0] = FR_KS * FR_LDA + n * 16 + (l4 & 1);
+        b_frag[ni][1] = (n >> 1) & 7;
+    }
+
+    // step e of the current window as scalars
+    auto step_word = [&](int e) -> unsigned
+    { return (unsigned)__builtin_amdgcn_readfirstlane((int)s_step[e]); };
+    auto task_ptr = [&](const unsigned long long *tab, unsigned t) -> fr_gptr
+    {
+        const unsigned long long v = tab[t];
+        return (fr_gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    };
+    auto issue = [&](int e, int stage_no)
+    {
+        const unsigned w = step_word(e);
+        const unsigned ab = w & 0xFFu, bb = (w >> 8) & 0xFFu, t = w >> 20;
+        const int k0 = (int)((w >> 16) & 15u) * FR_KS;
+        const fr_gptr pa = task_ptr(s_pa, t), pb = task_ptr(s_pb, t);
+        double *stage = lds + stage_no * FR_STAGE_DOUBLES;
+        const bool a_live = (ab >> a_piece) & 1u;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int k = wave + 8 * h;
+            const unsigned off = a_live ? (unsigned)(((k0 + k) * nb + M0) * 8) + a_voff : 0u;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dg_scalar_base(pa) + off), (fr_lptr)(stage + k * FR_LDA), 16, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int g = wave + 8 * h;
+            const bool b_live = (bb >> (g >> 1)) & 1u;
+            const unsigned off = b_live ? (unsigned)(((N0 + 8 * g) * nb + k0) * 8) + b_voff[wave & 1] : 0u;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dg_scalar_base(pb) + off), (fr_lptr)(stage + FR_KS * FR_LDA + g * 128), 16, 0, 0);
+        }
+    };
+
+    int stage_head = 0; // stage the next consumed step sits in (stages are used round-robin across windows)
+    for (int win0 = 0; win0 < ntask; win0 += TL_WINDOW)
+    {
+        // ---- the window's step list (no DMA is in flight here: plain barriers) --------------------------------------
+        __syncthreads();
+        unsigned v = 0;
+        {
+            const int t_ = tid >> 4, s_ = tid & 15;
+            if (tid < TL_WINDOW * 16 && win0 + t_ < ntask && s_ < nslab)
+            {
+                const SsssmTaskD &Tm = my_tasks[win0 + t_];
+                const double *pa_ = reinterpret_cast<const double *>(Tm.a.val), *pb_ = reinterpret_cast<const double *>(Tm.b.val);
+                unsigned ab_, bb_ = 0;
+                if (Tm.has_map)
+                {
+                    ab_ = ((unsigned)Tm.amap[s_] >> (M0 / 16)) & 0xFFu;
+                    bb_ = ((unsigned)Tm.bmap_t[s_] >> (N0 / 16)) & 0xFFu;
+                }
+                else
+                {
+                    ab_ = ((unsigned)mirror_map(pa_, nb)[s_] >> (M0 / 16)) & 0xFFu;
+                    const uint4 mb_ = *reinterpret_cast<const uint4 *>(mirror_map(pb_, nb) + N0 / 16);
+                    const unsigned w_[4] = {mb_.x, mb_.y, mb_.z, mb_.w};
+#pragma unroll
+                    for (int c_ = 0; c_ < 8; c_++)
+                        bb_ |= (((w_[c_ >> 1] >> (16 * (c_ & 1))) >> s_) & 1u) << c_;
+                }
+                if (ab_ && bb_ && (!G.slab_mask || ((G.slab_mask >> s_) & 1u)))
+                    v = (bb_ << 8) | ab_ | ((unsigned)s_ << 16) | ((unsigned)t_ << 20);
+                if (s_ == 0)
+                {
+                    s_pa[t_] = (unsigned long long)pa_;
+                    s_pb[t_] = (unsigned long long)pb_;
+#if PG_PLANES > 1
+                    s_sign[t_] = Tm.sign;
+#endif
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(v != 0);
+        if (lane == 0)
+            s_cnt[wave] = (u32)__builtin_popcountll(bal);
+        __syncthreads();
+        unsigned at = (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), all = 0;
+#pragma unroll
+        for (int w_i = 0; w_i < FR_THREADS / 64; w_i++)
+        {
+            const unsigned c_ = s_cnt[w_i];
+            at += w_i < wave ? c_ : 0u;
+            all += c_;
+        }
+        if (v)
+            s_step[at] = v;
+        __syncthreads();
+        const int T = __builtin_amdgcn_readfirstlane((int)all);
+        if (T == 0)
+            continue;
+
+        // ---- the pipeline over the window's T live steps -------------------------------------------------------------
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; p++)
+            if (p < T)
+                issue(p, (stage_head + p) % STAGES);
+        for (int st = 0; st < T; st++)
+        {
+            const int ahead = min(STAGES - 2, T - 1 - st);
+            if (STAGES >= 4 && ahead >= 2)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (STAGES >= 3 && ahead >= 1)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (st + STAGES - 1 < T)
+                issue(st + STAGES - 1, (stage_head + st + STAGES - 1) % STAGES);
+            const double *sA = lds + ((stage_head + st) % STAGES) * FR_STAGE_DOUBLES;
+            const unsigned w = step_word(st);
+            const unsigned ab = w & 0xFFu, bb = (w >> 8) & 0xFFu;
+            // this wavefront's live pieces: rows 2 mi + wr, columns wc + 4 ni
+            const unsigned a4 = ((ab >> wr) & 1u) | (((ab >> (2 + wr)) & 1u) << 1) | (((ab >> (4 + wr)) & 1u) << 2) | (((ab >> (6 + wr)) & 1u) << 3);
+            const unsigned b2 = ((bb >> wc) & 1u) | (((bb >> (wc + 4)) & 1u) << 1);
+            if (a4 && b2)
+            {
+                nprod += (unsigned)(__builtin_popcount(a4) * __builtin_popcount(b2));
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+                    if ((b2 >> ni) & 1u)
+                        touched |= a4 << (4 * ni);
+#if PG_PLANES > 1
+                const bool add = s_sign[w >> 20] < 0;
+#endif
+                // fragments of k-quarter kq + 1 are read while the matrix cores work on kq (dead pieces are read too: the
+                // addresses are valid LDS, the values are never used)
+                double fa[2][4], fb[2][2];
+#define TL_READ(buf_, kq_)                                                                            \
+    {                                                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < 4; mi++) fa[buf_][mi] = sA[a_frag + (kq_) * 4 * FR_LDA + mi * 32]; \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ni++) fb[buf_][ni] = sA[b_frag[ni][0] + 2 * ((2 * (kq_) + (l4 >> 1)) ^ b_frag[ni][1])]; \
+    }
+                TL_READ(0, 0)
+#pragma unroll
+                for (int kq = 0; kq < FR_KS / 4; kq++)
+                {
+                    if (kq + 1 < FR_KS / 4)
+                        TL_READ((kq + 1) & 1, kq + 1)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++)
+                    {
+                        if (!((b2 >> ni) & 1u))
+                            continue;
+#pragma unroll
+                        for (int mi = 0; mi < 4; mi++)
+                            if ((a4 >> mi) & 1u)
+                            {
+#if PG_PLANES > 1
+                                if (add)
+                                    acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kq & 1][ni], fa[kq & 1][mi], acc[ni][mi], 0, 0, 0);
+                                else
+#endif
+                                    acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kq & 1][ni], fa[kq & 1][mi], acc[ni][mi], 0, 0, DG_NEG_A);
+                            }
+                    }
+                }
+#undef TL_READ
+            }
+        }
+        stage_head = (stage_head + T) % STAGES;
+    }
+    if (product_counter && lane == 0 && nprod)
+        atomicAdd(product_counter, (unsigned long long)nprod);
+
+    // C += acc on the touched pieces: register r of lane l of piece (ni, mi) is C(M0 + (2 mi + wr) 16 + (l & 15), N0 + (wc + 4 ni) 16 + 4 r + (l >> 4))
+    double __attribute__((address_space(1))) *C = (double __attribute__((address_space(1))) *)reinterpret_cast<double *>(G.cdense);
+    const unsigned c_voff = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
+#define TL_C(ni_, mi_, r_)                                                                           \
+    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((const char __attribute__((address_space(1))) *)C +                    \
+                                                                  ((size_t)(N0 + (wc + 4 * (ni_)) * 16 + 4 * (r_)) * nb + M0 + wr * 16) * 8) + \
+                                                   dg_lane_offset(c_voff) + (mi_) * 256))
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+    {
+        const unsigned t4 = (touched >> (4 * ni)) & 0xFu;
+        if (!t4)
+            continue;
+        if (G.atomic)
+        {
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+            {
+                if (!((t4 >> mi) & 1u))
+                    continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (acc[ni][mi][r] != 0.0)
+                        atomicAdd((double *)&TL_C(ni, mi, r), acc[ni][mi][r]);
+            }
+            continue;
+        }
+        double old[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                old[mi][r] = ((t4 >> mi) & 1u) ? TL_C(ni, mi, r) : 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+        {
+            if (!((t4 >> mi) & 1u))
+                continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                TL_C(ni, mi, r) = old[mi][r] + acc[ni][mi][r];
+        }
+    }
+#undef TL_C
+}

@@ -505,6 +505,7 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
 #if defined(PG_DENSE_UPDATES)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 #include "pg_hip_dense.h"
+#include "pg_hip_front.h"
 #endif
 #if defined(CALCULATE_TYPE_R64)
 #include "pg_hip_trsm_dense.h"
@@ -1789,6 +1790,14 @@ struct Backend
     bool bg_active = false;
     std::unordered_set<const void *> bg_tiles;
     long long opt_background_updates = 1; // PANGULU_HIP_BACKGROUND_UPDATES=0 / option 14
+    // dense-front kernel (pg_hip_front.h) for the (destination, tile) pairs all of whose queued updates have every 16 x 16
+    // piece live: LDS stages of its operand pipeline (2, 3 or 4; 0 = off, everything through the general kernel)
+    long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15
+    long long opt_front_unit = 1;   // PANGULU_HIP_FRONT_UNIT: consecutive destinations of the front launch that share an XCD
+    // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 2 / 3 / 4 = the
+    // LDS-DMA pipeline with that many stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h)
+    long long opt_tiles_stages = 2; // PANGULU_HIP_TILES_STAGES / option 16
+    unsigned long long front_workgroups = 0, general_workgroups = 0;
     long long opt_records_stream = 1; // PANGULU_HIP_RECORDS_STREAM=0: sparsify on the main stream as before
     int nb_cfg = 0;
     // options
@@ -1875,6 +1884,16 @@ void ensure_ready()
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_bg_done, hipEventDisableTiming));
     if (const char *e = getenv("PANGULU_HIP_BACKGROUND_UPDATES"))
         B.opt_background_updates = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_FRONT_STAGES"))
+        B.opt_front_stages = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_FRONT_UNIT"))
+        B.opt_front_unit = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_TILES_STAGES"))
+        B.opt_tiles_stages = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_GROUP_CHUNK"))
+        B.opt_group_chunk = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_SMALL_LAUNCH_TASKS"))
+        B.opt_small_launch_tasks = atol(e);
     // Descriptors are written once by the host and read once per workgroup: the kernels read them straight from
     // pinned host memory (non-coherent, so the device L2 may cache them) instead of waiting for a staging copy per
     // launch (rocprofv3 showed ~1900 blit dispatches, ~50 ms, per factorisation of the bench matrix).
@@ -2207,7 +2226,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
         // (per update: a task descriptor in each class -- PG_PLANES^2 real products on the MFMA side --, a group in each, four
         // work items per MFMA group; the K-split of very small launches multiplies groups and work items of <= 64 tasks by four)
         const size_t per_task = sizeof(SsssmTaskD) * (1 + PG_PLANES * PG_PLANES) + sizeof(SsssmGroupD) * (1 + PG_PLANES) +
-                                sizeof(SsssmWorkD) * 4 * PG_PLANES;
+                                sizeof(SsssmWorkD) * 8 * PG_PLANES;
         size_t max_tasks = (seg.cap - 64 * 4 * PG_PLANES * (sizeof(SsssmGroupD) + 4 * sizeof(SsssmWorkD)) - 4096) / per_task;
         size_t take = std::min(n - i, std::min(max_tasks, launch_chunk_tasks()));
         SsssmTaskD *d_tasks_s, *d_tasks_d;
@@ -2220,9 +2239,12 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
         SsssmGroupD *groups_d = seg.alloc<SsssmGroupD>(take * ksplit * PG_PLANES, &d_groups_d);
         static std::vector<unsigned short> live_k; // per dense task and tile: K-slabs in which both operands have entries
         live_k.assign(take * 4 * PG_PLANES * PG_PLANES, 0);
-        SsssmWorkD *d_work;
-        SsssmWorkD *work = seg.alloc<SsssmWorkD>(take * ksplit * 4 * PG_PLANES, &d_work); // every workgroup of the MFMA launch
-        if (!tasks_s || !tasks_d || !groups_s || !groups_d || !work)
+        static std::vector<unsigned char> full_t; // per dense task: tiles on which the update is a dense-front product
+        full_t.assign(take * PG_PLANES * PG_PLANES, 0);
+        SsssmWorkD *d_work, *d_work_f;
+        SsssmWorkD *work = seg.alloc<SsssmWorkD>(take * ksplit * 4 * PG_PLANES, &d_work); // every workgroup of the MFMA launch ...
+        SsssmWorkD *work_f = seg.alloc<SsssmWorkD>(take * 4 * PG_PLANES, &d_work_f);      // ... and of the dense-front launch
+        if (!tasks_s || !tasks_d || !groups_s || !groups_d || !work || !work_f)
         {
             fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
             exit(EXIT_FAILURE);
@@ -2289,6 +2311,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
             {
                 SsssmTaskD T;
                 unsigned short live[4];
+                unsigned char full; // bit tl: every 16 x 16 piece of both operands that meets tile tl is live (dense front)
             };
             static thread_local std::vector<Heavy> heavy;
             heavy.clear();
@@ -2332,11 +2355,23 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                                      : (sa && sb && sa->occ_valid && sb->occ_valid)
                                          ? (unsigned short)(sa->occ_a[tl % tiles_per_dim] & sb->occ_b[tl / tiles_per_dim])
                                          : (unsigned short)0xFFFF;
+                    H.full = 0;
                     if (sa && sb && sa->occ_valid && sb->occ_valid)
                     {
                         H.T.has_map = 1;
                         memcpy(H.T.amap, sa->occ_map, sizeof(H.T.amap));
                         memcpy(H.T.bmap_t, sb->occ_map_t, sizeof(H.T.bmap_t));
+                        const int nslab = nb / 16;
+                        const unsigned pm = nb >= 128 ? 0xFFu : ((1u << nslab) - 1u);
+                        for (int tl = 0; tl < tiles_per_dim * tiles_per_dim; tl++)
+                        {
+                            const int tm = tl % tiles_per_dim, tn = tl / tiles_per_dim;
+                            bool all = true;
+                            for (int sl = 0; sl < nslab && all; sl++)
+                                all = (((unsigned)H.T.amap[sl] >> (8 * tm)) & pm) == pm && (((unsigned)H.T.bmap_t[sl] >> (8 * tn)) & pm) == pm;
+                            if (all)
+                                H.full |= (unsigned char)(1u << tl);
+                        }
                     }
                     heavy.push_back(H);
                     bytes_d += by;
@@ -2390,6 +2425,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
 #endif
                         for (int tl = 0; tl < 4; tl++)
                             live_k[nd * 4 + tl] = H.live[tl];
+                        full_t[nd] = H.full;
                         tasks_d[nd++] = T;
                     }
                 SsssmGroupD GP = G;
@@ -2477,16 +2513,27 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 HIP_CHECK(hipStreamWaitEvent(ds, B.ev_fork, 0));
             }
             {
-                // one workgroup per (group, tile) some update of the group can reach
+                // one workgroup per (group, tile) some update of the group can reach.  Pairs whose whole queue is dense-front
+                // products (every 16 x 16 piece of every operand live, no K-split) go to the front kernel's list
                 int tiles = nb / DG_TILE;
-                size_t nw = 0;
+                size_t nw = 0, nf = 0;
+                const bool front_on = B.opt_front_stages >= 2 && (nb == 128 || nb == 256);
                 for (size_t gi = 0; gi < gd; gi++)
+                {
+                    const SsssmGroupD &Gd = groups_d[gi];
+                    unsigned all_full = (front_on && !Gd.slab_mask) ? 0xFu : 0u;
+                    for (u32 t = Gd.task_begin; t < Gd.task_end && all_full; t++)
+                        all_full &= full_t[t];
                     for (int tl = 0; tl < tiles * tiles; tl++)
-                        if ((groups_d[gi].live_tiles >> tl) & 1u)
+                        if ((Gd.live_tiles >> tl) & 1u)
                         {
-                            const SsssmGroupD &Gd = groups_d[gi];
-                            work[nw++] = SsssmWorkD{Gd.cdense, Gd.task_begin, Gd.task_end, Gd.atomic, Gd.slab_mask, (u32)tl, 0u};
+                            const SsssmWorkD item{Gd.cdense, Gd.task_begin, Gd.task_end, Gd.atomic, Gd.slab_mask, (u32)tl, 0u};
+                            if ((all_full >> tl) & 1u)
+                                work_f[nf++] = item;
+                            else
+                                work[nw++] = item;
                         }
+                }
                 LaunchTimer lt(5, ds);
                 if (B.opt_profile)
                 {
@@ -2499,14 +2546,39 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                             for (int tl = 0; tl < tiles * tiles; tl++)
                                 steps += (unsigned long long)__builtin_popcount(live_k[(size_t)t * 4 + tl] & kmask);
                     }
-                    lt.tag[0] = nw;
+                    lt.tag[0] = nw + nf;
                     lt.tag[1] = nd;
                     lt.tag[2] = steps;
                 }
+                B.front_workgroups += nf;
+                B.general_workgroups += nw;
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
-                if (nw)
-                    hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb,
-                                       B.opt_count_flops ? B.d_flops + 6 : nullptr, debug_ssssm ? B.d_flops + 8 : nullptr, d_work);
+                unsigned long long *pc = B.opt_count_flops ? B.d_flops + 6 : nullptr;
+                if (nf)
+                {
+                    // the longest-running workgroups first: the front launch, then the general one fills in behind it
+                    const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_front_unit);
+                    if (B.opt_front_stages >= 4)
+                        hipLaunchKernelGGL((ssssm_front_f64_kernel<4, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                    else if (B.opt_front_stages == 3)
+                        hipLaunchKernelGGL((ssssm_front_f64_kernel<3, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                    else
+                        hipLaunchKernelGGL((ssssm_front_f64_kernel<2, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                }
+                if (nw && B.opt_tiles_stages >= 2)
+                {
+                    // round 3: LDS-DMA pipeline, strided piece ownership (pg_hip_front.h)
+                    const unsigned unit = (unsigned)(tiles * tiles);
+                    if (B.opt_tiles_stages >= 4)
+                        hipLaunchKernelGGL((ssssm_tiles_f64_kernel<4>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                    else if (B.opt_tiles_stages == 3)
+                        hipLaunchKernelGGL((ssssm_tiles_f64_kernel<3>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                    else
+                        hipLaunchKernelGGL((ssssm_tiles_f64_kernel<2>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                }
+                else if (nw)
+                    hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb, pc,
+                                       debug_ssssm ? B.d_flops + 8 : nullptr, d_work);
             }
             if (B.opt_count_flops)
                 hipLaunchKernelGGL(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, ds, d_tasks_d, nb, B.d_flops + 5);
@@ -3594,6 +3666,12 @@ extern "C"
         case PANGULU_HIP_OPT_BACKGROUND_UPDATES:
             B.opt_background_updates = value;
             return 0;
+        case PANGULU_HIP_OPT_FRONT_STAGES:
+            B.opt_front_stages = value;
+            return 0;
+        case PANGULU_HIP_OPT_TILES_STAGES:
+            B.opt_tiles_stages = value;
+            return 0;
         case PANGULU_HIP_OPT_RECORDS_STREAM:
         {
             ensure_ready();
@@ -3753,13 +3831,16 @@ extern "C"
                     f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15]);
         for (int c = 1; c <= 5; c++)
             B.stats.flops[c] = (double)f[c];
-        B.stats.mfma_flops_executed = 8192.0 * (double)f[6]; // 16 x 16 x 16 products counted by the MFMA update kernel
+        B.stats.mfma_flops_executed = 8192.0 * (double)f[6]; // 16 x 16 x 16 products counted by the MFMA update kernels
+        B.stats.ssssm_front_workgroups = B.front_workgroups;
+        B.stats.ssssm_general_workgroups = B.general_workgroups;
         if (out)
             *out = B.stats;
         if (reset)
         {
             memset(&B.stats, 0, sizeof(B.stats));
             B.mfma_flops_executed = 0;
+            B.front_workgroups = B.general_workgroups = 0;
             HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(f)));
         }
     }

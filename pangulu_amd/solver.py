@@ -195,4 +195,6 @@ def hip_stats(h_or_lib, reset=False):
                          flops=float(st.flops[k]), elapsed_ms=float(st.elapsed_ms[k]))
     out["ssssm_dense_mfma"]["mfma_flops_executed"] = float(st.mfma_flops_executed)
     out["tstrf"]["dense_path_tasks"] = int(st.trsm_dense_tasks)  # TSTRF + GESSM tasks solved on the matrix cores
+    out["ssssm_dense_mfma"]["front_workgroups"] = int(st.ssssm_front_workgroups)      # dense-front kernel (pg_hip_front.h)
+    out["ssssm_dense_mfma"]["general_workgroups"] = int(st.ssssm_general_workgroups)  # general MFMA kernel (pg_hip_dense.h)
     return out

@@ -71,6 +71,61 @@ def test_dense_blocks_take_the_mfma_path():
     assert np.abs(LU - A).max() <= 1e-11 * np.abs(A).max()
 
 
+@pytest.mark.parametrize("stages", [0, 2, 3, 4])
+@pytest.mark.parametrize("n,nb", [(2560, 256), (1536, 128)])
+def test_dense_front_kernel(n, nb, stages):
+    """A dense matrix: every tile of every update is a dense-front product and runs on the LDS-DMA kernel (pg_hip_front.h)
+    with 2, 3 or 4 stages -- or, with the switch at 0, on the general MFMA kernel; queues of up to five updates per
+    destination.  Factors against the oracle and against L U = A."""
+    import scipy.sparse as sp
+
+    from pangulu_amd import _lib
+
+    rng = np.random.default_rng(nb + stages)
+    A = rng.uniform(-1, 1, (n, n))
+    A += np.diag(np.abs(A).sum(axis=1) + 1.0)
+    S = sp.csc_matrix(A)
+    mat = (n, S.indptr.astype(np.uint64), S.indices.astype(np.uint32), S.data.copy(), None)
+    gpu = factorize(mat, nb, "hip", ordering="identity", hip_options={_lib.HIP_OPT_FRONT_STAGES: stages})
+    ref = factorize(mat, nb, oracle_library("r64"), ordering="identity")
+    st = gpu["hip_stats"]["ssssm_dense_mfma"]
+    assert st["tasks"] > 0, st
+    if stages:
+        # (launches with a handful of updates are cut four ways along K and stay on the general kernel)
+        assert st["front_workgroups"] > 0, st
+    else:
+        assert st["front_workgroups"] == 0 and st["general_workgroups"] > 0, st
+    for f in ("L", "U"):
+        assert max_rel_diff(gpu[f], ref[f]) <= 1e-12
+    LU = (gpu["L"] @ gpu["U"]).toarray()
+    assert np.abs(LU - A).max() <= 1e-11 * np.abs(A).max()
+    assert gpu["factor_check"] <= 1e-12 and gpu["residual"] <= 1e-12
+    counted = sum(v["flops"] for v in gpu["hip_stats"].values())
+    assert counted == gpu["info"]["flop"]
+    assert gpu["hip_stats"]["ssssm_dense_mfma"]["mfma_flops_executed"] == 2.0 * nb ** 3 * st["tasks"]
+
+
+@pytest.mark.parametrize("tiles_stages", [0, 2, 3, 4])
+@pytest.mark.parametrize("name,gen,nb", [("fem27_20_nb128", lambda: M.fem27(20), 128), ("fem27_24_nb256", lambda: M.fem27(24), 256),
+                                         ("shell_40_nb256", lambda: M.shell(40, 40), 256)])
+def test_general_update_kernels(name, gen, nb, tiles_stages):
+    """The general MFMA update kernel of round 3 (LDS-DMA pipeline with 2 / 3 / 4 stages, strided piece ownership) and round
+    2's (0), with the dense-front kernel off so that every tile goes through it: partly filled tiles, queues longer than
+    one window in the lower levels."""
+    from pangulu_amd import _lib
+
+    mat = gen()
+    gpu = factorize(mat, nb, "hip", hip_options={_lib.HIP_OPT_FRONT_STAGES: 0, _lib.HIP_OPT_TILES_STAGES: tiles_stages})
+    ref = factorize(mat, nb, oracle_library("r64"))
+    st = gpu["hip_stats"]["ssssm_dense_mfma"]
+    assert st["tasks"] > 0 and st["general_workgroups"] > 0 and st["front_workgroups"] == 0, st
+    for f in ("L", "U"):
+        assert max_rel_diff(gpu[f], ref[f]) <= 1e-12, (name, f)
+    assert gpu["factor_check"] <= 1e-12 and gpu["residual"] <= 1e-12
+    counted = sum(v["flops"] for v in gpu["hip_stats"].values())
+    assert counted == gpu["info"]["flop"]
+
+
 DENSE_MODE_CASES = [
     ("fem27_10_nb256", lambda: M.fem27(10), 256, "nd"),
     ("shell_14x12_nb128", lambda: M.shell(14, 12), 128, "nd"),
