@@ -1785,11 +1785,14 @@ struct Backend
     // panel (the following call) run beside them instead of behind them (fem27(112): the dense solves ran ALONE on the
     // device for 65 of 974 ms).  The destinations of the launches in flight are remembered; the first later call that
     // touches one of them -- as destination or operand -- makes the main stream wait first (join_background).
+    // MEASURED (fem27(112), one box, four steps each): the overlap is there -- dense solves exclusive 65 -> 17 ms, GETRF 13 -> 4,
+    // two or more classes at once 81 -> 245 ms -- and the factorisation does not get faster: 954.7 ms with it, 940.7 ms
+    // without.  The update kernels are throughput-bound and lose what the latency-bound kernels beside them gain.  OFF by default.
     hipStream_t stream_bg = nullptr;
     hipEvent_t ev_bg_fork = nullptr, ev_bg_done = nullptr;
     bool bg_active = false;
     std::unordered_set<const void *> bg_tiles;
-    long long opt_background_updates = 1; // PANGULU_HIP_BACKGROUND_UPDATES=0 / option 14
+    long long opt_background_updates = 0; // PANGULU_HIP_BACKGROUND_UPDATES=1 / option 14 (off: measured no gain, see Backend::stream_bg)
     // dense-front kernel (pg_hip_front.h) for the (destination, tile) pairs all of whose queued updates have every 16 x 16
     // piece live: LDS stages of its operand pipeline (2, 3 or 4; 0 = off, everything through the general kernel)
     long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15

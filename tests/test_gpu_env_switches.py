@@ -22,6 +22,14 @@ SWITCHES = [
     {"PANGULU_HIP_RESERVED_CUS": "8"},         # CU-masked bulk streams
     {"PANGULU_HIP_LAUNCH_CHUNK": "64"},        # launches cut into chunks of 64 tasks
     {"PANGULU_AMD_ASYNC_LAUNCH": "0"},         # platform calls on the scheduler thread
+    {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0"},  # lazy updates: queues accumulate until the destination's own panel task
+    {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64"},
+    {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64", "_matrix": "fem27"},  # (long queues cut by launch chunks)
+    {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_SMALL_LAUNCH_TASKS": "0", "_matrix": "fem27"},
+    {"PANGULU_AMD_PANEL_FIRST": "1", "PG_TEST_HIP_OPTIONS": "14=1"},  # look-ahead updates on the background stream
+    {"PANGULU_AMD_FORCE_MULTI_LOOP": "1"},     # one rank through the multi-rank scheduler loop (launcher thread + markers)
+    {"PG_TEST_HIP_OPTIONS": "15=0,16=0"},      # round 2's MFMA update kernel
+    {"PG_TEST_HIP_OPTIONS": "15=3,16=3"},      # LDS-DMA update kernels with three stages
     {"PANGULU_AMD_BIND_NUMA": "0"},
     {"HSA_ENABLE_INTERRUPT": "0"},             # what bench.py sets
     # the configuration bench.py TIMES: structural flop counting of the MFMA path off (the kernel gets a null product
@@ -35,9 +43,11 @@ SWITCHES = [
 @pytest.mark.parametrize("env", SWITCHES, ids=["+".join("%s=%s" % kv for kv in e.items()) or "defaults" for e in SWITCHES])
 def test_backend_switch_keeps_parity(env):
     e = dict(os.environ)
+    env = dict(env)
+    which = env.pop("_matrix", "shell")
     e.update(env)
     e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "env_switch_worker.py"), "shell"], env=e, cwd=ROOT,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "env_switch_worker.py"), which], env=e, cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
