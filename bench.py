@@ -649,6 +649,8 @@ def gpu_worker_main(args):
             "init_s": round(t_init, 2),
             "hbm_used_GB": round(used.value / 1e9, 2), "owned_records_GB": round(info["owned_bytes"] / 1e9, 2),
             "host_sched_s_last_step": round(info["time_numeric_host_sched"], 4),
+            # one rank: the first pangulu_gstrf of the handle (a warm-up step) recorded its launches, the timed steps replay the list
+            "static_schedule_replayed": bool(info["replayed"]),
             "batches_per_step": int(info["batches"]),
             "roofline": roofline,
             "model": model,

@@ -94,6 +94,7 @@ extern "C"
         double sampled_flop;                  /* structural flops of the tasks that were executed                      */
         unsigned long long sampled_tasks;
         double time_numeric_platform;         /* seconds inside the platform's hybrid_batched calls (compute thread or launcher) */
+        unsigned long long replayed;          /* 1: the last pangulu_gstrf replayed the handle's recorded launch schedule        */
         /* Structure-only model of the WHOLE factorisation for this handle's rank count, evaluated by every rank at
          * pangulu_init from the replicated symbolic pattern (HBM 8 TB/s, 78.6 TFLOP/s, 153 GB/s per xGMI link unless
          * PANGULU_AMD_MODEL_HBM_GBS / _FP_TFLOPS / _LINK_GBS say otherwise):
@@ -126,6 +127,12 @@ extern "C"
      * block records (call it after pangulu_init, before the first gstrf); reset_numeric() restores the records
      * from it with one device-to-device copy and re-arms the dependency counters, so the next pangulu_gstrf
      * factorises the same matrix again with its inputs already resident in HBM.  Both return 0 on success. */
+    /* New values on the pattern the handle was initialised with (csc_value in the order of the csc_rowidx given to
+     * pangulu_init, on rank 0): the block records are refilled and uploaded, ordering, symbolic factorisation, records,
+     * mapping -- and, on one rank, the recorded launch schedule -- are kept, and the next pangulu_gstrf factorises the new
+     * matrix (time stepping / Newton iterations on a fixed mesh).  Collective.  Returns 0 on success, 1 when the handle was
+     * built with scaling on (the matching depends on the values: call pangulu_init). */
+    int pangulu_amd_update_values(void **pangulu_handle, const sparse_value_t *csc_value);
     int pangulu_amd_snapshot(void **pangulu_handle);
     int pangulu_amd_reset_numeric(void **pangulu_handle);
 

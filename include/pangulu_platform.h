@@ -308,6 +308,14 @@ extern "C"
      * src/pangulu_thread.c:3-12).  The native host calls it around pangulu_init / gstrf / gstrs.  Returns 0 when the mask
      * was changed / restored, non-zero when there was nothing to do (no NUMA information, PANGULU_AMD_BIND_NUMA=0). */
     int pangulu_platform_0201001_bind_near_device(int enable);
+    /* Optional: the static schedule of a factorisation.  For a host whose call sequence is a pure function of the block
+     * pattern (one rank, dependency-free batches in a fixed order -- the native scheduler's) the launches of one
+     * factorisation can be recorded once and replayed for every later factorisation of the same pattern, with no host
+     * work per task.  cmd 1: start recording everything hybrid_batched issues, for `owner` (an opaque token); 2: stop
+     * (returns the number of recorded operations); 3: replay (0 = replayed, 1 = nothing valid: other owner, other
+     * options, nothing recorded); 0: drop (the owner's blocks are about to be freed).  Profiled runs and the eager host
+     * mirror are not recorded (cmd 1 returns -1). */
+    long long pangulu_platform_0201001_schedule(int cmd, const void *owner);
     /* stream all numeric kernels are launched on (a hipStream_t); for event timing in bench.py */
     void *pangulu_platform_0201001_get_stream(void);
     /* Cumulative per-kernel-class counters since the last reset.  Classes: 1 GETRF, 2 TSTRF, 3 GESSM,

@@ -78,6 +78,7 @@ class Info(ctypes.Structure):
         ("sampled_flop", ctypes.c_double),
         ("sampled_tasks", ctypes.c_ulonglong),
         ("time_numeric_platform", ctypes.c_double),
+        ("replayed", ctypes.c_ulonglong),
         ("model_ranks_tstar_max", ctypes.c_double),
         ("model_ranks_tstar_sum", ctypes.c_double),
         ("model_ranks_tstar_hbm", ctypes.c_double),
@@ -196,6 +197,8 @@ def load(vtype="r64", test_hooks=False):
         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong), vpp, vpp, vpp,
     ]
     lib.pangulu_amd_owned_block.restype = ctypes.c_int
+    lib.pangulu_amd_update_values.argtypes = [vpp, vp]
+    lib.pangulu_amd_update_values.restype = ctypes.c_int
     lib.pangulu_amd_snapshot.argtypes = [vpp]
     lib.pangulu_amd_snapshot.restype = ctypes.c_int
     lib.pangulu_amd_reset_numeric.argtypes = [vpp]

@@ -73,6 +73,7 @@ void bind_builtin_hip(Platform &p)
     p.marker_wait = pangulu_platform_0201001_marker_wait;
     p.block_trsv = pangulu_platform_0201001_block_trsv;
     p.block_spmv_add = pangulu_platform_0201001_block_spmv_add;
+    p.schedule = pangulu_platform_0201001_schedule;
     p.bind_near_device = pangulu_platform_0201001_bind_near_device;
 }
 
@@ -403,6 +404,8 @@ extern "C"
         comm->bcast(A.rowidx.data(), sizeof(u32) * A.rowidx.size(), 0);
         comm->bcast(A.value.data(), sizeof(val_t) * A.value.size(), 0);
         S->n_user = A.n;
+        S->user_colptr = A.colptr; // (pattern of the matrix as the user passed it: pangulu_amd_update_values maps new values through it)
+        S->user_rowidx = A.rowidx;
         S->info.n = A.n;
         S->info.nnz = A.nnz();
         S->info.nb = S->nb;
@@ -726,6 +729,44 @@ extern "C"
             return 1;
         NearDevice near(active_platform());
         *relative_error = factor_check(*S);
+        return 0;
+    }
+
+    int pangulu_amd_update_values(void **pangulu_handle, const sparse_value_t *csc_value)
+    {
+        Solver *S = (Solver *)*pangulu_handle;
+        Comm *comm = world();
+        if (!S->scale_row.empty() || S->analysis_only)
+            return 1; // (with scaling on, new values would need a new matching: call pangulu_init)
+        // the user's entry p of column j sits at (iperm[i], iperm[j]) of the permuted matrix; padding rows keep their unit diagonal
+        const u64 nnz = S->info.nnz;
+        std::vector<val_t> vals(nnz);
+        if (comm->rank == 0)
+            std::copy((const val_t *)csc_value, (const val_t *)csc_value + nnz, vals.begin());
+        comm->bcast(vals.data(), sizeof(val_t) * nnz, 0);
+        // Aperm holds the pattern; rebuild its values through the same permutation: entry order inside a permuted column is
+        // by row, so locate each entry by binary search
+        if (S->user_colptr.size() != (size_t)S->n_user + 1)
+            return 2;
+        CscMatrix &B = S->Aperm;
+#pragma omp parallel for schedule(dynamic, 512)
+        for (i64 j_ = 0; j_ < (i64)S->n_user; j_++)
+        {
+            const u32 j = (u32)j_, pj = S->iperm[j];
+            for (u64 p = S->user_colptr[j]; p < S->user_colptr[j + 1]; p++)
+            {
+                const u32 pi = S->iperm[S->user_rowidx[p]];
+                const u32 *b0 = B.rowidx.data() + B.colptr[pj], *b1 = B.rowidx.data() + B.colptr[pj + 1];
+                const u32 *hit = std::lower_bound(b0, b1, pi);
+                if (hit == b1 || *hit != pi)
+                    fatal("pangulu_amd_update_values: entry (%u,%u) is not in the pattern the handle was initialised with", S->user_rowidx[p], j);
+                B.value[hit - B.rowidx.data()] = vals[p];
+            }
+        }
+        NearDevice near(active_platform());
+        reload_values(*S, B);
+        if (S->arena_snapshot)
+            pangulu_amd_snapshot(pangulu_handle); // (bench-style resets restore the NEW values)
         return 0;
     }
 

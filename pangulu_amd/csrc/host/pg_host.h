@@ -75,6 +75,7 @@ struct Platform
     int (*bind_near_device)(int) = nullptr;
     void (*block_trsv)(pangulu_inblock_idx, int, pangulu_uint64_t, const pangulu_uint64_t *, const pangulu_hip_solve_row_t *, slot_t *const *,
                        const pangulu_exblock_idx *, val_t *, pangulu_uint64_t) = nullptr;
+    long long (*schedule)(int, const void *) = nullptr;
     void (*block_spmv_add)(pangulu_inblock_idx, pangulu_uint64_t, slot_t *const *, const pangulu_exblock_idx *, const pangulu_exblock_idx *, const int *,
                            const val_t *, val_t *, pangulu_uint64_t) = nullptr;
 };
@@ -311,6 +312,8 @@ struct Solver
     Symbolic sym;
     BlockPattern pat;
     CscMatrix Aperm;                       // kept for the factor check and residuals (rank 0 / all ranks)
+    std::vector<u64> user_colptr;          // pattern of the user's matrix (for pangulu_amd_update_values)
+    std::vector<u32> user_rowidx;
     // numeric state
     Storage storage;
     std::vector<slot_t *> slot_of;         // per non-diagonal block: owned / received slot, nullptr otherwise
@@ -330,6 +333,7 @@ struct Solver
     std::vector<u32> pending_dirty;        // owned slot indices with non-empty queues, in first-touch order
     u64 pending_total = 0;
     bool factored = false, host_values_current = true;
+    bool schedule_recorded = false;        // the back-end holds the launch list of this handle's factorisation (one rank)
     char *arena_snapshot = nullptr;        // pristine copy of the owned records (device side), see pangulu_amd_snapshot
     // statistics
     pangulu_amd_info_t info;
@@ -370,6 +374,8 @@ struct Solver
 
 void assign_subtrees(Solver &S);                          // subtree-to-rank mapping (multi-rank runs)
 void preprocess(Solver &S, const CscMatrix &Aperm);       // records, counters, bins, upload
+void scatter_values(Solver &S, const CscMatrix &Aperm);   // values of the permuted matrix into the owned records (host side)
+void reload_values(Solver &S, const CscMatrix &Aperm);    // new values on the same pattern: refill + upload + re-arm the counters
 void numeric_factorize(Solver &S);                        // the hot path
 void download_factors(Solver &S);                         // device -> host mirror of owned values
 void triangular_solve(Solver &S, val_t *rhs_permuted);    // forward + backward block sweeps (host kernels)

@@ -1069,17 +1069,45 @@ void numeric_factorize(Solver &S)
         fatal("pangulu_gstrf called twice on one handle (call pangulu_init again)");
     if (getenv("PANGULU_AMD_TRACE"))
         fprintf(stderr, "[pangulu_amd trace] rank %d: numeric factorisation starts\n", S.rank);
-    Sched sch(S);
-    S.info.sampled_flop = 0;
-    S.info.sampled_tasks = 0;
     Comm *comm = world();
     Platform &plat = active_platform();
+    // Static schedule (one rank on the device; PANGULU_AMD_REPLAY=0 turns it off): the launches of a factorisation depend on
+    // the block pattern and the back-end's options only, so the first pangulu_gstrf of a handle records them in the back-end
+    // (pangulu_platform_0201001_schedule) and every later one replays the list -- no scheduler, no descriptor building.
+    static const bool replay_on = !(getenv("PANGULU_AMD_REPLAY") && atoi(getenv("PANGULU_AMD_REPLAY")) == 0);
+    const bool can_schedule = replay_on && S.nproc == 1 && !plat.host_memory && plat.schedule && g_task_sample_stride <= 1 && !S.eager_host_mirror &&
+                              !getenv("PANGULU_AMD_FORCE_MULTI_LOOP");
     if (plat.set_option)
     {
         plat.set_option(PANGULU_HIP_OPT_HOST_MIRROR, S.eager_host_mirror ? 1 : 0);
         plat.set_option(PANGULU_HIP_OPT_ASSUME_INDEPENDENT, 1); // batches of this scheduler are dependency-free
-        plat.set_option(PANGULU_HIP_OPT_RESET_BLOCK_STATE, 0);  // block values were (re)loaded behind the back-end's back
     }
+    if (can_schedule && S.schedule_recorded)
+    {
+        comm->barrier();
+        const double t0 = wall_seconds();
+        if (plat.schedule(3, &S) == 0)
+        {
+            plat.synchronize();
+            S.info.time_numeric = wall_seconds() - t0;
+            S.info.time_numeric_host_sched = S.info.time_numeric_platform = 0;
+            S.info.replayed = 1;
+            for (auto &sl : S.storage.owned)
+                sl.data_status = PANGULU_DATA_READY;
+            S.rank_remain_task = 0;
+            S.factored = true;
+            S.host_values_current = false;
+            return;
+        }
+        S.schedule_recorded = false; // (other options than at recording time, or another handle recorded since: a normal run)
+    }
+    S.info.replayed = 0;
+    Sched sch(S);
+    S.info.sampled_flop = 0;
+    S.info.sampled_tasks = 0;
+    if (plat.set_option)
+        plat.set_option(PANGULU_HIP_OPT_RESET_BLOCK_STATE, 0);  // block values were (re)loaded behind the back-end's back
+    const bool recording = can_schedule && plat.schedule(1, &S) == 0;
     S.heap.clear();
     S.pending_total = 0;
     S.pending_dirty.clear();
@@ -1111,6 +1139,8 @@ void numeric_factorize(Solver &S)
     else
     {
         sch.compute_loop();
+        if (recording)
+            S.schedule_recorded = plat.schedule(2, &S) > 0;
         plat.synchronize();
     }
     if (getenv("PANGULU_AMD_TRACE"))

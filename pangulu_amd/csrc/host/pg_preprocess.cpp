@@ -402,6 +402,86 @@ void assign_subtrees(Solver &S)
     }
 }
 
+// scatter the permuted A into the owned patterns (zero elsewhere)
+// (the reference's pangulu_convert_block_fill_value_to_struct, src/pangulu_conversion.c:241-350)
+void scatter_values(Solver &S, const CscMatrix &A)
+{
+    const BlockPattern &P = S.pat;
+    const u32 nb = S.nb, n = S.n;
+    const int me = S.rank;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 j_ = 0; j_ < (i64)n; j_++)
+    {
+        u32 j = (u32)j_, bj = j / nb, c = j % nb;
+        for (u64 p = A.colptr[j]; p < A.colptr[j + 1]; p++)
+        {
+            u32 i = A.rowidx[p], bi = i / nb, r = i % nb;
+            slot_t *s = nullptr;
+            bool csr_row_search = false;
+            if (bi == bj)
+            {
+                if (i > j)
+                    s = S.diag_lower[bj];
+                else
+                {
+                    s = S.diag_upper[bj];
+                    csr_row_search = true;
+                }
+            }
+            else
+            {
+                if (S.owner(bi, bj) != me)
+                    continue;
+                u64 b = P.find(bi, bj);
+                if (b == ~0ull)
+                    fatal("entry (%u,%u) of A outside the symbolic block pattern", i, j);
+                s = S.slot_of[b];
+            }
+            if (!s)
+                continue;
+            u32 major = csr_row_search ? r : c, minor = csr_row_search ? c : r;
+            const pangulu_inblock_idx *b0 = s->rowindex + s->columnpointer[major];
+            const pangulu_inblock_idx *b1 = s->rowindex + s->columnpointer[major + 1];
+            const pangulu_inblock_idx *hit = std::lower_bound(b0, b1, (pangulu_inblock_idx)minor);
+            if (hit == b1 || *hit != minor)
+                fatal("entry (%u,%u) of A outside the symbolic pattern", i, j);
+            s->value[hit - s->rowindex] = A.value[p];
+        }
+    }
+}
+
+// New values on the same pattern (pangulu_amd_update_values): the records are zeroed, refilled from the permuted matrix and
+// uploaded; counters, slots and the recorded schedule of the handle stay as they are.
+void reload_values(Solver &S, const CscMatrix &A)
+{
+    Platform &plat = active_platform();
+    Storage &st = S.storage;
+    const u32 nb = S.nb;
+    for (auto &s : st.owned)
+        if (s.value)
+            memset((void *)s.value, 0, sizeof(val_t) * (size_t)s.columnpointer[nb]);
+    scatter_values(S, A);
+    if (!plat.host_memory)
+    {
+        plat.synchronize();
+        for (size_t c = 0; c < st.dchunks.size(); c++)
+            plat.memcpy_(st.dchunks[c], st.harena + c * st.dchunk_bytes, st.chunk_len(c), 0);
+        plat.synchronize();
+    }
+    S.remain = S.remain0;
+    S.remain_diag = S.remain_diag0;
+    S.rank_remain_task = S.rank_remain_task0;
+    S.rank_remain_recv = S.rank_remain_recv0;
+    for (auto &s : st.owned)
+        s.data_status = PANGULU_DATA_PREPARING;
+    for (auto &q : S.pending)
+        q.clear();
+    S.pending_dirty.clear();
+    S.pending_total = 0;
+    S.factored = false;
+    S.host_values_current = true;
+}
+
 void preprocess(Solver &S, const CscMatrix &A)
 {
     assign_subtrees(S);
@@ -628,47 +708,8 @@ void preprocess(Solver &S, const CscMatrix &A)
         }
     }
 
-    // ---- values: scatter the permuted A into the owned patterns (zero elsewhere) ----------------------
-    // (the reference's pangulu_convert_block_fill_value_to_struct, src/pangulu_conversion.c:241-350)
-#pragma omp parallel for schedule(dynamic, 256)
-    for (i64 j_ = 0; j_ < (analysis_only ? (i64)0 : (i64)n); j_++)
-    {
-        u32 j = (u32)j_, bj = j / nb, c = j % nb;
-        for (u64 p = A.colptr[j]; p < A.colptr[j + 1]; p++)
-        {
-            u32 i = A.rowidx[p], bi = i / nb, r = i % nb;
-            slot_t *s = nullptr;
-            bool csr_row_search = false;
-            if (bi == bj)
-            {
-                if (i > j)
-                    s = S.diag_lower[bj];
-                else
-                {
-                    s = S.diag_upper[bj];
-                    csr_row_search = true;
-                }
-            }
-            else
-            {
-                if (S.owner(bi, bj) != me)
-                    continue;
-                u64 b = P.find(bi, bj);
-                if (b == ~0ull)
-                    fatal("entry (%u,%u) of A outside the symbolic block pattern", i, j);
-                s = S.slot_of[b];
-            }
-            if (!s)
-                continue;
-            u32 major = csr_row_search ? r : c, minor = csr_row_search ? c : r;
-            const pangulu_inblock_idx *b0 = s->rowindex + s->columnpointer[major];
-            const pangulu_inblock_idx *b1 = s->rowindex + s->columnpointer[major + 1];
-            const pangulu_inblock_idx *hit = std::lower_bound(b0, b1, (pangulu_inblock_idx)minor);
-            if (hit == b1 || *hit != minor)
-                fatal("entry (%u,%u) of A outside the symbolic pattern", i, j);
-            s->value[hit - s->rowindex] = A.value[p];
-        }
-    }
+    if (!analysis_only)
+        scatter_values(S, A);
 
     // ---- dependency counters (src/pangulu_preprocessing.c:132-207, 443-556) ---------------------------
     S.remain.assign(nblk, 0);
@@ -964,6 +1005,8 @@ void download_factors(Solver &S)
 Solver::~Solver()
 {
     Platform &plat = active_platform();
+    if (schedule_recorded && plat.schedule)
+        plat.schedule(0, this); // the recorded launches point into this handle's arena and mirrors
     if (arena_snapshot)
     {
         if (plat.host_memory)

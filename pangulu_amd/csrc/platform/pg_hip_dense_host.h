@@ -359,8 +359,8 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify, bool
     {
         st = B.stream_rec;
         if (!fork_recorded)
-            HIP_CHECK(hipEventRecord(B.ev_rec_fork, after ? after : B.stream));
-        HIP_CHECK(hipStreamWaitEvent(st, B.ev_rec_fork, 0));
+            pg_event_record(B.ev_rec_fork, after ? after : B.stream);
+        pg_stream_wait(st, B.ev_rec_fork);
     }
     // (main-stream jobs need no join with the records stream: its jobs in flight write the records of FINISHED blocks
     // whose mirrors stay current; densify reads, and sparsify on the main stream rewrites, records of unfinished ones)
@@ -383,9 +383,9 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify, bool
         {
             LaunchTimer lt(densify ? 6 : 7, st);
             if (densify)
-                hipLaunchKernelGGL(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
+                PG_LAUNCH(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
             else
-                hipLaunchKernelGGL(sparsify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
+                PG_LAUNCH(sparsify_kernel, dim3((unsigned)take, slices), dim3(256), 0, st, d_jobs, nb);
         }
         HIP_CHECK(hipGetLastError());
         B.stats.launches[densify ? 6 : 7]++;
@@ -397,7 +397,7 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify, bool
     }
     if (st == B.stream_rec)
     {
-        HIP_CHECK(hipEventRecord(B.ev_rec, st));
+        pg_event_record(B.ev_rec, st);
         B.rec_dirty.store(true, std::memory_order_release);
     }
     jobs.clear();

@@ -31,6 +31,7 @@
 #include <atomic>
 #include <thread>
 #include <mutex>
+#include <functional>
 #include <unordered_map>
 #include <unordered_set>
 #include <unordered_set>
@@ -1830,6 +1831,48 @@ struct Backend
 
 Backend B;
 
+// ---------------------------------------------------------------------------------------------------------------
+// Static schedule (round 3).  For one rank the sequence of launches of a factorisation -- kernels, grids, descriptor
+// contents, stream forks and joins -- is a pure function of the block pattern and the options: nothing in it depends
+// on values or on timing (one launcher thread issues everything in the scheduler's order).  The first pangulu_gstrf on a
+// handle therefore RECORDS every launch and stream operation it issues (a closure each; the descriptor segments they
+// read are kept instead of recycled), and every later pangulu_gstrf on that handle with the same options REPLAYS the
+// list: no scheduler, no descriptor building, no host work per task -- about three thousand closures for the
+// Serena-class matrix instead of 2.8 million tasks.  pangulu_platform_0201001_schedule() is the control call.
+// ---------------------------------------------------------------------------------------------------------------
+struct Recorder
+{
+    int mode = 0; // 1: recording
+    bool valid = false;
+    const void *owner = nullptr;
+    unsigned long long signature = 0;
+    std::vector<std::function<void()>> ops;
+    std::vector<char *> segs; // pinned descriptor segments the recorded launches read (kept until the recording is dropped)
+    size_t descriptor_bytes = 0;
+};
+Recorder REC;
+
+#define PG_LAUNCH(kernel_, grid_, block_, shmem_, stream_, ...)                                            \
+    do                                                                                                       \
+    {                                                                                                        \
+        if (REC.mode == 1)                                                                                   \
+            REC.ops.emplace_back([=]() { hipLaunchKernelGGL(kernel_, grid_, block_, shmem_, stream_, __VA_ARGS__); }); \
+        hipLaunchKernelGGL(kernel_, grid_, block_, shmem_, stream_, __VA_ARGS__);                            \
+    } while (0)
+
+inline void pg_event_record(hipEvent_t e, hipStream_t s)
+{
+    if (REC.mode == 1)
+        REC.ops.emplace_back([e, s]() { HIP_CHECK(hipEventRecord(e, s)); });
+    HIP_CHECK(hipEventRecord(e, s));
+}
+inline void pg_stream_wait(hipStream_t s, hipEvent_t e)
+{
+    if (REC.mode == 1)
+        REC.ops.emplace_back([e, s]() { HIP_CHECK(hipStreamWaitEvent(s, e, 0)); });
+    HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+}
+
 void ensure_ready()
 {
     if (B.ready)
@@ -1961,7 +2004,7 @@ void join_records(hipStream_t s)
 {
     if (!B.rec_dirty.load(std::memory_order_acquire))
         return;
-    HIP_CHECK(hipStreamWaitEvent(s, B.ev_rec, 0));
+    pg_stream_wait(s, B.ev_rec);
     if (s == B.stream)
         B.rec_dirty.store(false, std::memory_order_release);
 }
@@ -1972,7 +2015,7 @@ void join_background(hipStream_t s)
 {
     if (!B.bg_active)
         return;
-    HIP_CHECK(hipStreamWaitEvent(s, B.ev_bg_done, 0));
+    pg_stream_wait(s, B.ev_bg_done);
     if (s == B.stream)
     {
         B.bg_active = false;
@@ -1983,6 +2026,22 @@ void join_background(hipStream_t s)
 Segment acquire_segment()
 {
     Ring &r = B.ring;
+    if (REC.mode == 1)
+    {
+        // recording: the launches will be replayed, their descriptors have to stay -- a segment of its own, kept by the recorder
+        char *h = nullptr, *d = nullptr;
+        HIP_CHECK(hipHostMalloc((void **)&h, r.seg_bytes, hipHostMallocNonCoherent | hipHostMallocMapped));
+        HIP_CHECK(hipHostGetDevicePointer((void **)&d, h, 0));
+        REC.segs.push_back(h);
+        REC.descriptor_bytes += r.seg_bytes;
+        Segment s;
+        s.h = h;
+        s.d = d;
+        s.cap = r.seg_bytes;
+        s.used = 0;
+        s.index = -1;
+        return s;
+    }
     int i = r.cur;
     r.cur = (r.cur + 1) % Ring::NSEG;
     if (r.used[i])
@@ -2002,7 +2061,8 @@ Segment acquire_segment()
 // the segment is complete: kernels launched from now on may read it (in place, see ensure_ready)
 void commit_segment(Segment &s)
 {
-    B.ring.pending.push_back(s.index);
+    if (s.index >= 0)
+        B.ring.pending.push_back(s.index);
 }
 
 hipEvent_t take_event()
@@ -2477,11 +2537,11 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
         if (background)
         {
             // mirrors are current and the operands final from here on (main stream); the kernels run on the background stream
-            HIP_CHECK(hipEventRecord(B.ev_bg_fork, B.stream));
-            HIP_CHECK(hipStreamWaitEvent(ms, B.ev_bg_fork, 0));
+            pg_event_record(B.ev_bg_fork, B.stream);
+            pg_stream_wait(ms, B.ev_bg_fork);
         }
         if (gs && gd && B.opt_two_streams && !background)
-            HIP_CHECK(hipEventRecord(B.ev_fork, B.stream)); // mirrors are current from here on
+            pg_event_record(B.ev_fork, B.stream); // mirrors are current from here on
         if (gs)
         {
             join_records(ms); // operands and destinations of the LDS kernel are sparse records
@@ -2494,10 +2554,10 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
             int colblocks = (nb + SSSSM_WAVES * cpw - 1) / (SSSSM_WAVES * cpw);
             size_t lds = sizeof(val_t) * (size_t)nb * SSSSM_WAVES;
             if (B.opt_getrf_strict)
-                hipLaunchKernelGGL(ssssm_sparse_kernel<true>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, ms,
+                PG_LAUNCH(ssssm_sparse_kernel<true>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, ms,
                                    d_groups_s, d_tasks_s, nb, cpw, B.d_flops + 4);
             else
-                hipLaunchKernelGGL(ssssm_sparse_kernel<false>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, ms,
+                PG_LAUNCH(ssssm_sparse_kernel<false>, dim3((unsigned)(gs * colblocks)), dim3(SSSSM_WAVES * 64), lds, ms,
                                    d_groups_s, d_tasks_s, nb, cpw, B.d_flops + 4);
             B.stats.launches[4]++;
             B.stats.tasks[4] += ns;
@@ -2513,7 +2573,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 // fork: the MFMA kernel starts as soon as the mirrors are ready and runs beside the LDS kernel (both
                 // are bound by memory latency and launch tails, not by a shared resource)
                 ds = B.stream2;
-                HIP_CHECK(hipStreamWaitEvent(ds, B.ev_fork, 0));
+                pg_stream_wait(ds, B.ev_fork);
             }
             {
                 // one workgroup per (group, tile) some update of the group can reach.  Pairs whose whole queue is dense-front
@@ -2562,33 +2622,33 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                     // the longest-running workgroups first: the front launch, then the general one fills in behind it
                     const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_front_unit);
                     if (B.opt_front_stages >= 4)
-                        hipLaunchKernelGGL((ssssm_front_f64_kernel<4, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<4, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
                     else if (B.opt_front_stages == 3)
-                        hipLaunchKernelGGL((ssssm_front_f64_kernel<3, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<3, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
                     else
-                        hipLaunchKernelGGL((ssssm_front_f64_kernel<2, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<2, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
                 }
                 if (nw && B.opt_tiles_stages >= 2)
                 {
                     // round 3: LDS-DMA pipeline, strided piece ownership (pg_hip_front.h)
                     const unsigned unit = (unsigned)(tiles * tiles);
                     if (B.opt_tiles_stages >= 4)
-                        hipLaunchKernelGGL((ssssm_tiles_f64_kernel<4>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                        PG_LAUNCH((ssssm_tiles_f64_kernel<4>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
                     else if (B.opt_tiles_stages == 3)
-                        hipLaunchKernelGGL((ssssm_tiles_f64_kernel<3>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                        PG_LAUNCH((ssssm_tiles_f64_kernel<3>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
                     else
-                        hipLaunchKernelGGL((ssssm_tiles_f64_kernel<2>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                        PG_LAUNCH((ssssm_tiles_f64_kernel<2>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
                 }
                 else if (nw)
-                    hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb, pc,
+                    PG_LAUNCH(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb, pc,
                                        debug_ssssm ? B.d_flops + 8 : nullptr, d_work);
             }
             if (B.opt_count_flops)
-                hipLaunchKernelGGL(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, ds, d_tasks_d, nb, B.d_flops + 5);
+                PG_LAUNCH(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, ds, d_tasks_d, nb, B.d_flops + 5);
             if (side)
             {
-                HIP_CHECK(hipEventRecord(B.ev_join, ds));
-                HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join, 0)); // join before anything later on the main stream
+                pg_event_record(B.ev_join, ds);
+                pg_stream_wait(B.stream, B.ev_join); // join before anything later on the main stream
             }
             B.stats.launches[5]++;
             B.stats.tasks[5] += nd_updates;
@@ -2600,7 +2660,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
     }
     if (background)
     {
-        HIP_CHECK(hipEventRecord(B.ev_bg_done, ms));
+        pg_event_record(B.ev_bg_done, ms);
         B.bg_active = true;
         for (size_t t = 0; t < n; t++)
             B.bg_tiles.insert(block_key_any(list[t]->opdst));
@@ -2617,6 +2677,17 @@ void launch_trsm(int nb, task_t **list, size_t n)
         Segment seg = acquire_segment();
         size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64 + 80 + 4 * sizeof(u32))); // (+80: a remote-diagonal image job per task at worst)
         take = std::min(take, launch_chunk_tasks());
+        {
+            // PANGULU_HIP_TRSM_CHUNK: solves per launch (0 = all).  The leaf levels of a large problem bring tens of thousands of
+            // solves in one call, and the device sits empty while their mirror jobs and descriptors are written
+            static const size_t trsm_chunk = []()
+            {
+                const char *e = getenv("PANGULU_HIP_TRSM_CHUNK");
+                const long v = e ? atol(e) : 0;
+                return v > 0 ? (size_t)v : ~(size_t)0;
+            }();
+            take = std::min(take, trsm_chunk);
+        }
         TrsmTaskD *d_tasks, *d_ftasks;
         TrsmTaskD *tasks = seg.alloc<TrsmTaskD>(take, &d_tasks);
         TrsmTaskD *ftasks = seg.alloc<TrsmTaskD>(take, &d_ftasks); // sparse views of the dense-path tasks (flop counting)
@@ -2754,8 +2825,8 @@ void launch_trsm(int nb, task_t **list, size_t n)
             g_half_image_jobs.clear();
             {
                 LaunchTimer lt(8);
-                hipLaunchKernelGGL(half_image_kernel, dim3((unsigned)nj), dim3(1024), sizeof(u32) * (size_t)(nb + 1), B.stream, d_jobs, nb);
-                hipLaunchKernelGGL(diag_tile_inverse_kernel, dim3((unsigned)(nj * (nb / 16))), dim3(64), 0, B.stream, d_imgs, nb);
+                PG_LAUNCH(half_image_kernel, dim3((unsigned)nj), dim3(1024), sizeof(u32) * (size_t)(nb + 1), B.stream, d_jobs, nb);
+                PG_LAUNCH(diag_tile_inverse_kernel, dim3((unsigned)(nj * (nb / 16))), dim3(64), 0, B.stream, d_imgs, nb);
             }
             B.stats.launches[8]++;
             B.stats.tasks[8] += nj;
@@ -2766,7 +2837,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         commit_segment(seg);
 #if defined(CALCULATE_TYPE_R64)
         if (ndense && nsparse && B.opt_two_streams)
-            HIP_CHECK(hipEventRecord(B.ev_fork, B.stream)); // mirrors and sparse records are current from here on
+            pg_event_record(B.ev_fork, B.stream); // mirrors and sparse records are current from here on
 #endif
         {
             LaunchTimer lt(nt >= ng ? 2 : 3);
@@ -2775,7 +2846,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 join_records(B.stream); // the sparse solves read the diagonal halves' records (behind the fork: the dense solves do not wait)
                 int vblocks = (nb + TRSM_WAVES - 1) / TRSM_WAVES;
                 size_t lds = sizeof(val_t) * (size_t)nb * TRSM_WAVES;
-                hipLaunchKernelGGL(trsm_sparse_kernel, dim3((unsigned)(nsparse * vblocks)), dim3(TRSM_WAVES * 64), lds, B.stream, d_tasks,
+                PG_LAUNCH(trsm_sparse_kernel, dim3((unsigned)(nsparse * vblocks)), dim3(TRSM_WAVES * 64), lds, B.stream, d_tasks,
                                    nb, B.d_flops + 2, B.d_flops + 3);
             }
 #if defined(CALCULATE_TYPE_R64)
@@ -2784,7 +2855,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 // the dense solves run beside the sparse ones (other blocks, same diagonal operands)
                 hipStream_t ds = (B.opt_two_streams && nsparse) ? B.stream2 : B.stream;
                 if (ds != B.stream)
-                    HIP_CHECK(hipStreamWaitEvent(ds, B.ev_fork, 0));
+                    pg_stream_wait(ds, B.ev_fork);
                 static const bool debug_trsm = getenv("PANGULU_HIP_DEBUG_TRSM") != nullptr; // (stamps share the GETRF debug slots)
                 // barrier-free kernel by default (PANGULU_HIP_TRSM_DIRECT=0: the LDS-staged one)
                 static const bool direct = getenv("PANGULU_HIP_TRSM_DIRECT") ? atoi(getenv("PANGULU_HIP_TRSM_DIRECT")) != 0 : true;
@@ -2798,17 +2869,17 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 if (!nw)
                     ;
                 else if (direct && nb == 256)
-                    hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<16>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, d_dwork);
+                    PG_LAUNCH(trsm_dense_direct_f64_kernel<16>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, d_dwork);
                 else if (direct)
-                    hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<8>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, d_dwork);
+                    PG_LAUNCH(trsm_dense_direct_f64_kernel<8>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, d_dwork);
                 else if (nb == 256)
-                    hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, dbg, d_dwork);
+                    PG_LAUNCH(trsm_dense_f64_kernel<16>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, dbg, d_dwork);
                 else
-                    hipLaunchKernelGGL(trsm_dense_f64_kernel<8>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, dbg, d_dwork);
+                    PG_LAUNCH(trsm_dense_f64_kernel<8>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, dbg, d_dwork);
                 if (ds != B.stream)
                 {
-                    HIP_CHECK(hipEventRecord(B.ev_join, ds));
-                    HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join, 0));
+                    pg_event_record(B.ev_join, ds);
+                    pg_stream_wait(B.stream, B.ev_join);
                 }
             }
 #endif
@@ -2818,7 +2889,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         if (ndense)
         {
             if (B.opt_count_flops)
-                hipLaunchKernelGGL(trsm_flop_count_kernel, dim3((unsigned)ndense), dim3(256), 0, B.stream, d_ftasks, nb, B.d_flops + 2,
+                PG_LAUNCH(trsm_flop_count_kernel, dim3((unsigned)ndense), dim3(256), 0, B.stream, d_ftasks, nb, B.d_flops + 2,
                                    B.d_flops + 3);
             B.stats.trsm_dense_tasks += ndense;
         }
@@ -2999,7 +3070,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         HIP_CHECK(hipFuncSetAttribute((const void *)getrf_tiled_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
                         t_allowed = lds_t;
                     }
-                    hipLaunchKernelGGL(getrf_tiled_f64_kernel, dim3((unsigned)take), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, B.d_flops + 1,
+                    PG_LAUNCH(getrf_tiled_f64_kernel, dim3((unsigned)take), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, B.d_flops + 1,
                                        debug_stamps ? B.d_flops + 8 : nullptr);
                 }
                 else if (lookahead_kernel)
@@ -3011,35 +3082,35 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         HIP_CHECK(hipFuncSetAttribute((const void *)getrf_lookahead_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_la));
                         la_allowed = lds_la;
                     }
-                    hipLaunchKernelGGL(getrf_lookahead_f64_kernel, dim3((unsigned)take), dim3(1024), lds_la, ks, d_tasks, nb, B.d_flops + 1,
+                    PG_LAUNCH(getrf_lookahead_f64_kernel, dim3((unsigned)take), dim3(1024), lds_la, ks, d_tasks, nb, B.d_flops + 1,
                                        debug_stamps ? B.d_flops + 8 : nullptr);
                 }
                 else if ((long)take >= narrow_from)
-                    hipLaunchKernelGGL(getrf_blocked_f64_kernel<512>, dim3((unsigned)take), dim3(512), lds, ks, d_tasks, nb,
+                    PG_LAUNCH(getrf_blocked_f64_kernel<512>, dim3((unsigned)take), dim3(512), lds, ks, d_tasks, nb,
                                        B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
                 else
-                    hipLaunchKernelGGL(getrf_blocked_f64_kernel<1024>, dim3((unsigned)take), dim3(1024), lds, ks, d_tasks, nb,
+                    PG_LAUNCH(getrf_blocked_f64_kernel<1024>, dim3((unsigned)take), dim3(1024), lds, ks, d_tasks, nb,
                                        B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
             }
 #endif
             if (!blocked)
             {
                 size_t lds = (sizeof(val_t) * 2 + sizeof(u16) * 2) * (size_t)nb;
-                hipLaunchKernelGGL(getrf_kernel, dim3((unsigned)take), dim3(GETRF_THREADS), lds, ks, d_tasks, nb, B.d_flops + 1);
+                PG_LAUNCH(getrf_kernel, dim3((unsigned)take), dim3(GETRF_THREADS), lds, ks, d_tasks, nb, B.d_flops + 1);
             }
             HIP_CHECK(hipGetLastError());
         }
 #if defined(CALCULATE_TYPE_R64)
         if (!deferred.empty())
-            HIP_CHECK(hipEventRecord(B.ev_rec_fork, ks)); // behind the factorisation
+            pg_event_record(B.ev_rec_fork, ks); // behind the factorisation
 #endif
         if (ks != B.stream)
         {
-            HIP_CHECK(hipEventRecord(B.ev_join3, ks));
+            pg_event_record(B.ev_join3, ks);
             if (defer_join && !B.opt_host_mirror)
                 B.getrf_join_pending = true; // the caller makes the main stream wait once its own kernels are queued
             else
-                HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join3, 0));
+                pg_stream_wait(B.stream, B.ev_join3);
         }
         release_pending_segments(ks); // (the descriptors are read on ks, which the main stream may not have joined yet)
 #if defined(CALCULATE_TYPE_R64)
@@ -3135,8 +3206,8 @@ void process_run(int nb, task_t *tasks, size_t n, std::vector<task_t *> &getrf, 
     bool side = B.opt_two_streams && !getrf.empty() && (!trsm.empty() || !ssssm.empty() || B.bulk_streams_masked);
     if (side)
     {
-        HIP_CHECK(hipEventRecord(B.ev_fork3, B.stream));
-        HIP_CHECK(hipStreamWaitEvent(B.stream3, B.ev_fork3, 0));
+        pg_event_record(B.ev_fork3, B.stream);
+        pg_stream_wait(B.stream3, B.ev_fork3);
         B.getrf_join_pending = false;
         launch_getrf(nb, getrf.data(), getrf.size(), B.stream3, true);
     }
@@ -3145,7 +3216,7 @@ void process_run(int nb, task_t *tasks, size_t n, std::vector<task_t *> &getrf, 
     if (side)
     {
         if (B.getrf_join_pending)
-            HIP_CHECK(hipStreamWaitEvent(B.stream, B.ev_join3, 0));
+            pg_stream_wait(B.stream, B.ev_join3);
         B.getrf_join_pending = false;
     }
     else
@@ -3798,6 +3869,76 @@ extern "C"
         HIP_CHECK(hipFree(d_blks));
         HIP_CHECK(hipFree(d_x));
         HIP_CHECK(hipFree(d_y));
+    }
+
+    // everything a recorded schedule depends on besides the block pattern
+    static unsigned long long options_signature()
+    {
+        const long long v[] = {B.opt_host_mirror, B.opt_dense_permille, B.opt_profile, B.opt_assume_independent, B.opt_getrf_strict, B.opt_count_flops,
+                               B.opt_group_chunk, B.opt_small_launch_tasks, B.opt_trsm_dense_permille, B.opt_two_streams, B.opt_records_stream,
+                               B.opt_background_updates, B.opt_front_stages, B.opt_front_unit, B.opt_tiles_stages, (long long)B.nb_cfg};
+        unsigned long long h = 1469598103934665603ull;
+        for (long long x : v)
+        {
+            h ^= (unsigned long long)x;
+            h *= 1099511628211ull;
+        }
+        return h;
+    }
+
+    static void drop_schedule()
+    {
+        for (char *h : REC.segs)
+            (void)hipHostFree(h);
+        REC = Recorder();
+    }
+
+    // Static schedule of a factorisation (see Recorder).  cmd 1: start recording for `owner` (an opaque token: the handle);
+    // 2: stop, the list is complete; 3: replay the list if it belongs to `owner` and the options are those it was recorded
+    // under (returns 0 when it was replayed, 1 when there is nothing valid to replay); 0: drop it (the owner's blocks are going
+    // away).  Returns the number of recorded operations for cmd 2.  Not recorded (returns -1 on cmd 1): per-launch profiling
+    // and the eager host mirror, whose copies and event pairs are not part of the list.
+    long long pangulu_platform_0201001_schedule(int cmd, const void *owner)
+    {
+        ensure_ready();
+        std::lock_guard<std::mutex> g(B.mutex);
+        HIP_CHECK(hipSetDevice(B.device));
+        switch (cmd)
+        {
+        case 0:
+            if (!owner || owner == REC.owner)
+            {
+                HIP_CHECK(hipDeviceSynchronize());
+                drop_schedule();
+            }
+            return 0;
+        case 1:
+            HIP_CHECK(hipDeviceSynchronize());
+            drop_schedule();
+            if (B.opt_profile || B.opt_host_mirror || !B.opt_assume_independent)
+                return -1;
+            REC.mode = 1;
+            REC.owner = owner;
+            REC.signature = options_signature();
+            return 0;
+        case 2:
+            if (REC.mode != 1)
+                return -1;
+            REC.mode = 0;
+            REC.valid = true;
+            return (long long)REC.ops.size();
+        case 3:
+            if (!REC.valid || REC.owner != owner || REC.signature != options_signature())
+                return 1;
+            for (auto &op : REC.ops)
+                op();
+            HIP_CHECK(hipGetLastError());
+            // (the records stream and the background stream may hold work the main stream has not joined: as after a real run)
+            B.rec_dirty.store(true, std::memory_order_release);
+            return 0;
+        default:
+            return -1;
+        }
     }
 
     void *pangulu_platform_0201001_get_stream(void)

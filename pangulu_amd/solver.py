@@ -175,6 +175,21 @@ def factors_as_scipy(h):
     return L.tocsc(), U.tocsc()
 
 
+def update_values(h, csc_value):
+    """New values on the pattern the handle was initialised with (same order as the csc_rowidx given to pangulu_init; rank 0):
+    the next pangulu_gstrf factorises the new matrix, re-using ordering, symbolic factorisation, records and -- on one rank --
+    the recorded launch schedule."""
+    if csc_value is not None:
+        va = np.ascontiguousarray(csc_value, dtype=h.dtype)
+        h._keep.append(va)
+        ptr = va.ctypes.data_as(ctypes.c_void_p)
+    else:
+        ptr = None
+    rc = h.lib.pangulu_amd_update_values(h.ref, ptr)
+    if rc != 0:
+        raise RuntimeError("pangulu_amd_update_values failed (%d)" % rc)
+
+
 def factor_check(h):
     """||L(U 1) - A 1||_2 / ||A 1||_2 on the factors where they are (the reference's pangulu_numeric_check,
     src/pangulu_numeric.c:1082-1341); collective over the ranks."""
