@@ -3876,7 +3876,7 @@ extern "C"
     {
         const long long v[] = {B.opt_host_mirror, B.opt_dense_permille, B.opt_profile, B.opt_assume_independent, B.opt_getrf_strict, B.opt_count_flops,
                                B.opt_group_chunk, B.opt_small_launch_tasks, B.opt_trsm_dense_permille, B.opt_two_streams, B.opt_records_stream,
-                               B.opt_background_updates, B.opt_front_stages, B.opt_front_unit, B.opt_tiles_stages, (long long)B.nb_cfg};
+                               B.opt_background_updates, B.opt_front_stages, B.opt_front_unit, B.opt_tiles_stages};
         unsigned long long h = 1469598103934665603ull;
         for (long long x : v)
         {
