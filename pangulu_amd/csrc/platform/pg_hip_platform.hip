@@ -32,6 +32,8 @@
 #include <thread>
 #include <mutex>
 #include <functional>
+#include <tuple>
+#include <type_traits>
 #include <unordered_map>
 #include <unordered_set>
 #include <unordered_set>
@@ -1847,18 +1849,48 @@ struct Recorder
     const void *owner = nullptr;
     unsigned long long signature = 0;
     std::vector<std::function<void()>> ops;
-    std::vector<char *> segs; // pinned descriptor segments the recorded launches read (kept until the recording is dropped)
+    // Descriptor segments of the recorded launches.  While recording, the kernels read them in place from pinned host memory
+    // (h, device-visible at d) like every other run; the REPLAYS read a copy in HBM (twin), made once when the recording ends:
+    // a workgroup's first two dependent reads -- its work item, its task descriptors -- then cost an L2/HBM round trip instead
+    // of two trips to host memory.  The closures are built with the twin addresses (rec_xl), the pinned originals are freed.
+    struct Seg
+    {
+        char *h, *d, *twin;
+        size_t cap;
+    };
+    std::vector<Seg> segs;
     size_t descriptor_bytes = 0;
 };
 Recorder REC;
 
-#define PG_LAUNCH(kernel_, grid_, block_, shmem_, stream_, ...)                                            \
-    do                                                                                                       \
-    {                                                                                                        \
-        if (REC.mode == 1)                                                                                   \
-            REC.ops.emplace_back([=]() { hipLaunchKernelGGL(kernel_, grid_, block_, shmem_, stream_, __VA_ARGS__); }); \
-        hipLaunchKernelGGL(kernel_, grid_, block_, shmem_, stream_, __VA_ARGS__);                            \
-    } while (0)
+// a kernel argument as the replay will pass it: pointers into a recorded descriptor segment move to the segment's HBM twin
+template <class T>
+inline T rec_xl(T v)
+{
+    if constexpr (std::is_pointer<T>::value)
+    {
+        const char *p = reinterpret_cast<const char *>(v);
+        for (const Recorder::Seg &sg : REC.segs)
+            if (p >= sg.d && p < sg.d + sg.cap)
+                return reinterpret_cast<T>(const_cast<char *>(sg.twin + (p - sg.d)));
+    }
+    return v;
+}
+
+template <class K, class... A>
+inline void pg_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, A... args)
+{
+    if (REC.mode == 1)
+    {
+        auto targs = std::make_tuple(rec_xl(args)...);
+        REC.ops.emplace_back([=]()
+                             { std::apply([&](auto... a)
+                                          { hipLaunchKernelGGL(kernel, grid, block, (unsigned)shmem, st, a...); },
+                                          targs); });
+    }
+    hipLaunchKernelGGL(kernel, grid, block, (unsigned)shmem, st, args...);
+}
+#define PG_LAUNCH(kernel_, grid_, block_, shmem_, stream_, ...) pg_launch(kernel_, grid_, block_, shmem_, stream_, __VA_ARGS__)
 
 inline void pg_event_record(hipEvent_t e, hipStream_t s)
 {
@@ -2029,10 +2061,11 @@ Segment acquire_segment()
     if (REC.mode == 1)
     {
         // recording: the launches will be replayed, their descriptors have to stay -- a segment of its own, kept by the recorder
-        char *h = nullptr, *d = nullptr;
+        char *h = nullptr, *d = nullptr, *twin = nullptr;
         HIP_CHECK(hipHostMalloc((void **)&h, r.seg_bytes, hipHostMallocNonCoherent | hipHostMallocMapped));
         HIP_CHECK(hipHostGetDevicePointer((void **)&d, h, 0));
-        REC.segs.push_back(h);
+        HIP_CHECK(hipMalloc((void **)&twin, r.seg_bytes));
+        REC.segs.push_back(Recorder::Seg{h, d, twin, r.seg_bytes});
         REC.descriptor_bytes += r.seg_bytes;
         Segment s;
         s.h = h;
@@ -3888,8 +3921,13 @@ extern "C"
 
     static void drop_schedule()
     {
-        for (char *h : REC.segs)
-            (void)hipHostFree(h);
+        for (Recorder::Seg &sg : REC.segs)
+        {
+            if (sg.h)
+                (void)hipHostFree(sg.h);
+            if (sg.twin)
+                (void)hipFree(sg.twin);
+        }
         REC = Recorder();
     }
 
@@ -3925,6 +3963,14 @@ extern "C"
             if (REC.mode != 1)
                 return -1;
             REC.mode = 0;
+            // the recorded run's kernels have read the segments in place; the replays read the HBM twins
+            HIP_CHECK(hipDeviceSynchronize());
+            for (Recorder::Seg &sg : REC.segs)
+            {
+                HIP_CHECK(hipMemcpy(sg.twin, sg.h, sg.cap, hipMemcpyHostToDevice));
+                HIP_CHECK(hipHostFree(sg.h));
+                sg.h = sg.d = nullptr;
+            }
             REC.valid = true;
             return (long long)REC.ops.size();
         case 3:
