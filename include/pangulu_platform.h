@@ -250,11 +250,12 @@ extern "C"
      *     0 keeps them on the main stream.  bench.py's profile pass turns it (and TWO_STREAMS) off so that the hipEvent
      *     pair around a launch brackets that kernel and nothing else. */
 #define PANGULU_HIP_OPT_RECORDS_STREAM 13
-    /*   PANGULU_HIP_OPT_BACKGROUND_UPDATES (default 0: measured no gain; environment PANGULU_HIP_BACKGROUND_UPDATES at start-up): in a
+    /*   PANGULU_HIP_OPT_BACKGROUND_UPDATES (default 1; environment PANGULU_HIP_BACKGROUND_UPDATES at start-up): in a
      *     dependency-free call (ASSUME_INDEPENDENT) that carries diagonal factorisations and updates but no panel solves --
      *     the native scheduler's look-ahead -- the update kernels run on a background stream that the main stream does not
      *     join at the end of the call; a later call that touches one of their destinations waits for them first (the native scheduler
-     *     then wants PANGULU_AMD_PANEL_FIRST=1).  0: GETRFs on a side stream, everything joined at the end of the call. */
+     *     issues the panel-tile updates ahead of such a call, PANGULU_AMD_PANEL_FIRST).  0: GETRFs on a side stream, everything
+     *     joined at the end of the call. */
 #define PANGULU_HIP_OPT_BACKGROUND_UPDATES 14
     /*   PANGULU_HIP_OPT_FRONT_STAGES (default 2; environment PANGULU_HIP_FRONT_STAGES at start-up): (destination, 128 x 128
      *     tile) pairs whose queued updates are all dense-front products -- every 16 x 16 piece of both operands that meets

@@ -137,7 +137,7 @@ struct Sched
     std::vector<task_t> batch, ssssm_batch, combined;
     size_t lookahead_max_getrf = 128; // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
     bool panel_lookahead_on = true;   // PANGULU_AMD_PANEL_LOOKAHEAD (0 disables)
-    bool panel_first_on = false;      // PANGULU_AMD_PANEL_FIRST=1: panel-tile updates ahead of the look-ahead call (for PANGULU_HIP_BACKGROUND_UPDATES)
+    bool panel_first_on = true;       // PANGULU_AMD_PANEL_FIRST (0: panel-tile updates inside the look-ahead call, round 2's order)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
     double gather_max_s = 600e-6, gather_quiet_s = 60e-6, t_gather = 0, t_idle = 0, t_work = 0;

@@ -1788,14 +1788,15 @@ struct Backend
     // panel (the following call) run beside them instead of behind them (fem27(112): the dense solves ran ALONE on the
     // device for 65 of 974 ms).  The destinations of the launches in flight are remembered; the first later call that
     // touches one of them -- as destination or operand -- makes the main stream wait first (join_background).
-    // MEASURED (fem27(112), one box, four steps each): the overlap is there -- dense solves exclusive 65 -> 17 ms, GETRF 13 -> 4,
-    // two or more classes at once 81 -> 245 ms -- and the factorisation does not get faster: 954.7 ms with it, 940.7 ms
-    // without.  The update kernels are throughput-bound and lose what the latency-bound kernels beside them gain.  OFF by default.
+    // MEASURED (fem27(112), one box each): the overlap is there -- dense solves exclusive 65 -> 17 ms, GETRF 13 -> 4, two or more
+    // classes at once 81 -> 245 ms.  With the scheduler in the loop the factorisation did not get faster (954.7 against 940.7 ms:
+    // the extra call per level cost the host-bound run more than the overlap returned); replayed from the static schedule it
+    // does: 873.1 against 887.6 ms, shell(398) 39.05 against 39.72.  On by default since then.
     hipStream_t stream_bg = nullptr;
     hipEvent_t ev_bg_fork = nullptr, ev_bg_done = nullptr;
     bool bg_active = false;
     std::unordered_set<const void *> bg_tiles;
-    long long opt_background_updates = 0; // PANGULU_HIP_BACKGROUND_UPDATES=1 / option 14 (off: measured no gain, see Backend::stream_bg)
+    long long opt_background_updates = 1; // PANGULU_HIP_BACKGROUND_UPDATES=0 / option 14
     // dense-front kernel (pg_hip_front.h) for the (destination, tile) pairs all of whose queued updates have every 16 x 16
     // piece live: LDS stages of its operand pipeline (2, 3 or 4; 0 = off, everything through the general kernel)
     long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15
@@ -1803,6 +1804,7 @@ struct Backend
     // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 2 / 3 / 4 = the
     // LDS-DMA pipeline with that many stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h)
     long long opt_tiles_stages = 2; // PANGULU_HIP_TILES_STAGES / option 16
+    long long opt_tiles_unit = 1;   // PANGULU_HIP_TILES_UNIT: consecutive destinations of the general launch that share an XCD
     unsigned long long front_workgroups = 0, general_workgroups = 0;
     long long opt_records_stream = 1; // PANGULU_HIP_RECORDS_STREAM=0: sparsify on the main stream as before
     int nb_cfg = 0;
@@ -1970,6 +1972,12 @@ void ensure_ready()
         B.opt_tiles_stages = atol(e);
     if (const char *e = getenv("PANGULU_HIP_GROUP_CHUNK"))
         B.opt_group_chunk = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_TILES_UNIT"))
+        B.opt_tiles_unit = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_DENSE_PERMILLE"))
+        B.opt_dense_permille = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_TRSM_DENSE_PERMILLE"))
+        B.opt_trsm_dense_permille = atol(e);
     if (const char *e = getenv("PANGULU_HIP_SMALL_LAUNCH_TASKS"))
         B.opt_small_launch_tasks = atol(e);
     // Descriptors are written once by the host and read once per workgroup: the kernels read them straight from
@@ -2664,7 +2672,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 if (nw && B.opt_tiles_stages >= 2)
                 {
                     // round 3: LDS-DMA pipeline, strided piece ownership (pg_hip_front.h)
-                    const unsigned unit = (unsigned)(tiles * tiles);
+                    const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_tiles_unit);
                     if (B.opt_tiles_stages >= 4)
                         PG_LAUNCH((ssssm_tiles_f64_kernel<4>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
                     else if (B.opt_tiles_stages == 3)
@@ -3909,7 +3917,7 @@ extern "C"
     {
         const long long v[] = {B.opt_host_mirror, B.opt_dense_permille, B.opt_profile, B.opt_assume_independent, B.opt_getrf_strict, B.opt_count_flops,
                                B.opt_group_chunk, B.opt_small_launch_tasks, B.opt_trsm_dense_permille, B.opt_two_streams, B.opt_records_stream,
-                               B.opt_background_updates, B.opt_front_stages, B.opt_front_unit, B.opt_tiles_stages};
+                               B.opt_background_updates, B.opt_front_stages, B.opt_front_unit, B.opt_tiles_stages, B.opt_tiles_unit};
         unsigned long long h = 1469598103934665603ull;
         for (long long x : v)
         {

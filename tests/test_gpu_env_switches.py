@@ -26,7 +26,9 @@ SWITCHES = [
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64"},
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64", "_matrix": "fem27"},  # (long queues cut by launch chunks)
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_SMALL_LAUNCH_TASKS": "0", "_matrix": "fem27"},
-    {"PANGULU_AMD_PANEL_FIRST": "1", "PG_TEST_HIP_OPTIONS": "14=1"},  # look-ahead updates on the background stream
+    {"PANGULU_AMD_PANEL_FIRST": "0", "PG_TEST_HIP_OPTIONS": "14=0"},  # round 2's look-ahead: no background stream
+    {"PANGULU_AMD_PANEL_FIRST": "0"},
+    {"PANGULU_AMD_REPLAY": "0"},
     {"PANGULU_AMD_FORCE_MULTI_LOOP": "1"},     # one rank through the multi-rank scheduler loop (launcher thread + markers)
     {"PG_TEST_HIP_OPTIONS": "15=0,16=0"},      # round 2's MFMA update kernel
     {"PG_TEST_HIP_OPTIONS": "15=3,16=3"},      # LDS-DMA update kernels with three stages
