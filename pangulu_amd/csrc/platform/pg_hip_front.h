@@ -296,9 +296,18 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
         b_frag[ni][1] = (n >> 1) & 7;
     }
 
+    // A work item whose whole queue is dense-front products (the host sets pad_ = 1: every 16 x 16 piece of every operand that
+    // meets the tile is live, no K-split) needs no step list: step e of a window is slab e & 15 of task e >> 4, all pieces live.
+    // Such items share the launch with the partly filled ones (one launch = one tail) and skip the bookkeeping barriers.
+    const bool all_live = G.pad_ != 0;
+    const int slab_shift = nb == 256 ? 4 : 3;
     // step e of the current window as scalars
     auto step_word = [&](int e) -> unsigned
-    { return (unsigned)__builtin_amdgcn_readfirstlane((int)s_step[e]); };
+    {
+        if (all_live)
+            return ((unsigned)(e >> slab_shift) << 20) | ((unsigned)(e & (nslab - 1)) << 16) | 0xFFFFu; // (nslab = 8 or 16)
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)s_step[e]);
+    };
     auto task_ptr = [&](const unsigned long long *tab, unsigned t) -> fr_gptr
     {
         const unsigned long long v = tab[t];
@@ -335,6 +344,20 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
         // ---- the window's step list (no DMA is in flight here: plain barriers) --------------------------------------
         __syncthreads();
         unsigned v = 0;
+        if (all_live)
+        {
+            // (only the operand pointers of the window's tasks)
+            if (tid < TL_WINDOW && win0 + tid < ntask)
+            {
+                const SsssmTaskD &Tm = my_tasks[win0 + tid];
+                s_pa[tid] = (unsigned long long)reinterpret_cast<const double *>(Tm.a.val);
+                s_pb[tid] = (unsigned long long)reinterpret_cast<const double *>(Tm.b.val);
+#if PG_PLANES > 1
+                s_sign[tid] = Tm.sign;
+#endif
+            }
+        }
+        else
         {
             const int t_ = tid >> 4, s_ = tid & 15;
             if (tid < TL_WINDOW * 16 && win0 + t_ < ntask && s_ < nslab)
@@ -368,22 +391,31 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
                 }
             }
         }
-        const unsigned long long bal = __ballot(v != 0);
-        if (lane == 0)
-            s_cnt[wave] = (u32)__builtin_popcountll(bal);
-        __syncthreads();
-        unsigned at = (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), all = 0;
-#pragma unroll
-        for (int w_i = 0; w_i < FR_THREADS / 64; w_i++)
+        int T;
+        if (all_live)
         {
-            const unsigned c_ = s_cnt[w_i];
-            at += w_i < wave ? c_ : 0u;
-            all += c_;
+            __syncthreads();
+            T = min(TL_WINDOW, ntask - win0) * nslab;
         }
-        if (v)
-            s_step[at] = v;
-        __syncthreads();
-        const int T = __builtin_amdgcn_readfirstlane((int)all);
+        else
+        {
+            const unsigned long long bal = __ballot(v != 0);
+            if (lane == 0)
+                s_cnt[wave] = (u32)__builtin_popcountll(bal);
+            __syncthreads();
+            unsigned at = (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), all = 0;
+#pragma unroll
+            for (int w_i = 0; w_i < FR_THREADS / 64; w_i++)
+            {
+                const unsigned c_ = s_cnt[w_i];
+                at += w_i < wave ? c_ : 0u;
+                all += c_;
+            }
+            if (v)
+                s_step[at] = v;
+            __syncthreads();
+            T = __builtin_amdgcn_readfirstlane((int)all);
+        }
         if (T == 0)
             continue;
 

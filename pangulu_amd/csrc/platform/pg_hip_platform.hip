@@ -1799,7 +1799,7 @@ struct Backend
     long long opt_background_updates = 1; // PANGULU_HIP_BACKGROUND_UPDATES=0 / option 14
     // dense-front kernel (pg_hip_front.h) for the (destination, tile) pairs all of whose queued updates have every 16 x 16
     // piece live: LDS stages of its operand pipeline (2, 3 or 4; 0 = off, everything through the general kernel)
-    long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15
+    long long opt_front_stages = 1; // PANGULU_HIP_FRONT_STAGES / option 15: 1 = inside the general launch (no step list), 2..4 = own kernel
     long long opt_front_unit = 1;   // PANGULU_HIP_FRONT_UNIT: consecutive destinations of the front launch that share an XCD
     // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 2 / 3 / 4 = the
     // LDS-DMA pipeline with that many stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h)
@@ -2620,8 +2620,8 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 // one workgroup per (group, tile) some update of the group can reach.  Pairs whose whole queue is dense-front
                 // products (every 16 x 16 piece of every operand live, no K-split) go to the front kernel's list
                 int tiles = nb / DG_TILE;
-                size_t nw = 0, nf = 0;
-                const bool front_on = B.opt_front_stages >= 2 && (nb == 128 || nb == 256);
+                size_t nw = 0, nf = 0, nfm = 0;
+                const bool front_on = B.opt_front_stages >= 1 && (nb == 128 || nb == 256) && (B.opt_front_stages >= 2 || B.opt_tiles_stages >= 2);
                 for (size_t gi = 0; gi < gd; gi++)
                 {
                     const SsssmGroupD &Gd = groups_d[gi];
@@ -2631,11 +2631,18 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                     for (int tl = 0; tl < tiles * tiles; tl++)
                         if ((Gd.live_tiles >> tl) & 1u)
                         {
-                            const SsssmWorkD item{Gd.cdense, Gd.task_begin, Gd.task_end, Gd.atomic, Gd.slab_mask, (u32)tl, 0u};
-                            if ((all_full >> tl) & 1u)
-                                work_f[nf++] = item;
-                            else
+                            SsssmWorkD item{Gd.cdense, Gd.task_begin, Gd.task_end, Gd.atomic, Gd.slab_mask, (u32)tl, 0u};
+                            if (!((all_full >> tl) & 1u))
                                 work[nw++] = item;
+                            else if (B.opt_front_stages == 1 && B.opt_tiles_stages >= 2)
+                            {
+                                // same launch as the partly filled tiles: one launch, one tail; the kernel skips the step list
+                                item.pad_ = 1u;
+                                work[nw++] = item;
+                                nfm++;
+                            }
+                            else
+                                work_f[nf++] = item;
                         }
                 }
                 LaunchTimer lt(5, ds);
@@ -2654,8 +2661,8 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                     lt.tag[1] = nd;
                     lt.tag[2] = steps;
                 }
-                B.front_workgroups += nf;
-                B.general_workgroups += nw;
+                B.front_workgroups += nf + nfm;
+                B.general_workgroups += nw - nfm;
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 unsigned long long *pc = B.opt_count_flops ? B.d_flops + 6 : nullptr;
                 if (nf)

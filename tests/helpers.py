@@ -45,7 +45,7 @@ def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_fa
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_SSSSM_GROUP_CHUNK, 8)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_TRSM_DENSE_PERMILLE, 10)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_SMALL_LAUNCH_TASKS, 2048)
-        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_FRONT_STAGES, 2)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_FRONT_STAGES, 1)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_TILES_STAGES, 2)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_BACKGROUND_UPDATES, 1)
         for opt, val in (hip_options or {}).items():

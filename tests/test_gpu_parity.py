@@ -71,12 +71,12 @@ def test_dense_blocks_take_the_mfma_path():
     assert np.abs(LU - A).max() <= 1e-11 * np.abs(A).max()
 
 
-@pytest.mark.parametrize("stages", [0, 2, 3, 4])
+@pytest.mark.parametrize("stages", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("n,nb", [(2560, 256), (1536, 128)])
 def test_dense_front_kernel(n, nb, stages):
     """A dense matrix: every tile of every update is a dense-front product and runs on the LDS-DMA kernel (pg_hip_front.h)
-    with 2, 3 or 4 stages -- or, with the switch at 0, on the general MFMA kernel; queues of up to five updates per
-    destination.  Factors against the oracle and against L U = A."""
+    with 2, 3 or 4 stages, inside the general launch on its no-step-list path (1, the default), or, with the switch at 0, like
+    any partly filled tile; queues of up to nine updates per destination.  Factors against the oracle and against L U = A."""
     import scipy.sparse as sp
 
     from pangulu_amd import _lib

@@ -14,8 +14,11 @@ import sys,json
 l=json.loads(sys.stdin.read())
 print('$name: ms_per_step %.2f (min %.2f) residual %.2e replayed %s' % (l['ms_per_step'], min(l['step_ms']), l['residual'], l.get('static_schedule_replayed')))"
 }
+( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "dense_front or general_update" ) > gpurun_out/r03k_pytest.log 2>&1; tail -4 gpurun_out/r03k_pytest.log
 F="--steps 4 --warmup 2"
 run fem_default $F
+run fem_front2 PANGULU_HIP_FRONT_STAGES=2 $F
+run fem_front0 PANGULU_HIP_FRONT_STAGES=0 $F
 run fem_tiles_unit8 PANGULU_HIP_TILES_UNIT=8 PANGULU_HIP_FRONT_UNIT=8 $F
 run fem_tiles_unit4 PANGULU_HIP_TILES_UNIT=4 PANGULU_HIP_FRONT_UNIT=4 $F
 run fem_dense2 PANGULU_HIP_DENSE_PERMILLE=2 $F
@@ -29,6 +32,7 @@ run fem_trsm5 PANGULU_HIP_TRSM_DENSE_PERMILLE=5 $F
 run fem_trsm30 PANGULU_HIP_TRSM_DENSE_PERMILLE=30 $F
 S="--workload shell --steps 10 --warmup 2"
 run shell_default $S
+run shell_front2 PANGULU_HIP_FRONT_STAGES=2 $S
 run shell_tiles_unit8 PANGULU_HIP_TILES_UNIT=8 PANGULU_HIP_FRONT_UNIT=8 $S
 run shell_dense2 PANGULU_HIP_DENSE_PERMILLE=2 $S
 run shell_dense10 PANGULU_HIP_DENSE_PERMILLE=10 $S
