@@ -579,7 +579,7 @@ def gpu_worker_main(args):
             # from a committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass (tools/profile_recipe.sh; FETCH_SIZE doubled as
             # MI355X_MICROARCH.md prescribes for gfx950) -- but ONLY if that pass profiled this build's kernels on this
             # workload: the file records the workload and a hash of the kernel sources, anything else leaves `traffic` null
-            rocprof_name = {"ssssm_dense_mfma": "ssssm_dense_f64_kernel", "getrf": "getrf_tiled_f64_kernel",
+            rocprof_name = {"ssssm_dense_mfma": "ssssm_tiles_f64_kernel<2>", "getrf": "getrf_tiled_f64_kernel",
                             "tstrf": "trsm_dense_direct_f64_kernel<16>", "gessm": "trsm_dense_direct_f64_kernel<16>",
                             "ssssm_sparse": "ssssm_sparse_kernel<false>"}.get(dom)
             tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")

@@ -257,11 +257,12 @@ extern "C"
      *     issues the panel-tile updates ahead of such a call, PANGULU_AMD_PANEL_FIRST).  0: GETRFs on a side stream, everything
      *     joined at the end of the call. */
 #define PANGULU_HIP_OPT_BACKGROUND_UPDATES 14
-    /*   PANGULU_HIP_OPT_FRONT_STAGES (default 1; environment PANGULU_HIP_FRONT_STAGES at start-up): (destination, 128 x 128
+    /*   PANGULU_HIP_OPT_FRONT_STAGES (default 2; environment PANGULU_HIP_FRONT_STAGES at start-up): (destination, 128 x 128
      *     tile) pairs whose queued updates are all dense-front products -- every 16 x 16 piece of both operands that meets
      *     the tile holds pattern entries -- need no occupancy bookkeeping.  1: they run inside the general launch on its
      *     no-step-list path (one launch, one tail; needs TILES_STAGES >= 2); 2, 3 or 4: on the dense-front kernel of their
-     *     own (operand slabs by LDS-DMA, that many LDS stages); 0: treated like any other tile. */
+     *     own (operand slabs by LDS-DMA, that many LDS stages) when a launch has at least PANGULU_HIP_FRONT_MIN_WGS (2048) of
+     *     them, inside the general launch otherwise; 0: treated like any other tile. */
 #define PANGULU_HIP_OPT_FRONT_STAGES 15
     /*   PANGULU_HIP_OPT_TILES_STAGES (default 2; environment PANGULU_HIP_TILES_STAGES at start-up): the general MFMA update
      *     kernel -- 2, 3 or 4: operand slabs by LDS-DMA with that many LDS stages, strided piece ownership of the wavefronts

@@ -338,6 +338,20 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
         }
     };
 
+    // register r of lane l of piece (ni, mi) is C(M0 + (2 mi + wr) 16 + (l & 15), N0 + (wc + 4 ni) 16 + 4 r + (l >> 4))
+    double __attribute__((address_space(1))) *C = (double __attribute__((address_space(1))) *)reinterpret_cast<double *>(G.cdense);
+    const unsigned c_voff = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
+#define TL_C(ni_, mi_, r_)                                                                           \
+    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((const char __attribute__((address_space(1))) *)C +                    \
+                                                                  ((size_t)(N0 + (wc + 4 * (ni_)) * 16 + 4 * (r_)) * nb + M0 + wr * 16) * 8) + \
+                                                   dg_lane_offset(c_voff) + (mi_) * 256))
+    // A workgroup that owns its destination (no atomics) and whose queue fits one window knows, once the step list is there,
+    // which pieces of C it is going to touch: their values go into the accumulators before the first slab is consumed (the
+    // matrix cores subtract: acc = C - sum A B) and the epilogue is stores only -- a read-modify-write at the end is a dependent
+    // memory round trip that nothing hides.
+    unsigned pre = 0;
+    const bool may_preload = !G.atomic && ntask <= TL_WINDOW;
+
     int stage_head = 0; // stage the next consumed step sits in (stages are used round-robin across windows)
     for (int win0 = 0; win0 < ntask; win0 += TL_WINDOW)
     {
@@ -419,6 +433,40 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
         if (T == 0)
             continue;
 
+        // (the destination first: its loads are then older than every DMA, and the counted waits below cover them)
+        if (may_preload)
+        {
+            unsigned m = 0;
+            if (all_live)
+                m = 0xFFu;
+            else
+            {
+                for (int e = lane; e < T; e += 64)
+                {
+                    const unsigned w = s_step[e];
+                    const unsigned ab = w & 0xFFu, bb = (w >> 8) & 0xFFu;
+                    const unsigned a4 = ((ab >> wr) & 1u) | (((ab >> (2 + wr)) & 1u) << 1) | (((ab >> (4 + wr)) & 1u) << 2) | (((ab >> (6 + wr)) & 1u) << 3);
+                    if ((bb >> wc) & 1u)
+                        m |= a4;
+                    if ((bb >> (wc + 4)) & 1u)
+                        m |= a4 << 4;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+                    m |= (unsigned)__shfl_xor((int)m, off, 64);
+            }
+            pre = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++)
+                    if ((pre >> (4 * ni + mi)) & 1u)
+                    {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            acc[ni][mi][r] = TL_C(ni, mi, r);
+                    }
+        }
         // ---- the pipeline over the window's T live steps -------------------------------------------------------------
 #pragma unroll
         for (int p = 0; p < STAGES - 1; p++)
@@ -492,13 +540,22 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
     if (product_counter && lane == 0 && nprod)
         atomicAdd(product_counter, (unsigned long long)nprod);
 
-    // C += acc on the touched pieces: register r of lane l of piece (ni, mi) is C(M0 + (2 mi + wr) 16 + (l & 15), N0 + (wc + 4 ni) 16 + 4 r + (l >> 4))
-    double __attribute__((address_space(1))) *C = (double __attribute__((address_space(1))) *)reinterpret_cast<double *>(G.cdense);
-    const unsigned c_voff = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
-#define TL_C(ni_, mi_, r_)                                                                           \
-    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((const char __attribute__((address_space(1))) *)C +                    \
-                                                                  ((size_t)(N0 + (wc + 4 * (ni_)) * 16 + 4 * (r_)) * nb + M0 + wr * 16) * 8) + \
-                                                   dg_lane_offset(c_voff) + (mi_) * 256))
+    if (pre)
+    {
+        // preloaded: the accumulators hold C - sum A B; stores only
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                if ((pre >> (4 * ni + mi)) & 1u)
+                {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        TL_C(ni, mi, r) = acc[ni][mi][r];
+                }
+        touched = 0; // (a subset of pre: everything has been written)
+    }
+    // C += acc on the touched pieces
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
     {

@@ -1799,7 +1799,8 @@ struct Backend
     long long opt_background_updates = 1; // PANGULU_HIP_BACKGROUND_UPDATES=0 / option 14
     // dense-front kernel (pg_hip_front.h) for the (destination, tile) pairs all of whose queued updates have every 16 x 16
     // piece live: LDS stages of its operand pipeline (2, 3 or 4; 0 = off, everything through the general kernel)
-    long long opt_front_stages = 1; // PANGULU_HIP_FRONT_STAGES / option 15: 1 = inside the general launch (no step list), 2..4 = own kernel
+    long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15: 1 = inside the general launch (no step list), 2..4 = own kernel
+    long long opt_front_min_wgs = 2048; // PANGULU_HIP_FRONT_MIN_WGS: ... from this many qualifying workgroups in a launch on
     long long opt_front_unit = 1;   // PANGULU_HIP_FRONT_UNIT: consecutive destinations of the front launch that share an XCD
     // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 2 / 3 / 4 = the
     // LDS-DMA pipeline with that many stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h)
@@ -1810,14 +1811,14 @@ struct Backend
     int nb_cfg = 0;
     // options
     long long opt_host_mirror = 1;
-    long long opt_dense_permille = 5; // (10 until the end of round 2; the leaner MFMA kernel pays from 0.5 % fill: 43.0-44.4 vs 43.9-44.9 ms)
+    long long opt_dense_permille = 2; // (10 until the end of round 2, 5 until round 3's sweep on replayed runs: fem27(112) 887.8 / 892.1 / 906.8 ms at 2 / 5 / 10, shell(398) 37.9 / 38.5 / 39.2)
     long long opt_profile = 0;
     long long opt_assume_independent = 0;
     long long opt_getrf_strict = 0;
     long long opt_count_flops = 1;
     long long opt_group_chunk = 8;
     long long opt_small_launch_tasks = 2048;
-    long long opt_trsm_dense_permille = 10;
+    long long opt_trsm_dense_permille = 5; // (round 3 sweep: shell(398) 38.2 / 38.5 / 39.4 ms at 5 / 10 / 30, fem27(112) indifferent)
     long long opt_two_streams = 1;
     double mfma_flops_executed = 0;
     // resources
@@ -1968,6 +1969,8 @@ void ensure_ready()
         B.opt_front_stages = atol(e);
     if (const char *e = getenv("PANGULU_HIP_FRONT_UNIT"))
         B.opt_front_unit = atol(e);
+    if (const char *e = getenv("PANGULU_HIP_FRONT_MIN_WGS"))
+        B.opt_front_min_wgs = atol(e);
     if (const char *e = getenv("PANGULU_HIP_TILES_STAGES"))
         B.opt_tiles_stages = atol(e);
     if (const char *e = getenv("PANGULU_HIP_GROUP_CHUNK"))
@@ -2622,27 +2625,41 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 int tiles = nb / DG_TILE;
                 size_t nw = 0, nf = 0, nfm = 0;
                 const bool front_on = B.opt_front_stages >= 1 && (nb == 128 || nb == 256) && (B.opt_front_stages >= 2 || B.opt_tiles_stages >= 2);
+                // (first pass: which pairs qualify, and how many -- a front launch of its own pays from a few thousand workgroups
+                //  on: fem27(112) 883.8 ms with it against 892.1 with the pairs inside the general launch, shell(398) 39.2 against 38.5)
+                static std::vector<unsigned char> full_g;
+                full_g.assign(gd, 0);
+                size_t nfull = 0;
+                for (size_t gi = 0; gi < gd && front_on; gi++)
+                {
+                    const SsssmGroupD &Gd = groups_d[gi];
+                    unsigned all_full = Gd.slab_mask ? 0u : 0xFu;
+                    for (u32 t = Gd.task_begin; t < Gd.task_end && all_full; t++)
+                        all_full &= full_t[t];
+                    all_full &= Gd.live_tiles;
+                    full_g[gi] = (unsigned char)all_full;
+                    nfull += (size_t)__builtin_popcount(all_full);
+                }
+                const bool own_launch = B.opt_front_stages >= 2 && (B.opt_tiles_stages < 2 || nfull >= (size_t)B.opt_front_min_wgs);
                 for (size_t gi = 0; gi < gd; gi++)
                 {
                     const SsssmGroupD &Gd = groups_d[gi];
-                    unsigned all_full = (front_on && !Gd.slab_mask) ? 0xFu : 0u;
-                    for (u32 t = Gd.task_begin; t < Gd.task_end && all_full; t++)
-                        all_full &= full_t[t];
+                    const unsigned all_full = full_g[gi];
                     for (int tl = 0; tl < tiles * tiles; tl++)
                         if ((Gd.live_tiles >> tl) & 1u)
                         {
                             SsssmWorkD item{Gd.cdense, Gd.task_begin, Gd.task_end, Gd.atomic, Gd.slab_mask, (u32)tl, 0u};
                             if (!((all_full >> tl) & 1u))
                                 work[nw++] = item;
-                            else if (B.opt_front_stages == 1 && B.opt_tiles_stages >= 2)
+                            else if (own_launch)
+                                work_f[nf++] = item;
+                            else
                             {
                                 // same launch as the partly filled tiles: one launch, one tail; the kernel skips the step list
                                 item.pad_ = 1u;
                                 work[nw++] = item;
                                 nfm++;
                             }
-                            else
-                                work_f[nf++] = item;
                         }
                 }
                 LaunchTimer lt(5, ds);
@@ -3924,7 +3941,7 @@ extern "C"
     {
         const long long v[] = {B.opt_host_mirror, B.opt_dense_permille, B.opt_profile, B.opt_assume_independent, B.opt_getrf_strict, B.opt_count_flops,
                                B.opt_group_chunk, B.opt_small_launch_tasks, B.opt_trsm_dense_permille, B.opt_two_streams, B.opt_records_stream,
-                               B.opt_background_updates, B.opt_front_stages, B.opt_front_unit, B.opt_tiles_stages, B.opt_tiles_unit};
+                               B.opt_background_updates, B.opt_front_stages, B.opt_front_unit, B.opt_tiles_stages, B.opt_tiles_unit, B.opt_front_min_wgs};
         unsigned long long h = 1469598103934665603ull;
         for (long long x : v)
         {

@@ -40,12 +40,12 @@ def factorize(mat, nb, platform, vtype="r64", ordering=None, solve=True, keep_fa
     if platform == "hip":
         pa.hip_stats(lib, reset=True)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_GETRF_STRICT_ORDER, 0)
-        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_DENSE_THRESHOLD_PERMILLE, 5)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_DENSE_THRESHOLD_PERMILLE, 2)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 1)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_SSSSM_GROUP_CHUNK, 8)
-        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_TRSM_DENSE_PERMILLE, 10)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_TRSM_DENSE_PERMILLE, 5)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_SMALL_LAUNCH_TASKS, 2048)
-        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_FRONT_STAGES, 1)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_FRONT_STAGES, 2)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_TILES_STAGES, 2)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_BACKGROUND_UPDATES, 1)
         for opt, val in (hip_options or {}).items():

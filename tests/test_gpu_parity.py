@@ -86,6 +86,8 @@ def test_dense_front_kernel(n, nb, stages):
     A += np.diag(np.abs(A).sum(axis=1) + 1.0)
     S = sp.csc_matrix(A)
     mat = (n, S.indptr.astype(np.uint64), S.indices.astype(np.uint32), S.data.copy(), None)
+    # (the dense-front kernel gets a launch of its own from PANGULU_HIP_FRONT_MIN_WGS qualifying workgroups on; the
+    #  conftest sets it to 64 for the GPU suite so that the test matrices reach both paths)
     gpu = factorize(mat, nb, "hip", ordering="identity", hip_options={_lib.HIP_OPT_FRONT_STAGES: stages})
     ref = factorize(mat, nb, oracle_library("r64"), ordering="identity")
     st = gpu["hip_stats"]["ssssm_dense_mfma"]

@@ -9,7 +9,7 @@ import csv
 import sys
 from collections import defaultdict
 
-ABBR = [("block_trsv", "solve"), ("ssssm_dense", "SD"), ("ssssm_sparse", "SS"), ("trsm_dense", "TD"), ("trsm_sparse", "TS"), ("getrf", "GF"),
+ABBR = [("block_trsv", "solve"), ("block_spmv", "solve"), ("ssssm_dense", "SD"), ("ssssm_tiles", "SD"), ("ssssm_front", "SD"), ("ssssm_sparse", "SS"), ("trsm_dense", "TD"), ("trsm_sparse", "TS"), ("getrf", "GF"),
         ("densify", "dn"), ("sparsify", "sp"), ("half_image", "hi"), ("diag_tile", "iv"), ("flop_count", "fc")]
 
 

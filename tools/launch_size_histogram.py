@@ -22,7 +22,7 @@ segs=[x for x in segs if len(x)>200]
 print('factorisations found',len(segs),[len(x) for x in segs])
 seg=segs[-2] if len(segs)>1 else segs[-1]
 print('span ms',(int(seg[-1]['End_Timestamp'])-int(seg[0]['Start_Timestamp']))/1e6)
-for key in ('ssssm_dense','trsm_dense_direct','getrf_tiled','densify','sparsify'):
+for key in ('ssssm_tiles','ssssm_front','ssssm_dense','trsm_dense_direct','getrf_tiled','densify','sparsify'):
     b=collections.defaultdict(lambda:[0,0.0])
     for r in seg:
         n=short(r['Kernel_Name'])

@@ -69,7 +69,14 @@ def main():
 
         summary["kernel_source_hash"] = bench.kernel_source_hash()
         summary["profile"] = os.environ.get("PROFILE_NAME", os.path.basename(out_json))
-        json.dump(summary, open(out_json, "w"), indent=1)
+        # profiles/hbm_traffic.json is keyed by workload (bench.workload_key): WORKLOAD_KEY set = merge into that file's entry
+        key = os.environ.get("WORKLOAD_KEY")
+        if key:
+            allw = json.load(open(out_json)) if os.path.exists(out_json) else {}
+            allw[key] = summary
+            json.dump(allw, open(out_json, "w"), indent=1)
+        else:
+            json.dump(summary, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
