@@ -476,6 +476,10 @@ def gpu_worker_main(args):
         n, cp, ri, va, coords = mat
     else:
         mat, n, cp, ri, va, coords, workload = None, 0, None, None, None, None, ""
+    # structural flop counting of MFMA-path updates costs an extra pass per task: off in the timed steps (F comes from
+    # the symbolic pattern), on in the profile pass below.  Set BEFORE pangulu_init: on one rank the launch schedule is recorded
+    # there, under the options in force, and a factorisation under other options runs the scheduler again.
+    lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 0)
     t0 = time.time()
     h = pa.pangulu_init(n, len(va) if va is not None else 0, cp, ri, va, nb=args.nb, ordering=args.ordering,
                         coords=coords if args.ordering == "nd" else None, nthread=nthreads)
@@ -496,10 +500,8 @@ def gpu_worker_main(args):
         lib.pangulu_amd_comm_barrier()
         return time.perf_counter() - t
 
-    # structural flop counting of MFMA-path updates costs an extra pass per task: off in the timed steps (F comes from
-    # the symbolic pattern), on in the profile pass below.  tests/test_gpu_env_switches.py runs the parity cases in this
-    # configuration too, and the line's residual / factor_check come from the last TIMED step.
-    lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 0)
+    # (COUNT_FLOPS is off since before pangulu_init; tests/test_gpu_env_switches.py runs the parity cases in this
+    # configuration too, and the line's residual / factor_check come from the last TIMED step)
     for _ in range(args.warmup):
         one_step()
         lib.pangulu_amd_reset_numeric(h.ref)
@@ -650,7 +652,7 @@ def gpu_worker_main(args):
             "hbm_used_GB": round(used.value / 1e9, 2), "owned_records_GB": round(info["owned_bytes"] / 1e9, 2),
             "host_sched_s_last_step": round(info["time_numeric_host_sched"], 4),
             # one rank: the first pangulu_gstrf of the handle (a warm-up step) recorded its launches, the timed steps replay the list
-            "static_schedule_replayed": bool(info["replayed"]),
+            "static_schedule_replayed": bool(info["replayed"]), "schedule_record_s": round(info["time_schedule_record"], 2),
             "batches_per_step": int(info["batches"]),
             "roofline": roofline,
             "model": model,

@@ -95,6 +95,7 @@ extern "C"
         unsigned long long sampled_tasks;
         double time_numeric_platform;         /* seconds inside the platform's hybrid_batched calls (compute thread or launcher) */
         unsigned long long replayed;          /* 1: the last pangulu_gstrf replayed the handle's recorded launch schedule        */
+        double time_schedule_record;          /* seconds pangulu_init spent recording the launch schedule (dry run of the scheduler) */
         /* Structure-only model of the WHOLE factorisation for this handle's rank count, evaluated by every rank at
          * pangulu_init from the replicated symbolic pattern (HBM 8 TB/s, 78.6 TFLOP/s, 153 GB/s per xGMI link unless
          * PANGULU_AMD_MODEL_HBM_GBS / _FP_TFLOPS / _LINK_GBS say otherwise):

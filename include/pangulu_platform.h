@@ -261,7 +261,7 @@ extern "C"
      *     tile) pairs whose queued updates are all dense-front products -- every 16 x 16 piece of both operands that meets
      *     the tile holds pattern entries -- need no occupancy bookkeeping.  1: they run inside the general launch on its
      *     no-step-list path (one launch, one tail; needs TILES_STAGES >= 2); 2, 3 or 4: on the dense-front kernel of their
-     *     own (operand slabs by LDS-DMA, that many LDS stages) when a launch has at least PANGULU_HIP_FRONT_MIN_WGS (2048) of
+     *     own (operand slabs by LDS-DMA, that many LDS stages) when a launch has at least PANGULU_HIP_FRONT_MIN_WGS (8192) of
      *     them, inside the general launch otherwise; 0: treated like any other tile. */
 #define PANGULU_HIP_OPT_FRONT_STAGES 15
     /*   PANGULU_HIP_OPT_TILES_STAGES (default 2; environment PANGULU_HIP_TILES_STAGES at start-up): the general MFMA update

@@ -79,6 +79,7 @@ class Info(ctypes.Structure):
         ("sampled_tasks", ctypes.c_ulonglong),
         ("time_numeric_platform", ctypes.c_double),
         ("replayed", ctypes.c_ulonglong),
+        ("time_schedule_record", ctypes.c_double),
         ("model_ranks_tstar_max", ctypes.c_double),
         ("model_ranks_tstar_sum", ctypes.c_double),
         ("model_ranks_tstar_hbm", ctypes.c_double),

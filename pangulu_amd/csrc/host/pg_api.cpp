@@ -546,6 +546,7 @@ extern "C"
         S->sym.ptr = std::vector<u64>();
         comm->barrier();
         S->info.time_preprocess = wall_seconds() - t0;
+        record_schedule(*S); // (one rank on the device: the first pangulu_gstrf will already replay)
         *pangulu_handle = (void *)S;
     }
 

@@ -377,6 +377,7 @@ void preprocess(Solver &S, const CscMatrix &Aperm);       // records, counters, 
 void scatter_values(Solver &S, const CscMatrix &Aperm);   // values of the permuted matrix into the owned records (host side)
 void reload_values(Solver &S, const CscMatrix &Aperm);    // new values on the same pattern: refill + upload + re-arm the counters
 void numeric_factorize(Solver &S);                        // the hot path
+void record_schedule(Solver &S);                          // pangulu_init, one rank: dry run of the scheduler, the back-end records the launch list
 void download_factors(Solver &S);                         // device -> host mirror of owned values
 void triangular_solve(Solver &S, val_t *rhs_permuted);    // forward + backward block sweeps (host kernels)
 double factor_check(Solver &S);                           // ||L(U 1) - A 1|| / ||A 1|| on the factors where they are (pg_check.cpp; collective)

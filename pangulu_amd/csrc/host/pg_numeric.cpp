@@ -135,7 +135,7 @@ struct Sched
     Comm *comm;
     std::vector<char> sent_flag;
     std::vector<task_t> batch, ssssm_batch, combined;
-    size_t lookahead_max_getrf = 128; // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables)
+    size_t lookahead_max_getrf = 32;  // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables; 128 until round 3's sweep on replayed runs: fem27(112) 836.1 / 845.0 / 902.9 ms at 32 / 128 / 1024)
     bool panel_lookahead_on = true;   // PANGULU_AMD_PANEL_LOOKAHEAD (0 disables)
     bool panel_first_on = true;       // PANGULU_AMD_PANEL_FIRST (0: panel-tile updates inside the look-ahead call, round 2's order)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
@@ -186,7 +186,8 @@ struct Sched
     bool forced_multi = false; // PANGULU_AMD_FORCE_MULTI_LOOP=1: one rank through the multi-rank loop (measurement aid)
     bool lq_stop = false, lq_busy = false;
 
-    explicit Sched(Solver &s) : S(s), P(s.pat), plat(active_platform()), comm(world()), sent_flag((size_t)s.nproc, 0), multi(s.nproc > 1)
+    bool dry_run = false; // the scheduler's dry run at pangulu_init: platform calls record, nothing is launched (no launcher thread)
+    explicit Sched(Solver &s, bool dry = false) : S(s), P(s.pat), plat(active_platform()), comm(world()), sent_flag((size_t)s.nproc, 0), multi(s.nproc > 1), dry_run(dry)
     {
         if (const char *e = getenv("PANGULU_AMD_FORCE_MULTI_LOOP"))
             forced_multi = atoi(e) != 0 && s.nproc == 1;
@@ -207,7 +208,7 @@ struct Sched
             stall_limit_s = atof(e);
         use_markers = multi && !plat.host_memory && plat.marker_record && plat.marker_done && plat.marker_wait && !getenv("PANGULU_AMD_SYNC_EVERY_BATCH");
         const char *al = getenv("PANGULU_AMD_ASYNC_LAUNCH");
-        async_launch = !plat.host_memory && !(al && atoi(al) == 0) && (!multi || use_markers);
+        async_launch = !plat.host_memory && !(al && atoi(al) == 0) && (!multi || use_markers) && !dry_run;
         if (async_launch)
             launcher = std::thread([this]()
                                    { launcher_loop(); });
@@ -1063,6 +1064,65 @@ struct Sched
 
 } // namespace
 
+static bool schedule_possible(const Solver &S, Platform &plat)
+{
+    static const bool replay_on = !(getenv("PANGULU_AMD_REPLAY") && atoi(getenv("PANGULU_AMD_REPLAY")) == 0);
+    return replay_on && S.nproc == 1 && !plat.host_memory && plat.schedule && g_task_sample_stride <= 1 && !S.eager_host_mirror && !S.analysis_only &&
+           !getenv("PANGULU_AMD_FORCE_MULTI_LOOP");
+}
+
+// pangulu_init, one rank on the device: run the scheduler once with the back-end in record-only mode -- every batch goes
+// through the same host code as in a factorisation (mirror bookkeeping, descriptors, work lists), nothing is launched -- so that
+// already the FIRST pangulu_gstrf of the handle replays a launch list instead of scheduling 2.8 million tasks beside the device.
+// PANGULU_AMD_RECORD_AT_INIT=0 leaves the recording to the first pangulu_gstrf (which then runs the scheduler).
+void record_schedule(Solver &S)
+{
+    Platform &plat = active_platform();
+    static const bool at_init = !(getenv("PANGULU_AMD_RECORD_AT_INIT") && atoi(getenv("PANGULU_AMD_RECORD_AT_INIT")) == 0);
+    if (!at_init || !schedule_possible(S, plat))
+        return;
+    const double t0 = wall_seconds();
+    plat.set_option(PANGULU_HIP_OPT_HOST_MIRROR, 0);
+    plat.set_option(PANGULU_HIP_OPT_ASSUME_INDEPENDENT, 1);
+    plat.set_option(PANGULU_HIP_OPT_RESET_BLOCK_STATE, 0);
+    if (plat.schedule(4, &S) != 0)
+        return;
+    {
+        Sched sch(S, true);
+        S.heap.clear();
+        S.pending_total = 0;
+        S.pending_dirty.clear();
+        {
+            std::lock_guard<std::mutex> g(S.info_mutex);
+            for (u32 level = 0; level < S.nbk; level++)
+                if (S.remain_diag[level] == 1)
+                {
+                    S.remain_diag[level]--;
+                    sch.push_panel(level, level, level, PANGULU_TASK_GETRF, S.diag_lower[level], nullptr);
+                }
+        }
+        sch.compute_loop();
+        S.info.batches = sch.batches;
+    }
+    S.schedule_recorded = plat.schedule(2, &S) > 0;
+    // re-arm: nothing ran on the device, the block values are untouched
+    S.remain = S.remain0;
+    S.remain_diag = S.remain_diag0;
+    S.rank_remain_task = S.rank_remain_task0;
+    for (auto &sl : S.storage.owned)
+        sl.data_status = PANGULU_DATA_PREPARING;
+    for (auto &q : S.pending)
+        q.clear();
+    S.pending_dirty.clear();
+    S.pending_total = 0;
+    S.heap.clear();
+    plat.set_option(PANGULU_HIP_OPT_RESET_BLOCK_STATE, 0);
+    S.info.time_schedule_record = wall_seconds() - t0;
+    if (getenv("PANGULU_AMD_TRACE"))
+        fprintf(stderr, "[pangulu_amd trace] init: launch schedule recorded by a dry run of the scheduler in %.2f s (%s)\n", S.info.time_schedule_record,
+                S.schedule_recorded ? "ok" : "nothing recorded");
+}
+
 void numeric_factorize(Solver &S)
 {
     if (S.factored)
@@ -1074,9 +1134,7 @@ void numeric_factorize(Solver &S)
     // Static schedule (one rank on the device; PANGULU_AMD_REPLAY=0 turns it off): the launches of a factorisation depend on
     // the block pattern and the back-end's options only, so the first pangulu_gstrf of a handle records them in the back-end
     // (pangulu_platform_0201001_schedule) and every later one replays the list -- no scheduler, no descriptor building.
-    static const bool replay_on = !(getenv("PANGULU_AMD_REPLAY") && atoi(getenv("PANGULU_AMD_REPLAY")) == 0);
-    const bool can_schedule = replay_on && S.nproc == 1 && !plat.host_memory && plat.schedule && g_task_sample_stride <= 1 && !S.eager_host_mirror &&
-                              !getenv("PANGULU_AMD_FORCE_MULTI_LOOP");
+    const bool can_schedule = schedule_possible(S, plat);
     if (plat.set_option)
     {
         plat.set_option(PANGULU_HIP_OPT_HOST_MIRROR, S.eager_host_mirror ? 1 : 0);

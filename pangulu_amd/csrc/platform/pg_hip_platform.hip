@@ -1800,7 +1800,7 @@ struct Backend
     // dense-front kernel (pg_hip_front.h) for the (destination, tile) pairs all of whose queued updates have every 16 x 16
     // piece live: LDS stages of its operand pipeline (2, 3 or 4; 0 = off, everything through the general kernel)
     long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15: 1 = inside the general launch (no step list), 2..4 = own kernel
-    long long opt_front_min_wgs = 2048; // PANGULU_HIP_FRONT_MIN_WGS: ... from this many qualifying workgroups in a launch on
+    long long opt_front_min_wgs = 8192; // PANGULU_HIP_FRONT_MIN_WGS: ... from this many qualifying workgroups in a launch on (sweep: fem27(112) 842.8 / 845.0 / 849.0 ms at 8192 / 2048 / never)
     long long opt_front_unit = 1;   // PANGULU_HIP_FRONT_UNIT: consecutive destinations of the front launch that share an XCD
     // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 2 / 3 / 4 = the
     // LDS-DMA pipeline with that many stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h)
@@ -1847,7 +1847,7 @@ Backend B;
 // ---------------------------------------------------------------------------------------------------------------
 struct Recorder
 {
-    int mode = 0; // 1: recording
+    int mode = 0; // 1: recording while executing; 2: recording only (dry run of the scheduler at pangulu_init: nothing is launched)
     bool valid = false;
     const void *owner = nullptr;
     unsigned long long signature = 0;
@@ -1883,13 +1883,15 @@ inline T rec_xl(T v)
 template <class K, class... A>
 inline void pg_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, A... args)
 {
-    if (REC.mode == 1)
+    if (REC.mode != 0)
     {
         auto targs = std::make_tuple(rec_xl(args)...);
         REC.ops.emplace_back([=]()
                              { std::apply([&](auto... a)
                                           { hipLaunchKernelGGL(kernel, grid, block, (unsigned)shmem, st, a...); },
                                           targs); });
+        if (REC.mode == 2)
+            return;
     }
     hipLaunchKernelGGL(kernel, grid, block, (unsigned)shmem, st, args...);
 }
@@ -1897,15 +1899,17 @@ inline void pg_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t
 
 inline void pg_event_record(hipEvent_t e, hipStream_t s)
 {
-    if (REC.mode == 1)
+    if (REC.mode != 0)
         REC.ops.emplace_back([e, s]() { HIP_CHECK(hipEventRecord(e, s)); });
-    HIP_CHECK(hipEventRecord(e, s));
+    if (REC.mode != 2)
+        HIP_CHECK(hipEventRecord(e, s));
 }
 inline void pg_stream_wait(hipStream_t s, hipEvent_t e)
 {
-    if (REC.mode == 1)
+    if (REC.mode != 0)
         REC.ops.emplace_back([e, s]() { HIP_CHECK(hipStreamWaitEvent(s, e, 0)); });
-    HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+    if (REC.mode != 2)
+        HIP_CHECK(hipStreamWaitEvent(s, e, 0));
 }
 
 void ensure_ready()
@@ -2069,7 +2073,7 @@ void join_background(hipStream_t s)
 Segment acquire_segment()
 {
     Ring &r = B.ring;
-    if (REC.mode == 1)
+    if (REC.mode != 0)
     {
         // recording: the launches will be replayed, their descriptors have to stay -- a segment of its own, kept by the recorder
         char *h = nullptr, *d = nullptr, *twin = nullptr;
@@ -3983,16 +3987,17 @@ extern "C"
             }
             return 0;
         case 1:
+        case 4:
             HIP_CHECK(hipDeviceSynchronize());
-            drop_schedule();
+            drop_schedule(); // (4: like 1, but nothing is launched while recording -- the scheduler's dry run at pangulu_init)
             if (B.opt_profile || B.opt_host_mirror || !B.opt_assume_independent)
                 return -1;
-            REC.mode = 1;
+            REC.mode = cmd == 4 ? 2 : 1;
             REC.owner = owner;
             REC.signature = options_signature();
             return 0;
         case 2:
-            if (REC.mode != 1)
+            if (REC.mode == 0)
                 return -1;
             REC.mode = 0;
             // the recorded run's kernels have read the segments in place; the replays read the HBM twins

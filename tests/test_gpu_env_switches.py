@@ -28,7 +28,8 @@ SWITCHES = [
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_SMALL_LAUNCH_TASKS": "0", "_matrix": "fem27"},
     {"PANGULU_AMD_PANEL_FIRST": "0", "PG_TEST_HIP_OPTIONS": "14=0"},  # round 2's look-ahead: no background stream
     {"PANGULU_AMD_PANEL_FIRST": "0"},
-    {"PANGULU_AMD_REPLAY": "0"},
+    {"PANGULU_AMD_REPLAY": "0"},               # the scheduler in the loop (no static schedule)
+    {"PANGULU_AMD_RECORD_AT_INIT": "0"},       # schedule recorded by the first gstrf instead of a dry run at init
     {"PANGULU_AMD_FORCE_MULTI_LOOP": "1"},     # one rank through the multi-rank scheduler loop (launcher thread + markers)
     {"PG_TEST_HIP_OPTIONS": "15=0,16=0"},      # round 2's MFMA update kernel
     {"PG_TEST_HIP_OPTIONS": "15=3,16=3"},      # LDS-DMA update kernels with three stages
