@@ -581,15 +581,19 @@ def gpu_worker_main(args):
             # from a committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass (tools/profile_recipe.sh; FETCH_SIZE doubled as
             # MI355X_MICROARCH.md prescribes for gfx950) -- but ONLY if that pass profiled this build's kernels on this
             # workload: the file records the workload and a hash of the kernel sources, anything else leaves `traffic` null
-            rocprof_name = {"ssssm_dense_mfma": "ssssm_tiles_f64_kernel<2>", "getrf": "getrf_tiled_f64_kernel",
-                            "tstrf": "trsm_dense_direct_f64_kernel<16>", "gessm": "trsm_dense_direct_f64_kernel<16>",
-                            "ssssm_sparse": "ssssm_sparse_kernel<false>"}.get(dom)
+            # (a launch of the MFMA update class is one launch of the general kernel plus, from 8192 dense-front workgroups on,
+            #  one of the dense-front kernel: their bytes are added up per launch of the class)
+            rocprof_names = {"ssssm_dense_mfma": ["ssssm_tiles_f64_kernel<2>", "ssssm_front_f64_kernel<2, true>"], "getrf": ["getrf_tiled_f64_kernel"],
+                             "tstrf": ["trsm_dense_direct_f64_kernel<16>"], "gessm": ["trsm_dense_direct_f64_kernel<16>"],
+                             "ssssm_sparse": ["ssssm_sparse_kernel<false>"]}.get(dom)
             tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if world == 1 and rocprof_name and os.path.exists(tfile):
+            if world == 1 and rocprof_names and os.path.exists(tfile):
                 tj = json.load(open(tfile)).get(workload_key(args))
-                if tj and tj.get("kernel_source_hash") == kernel_source_hash() and tj.get(rocprof_name):
-                    roofline["traffic"] = tj[rocprof_name]["hbm_bytes_per_launch"]
-                    roofline["traffic_unit"] = "bytes per launch (rocprofv3 PMC pass of this build on this workload, %s)" % tj.get("profile", "profiles/")
+                if tj and tj.get("kernel_source_hash") == kernel_source_hash() and tj.get(rocprof_names[0]):
+                    total = sum(tj[k]["hbm_bytes_per_launch"] * tj[k]["calls"] for k in rocprof_names if tj.get(k))
+                    roofline["traffic"] = total / tj[rocprof_names[0]]["calls"]
+                    roofline["traffic_unit"] = "HBM bytes per launch of the class (rocprofv3 PMC passes of this build on this workload, %s; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % tj.get("profile", "profiles/")
+                    roofline["traffic_over_algorithmic"] = roofline["traffic"] / (v["alg_bytes"] / max(1, v["launches"]))
                 else:
                     roofline["traffic_note"] = "no PMC pass of this build on this workload committed (profiles/hbm_traffic.json)"
             roofline["avg_launch_us"] = kernels[dom]["avg_launch_us"]
