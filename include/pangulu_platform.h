@@ -260,12 +260,14 @@ extern "C"
     /*   PANGULU_HIP_OPT_FRONT_STAGES (default 2; environment PANGULU_HIP_FRONT_STAGES at start-up): (destination, 128 x 128
      *     tile) pairs whose queued updates are all dense-front products -- every 16 x 16 piece of both operands that meets
      *     the tile holds pattern entries -- need no occupancy bookkeeping.  1: they run inside the general launch on its
-     *     no-step-list path (one launch, one tail; needs TILES_STAGES >= 2); 2, 3 or 4: on the dense-front kernel of their
+     *     no-step-list path (one launch, one tail; needs TILES_STAGES >= 1); 2, 3 or 4: on the dense-front kernel of their
      *     own (operand slabs by LDS-DMA, that many LDS stages) when a launch has at least PANGULU_HIP_FRONT_MIN_WGS (8192) of
      *     them, inside the general launch otherwise; 0: treated like any other tile. */
 #define PANGULU_HIP_OPT_FRONT_STAGES 15
     /*   PANGULU_HIP_OPT_TILES_STAGES (default 2; environment PANGULU_HIP_TILES_STAGES at start-up): the general MFMA update
-     *     kernel -- 2, 3 or 4: operand slabs by LDS-DMA with that many LDS stages, strided piece ownership of the wavefronts
+     *     kernel -- operand slabs by LDS-DMA, strided piece ownership of the wavefronts.  2: two LDS stages, step records
+     *     fetched a step ahead, the DMA instructions of the next slab issued behind the first products of the current one
+     *     (ssssm_tilesv_f64_kernel); 1: two stages, DMA issue right behind the barrier; 3 or 4: that many stages
      *     (ssssm_tiles_f64_kernel); 0: round 2's kernel (register staging, contiguous 64 x 32 sub-tiles). */
 #define PANGULU_HIP_OPT_TILES_STAGES 16
     int pangulu_platform_0201001_set_option(int option, long long value);

@@ -245,6 +245,12 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_front
 //    drains between windows (queues longer than 16 are rare: the scheduler flushes them level by level).
 // ---------------------------------------------------------------------------------------------------------------
 #define TL_WINDOW 16
+#ifndef TL_MARK // (cycle probes of tools/microbench/front_gemm.hip; nothing in the product build)
+#define TL_PROBE_DECL
+#define TL_MARK(i)
+#define TL_PROBE_STEP
+#define TL_PROBE_FLUSH
+#endif
 template <int STAGES>
 __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb, const SsssmWorkD *__restrict__ work,
                                                                      unsigned long long *__restrict__ product_counter, unsigned unit)
@@ -472,8 +478,11 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
         for (int p = 0; p < STAGES - 1; p++)
             if (p < T)
                 issue(p, (stage_head + p) % STAGES);
+        TL_PROBE_DECL
         for (int st = 0; st < T; st++)
         {
+            TL_MARK(4)
+            TL_PROBE_STEP
             const int ahead = min(STAGES - 2, T - 1 - st);
             if (STAGES >= 4 && ahead >= 2)
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -481,9 +490,12 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TL_MARK(0)
             __builtin_amdgcn_s_barrier();
+            TL_MARK(1)
             if (st + STAGES - 1 < T)
                 issue(st + STAGES - 1, (stage_head + st + STAGES - 1) % STAGES);
+            TL_MARK(2)
             const double *sA = lds + ((stage_head + st) % STAGES) * FR_STAGE_DOUBLES;
             const unsigned w = step_word(st);
             const unsigned ab = w & 0xFFu, bb = (w >> 8) & 0xFFu;
@@ -534,7 +546,9 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
                 }
 #undef TL_READ
             }
+            TL_MARK(3)
         }
+        TL_PROBE_FLUSH
         stage_head = (stage_head + T) % STAGES;
     }
     if (product_counter && lane == 0 && nprod)
@@ -556,6 +570,372 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
         touched = 0; // (a subset of pre: everything has been written)
     }
     // C += acc on the touched pieces
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+    {
+        const unsigned t4 = (touched >> (4 * ni)) & 0xFu;
+        if (!t4)
+            continue;
+        if (G.atomic)
+        {
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+            {
+                if (!((t4 >> mi) & 1u))
+                    continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (acc[ni][mi][r] != 0.0)
+                        atomicAdd((double *)&TL_C(ni, mi, r), acc[ni][mi][r]);
+            }
+            continue;
+        }
+        double old[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                old[mi][r] = ((t4 >> mi) & 1u) ? TL_C(ni, mi, r) : 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+        {
+            if (!((t4 >> mi) & 1u))
+                continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                TL_C(ni, mi, r) = old[mi][r] + acc[ni][mi][r];
+        }
+    }
+#undef TL_C
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ssssm_tilesv_f64_kernel: the two-stage general update kernel with the fixed cost of a slab step taken out of the chain.
+// Cycle probes in the kernel above (tools/microbench/front_gemm.hip -DTL_PROBE, profiles/r03n_step_cost.log: steps with
+// k x k live products of 64): a step costs F + W cycles, W = its matrix-core work and F = 2300 cycles that do not overlap
+// with it -- the two workgroups of a CU fall into phase: 860 cycles between the barrier and the first fragment read (two
+// dependent LDS round trips for the step word and the operand pointers, then all eight wavefronts queue their four DMA
+// instructions at a 64 B/clk address path at once: 16 cycles each), a third round trip for the step word and a fourth for
+// the first fragments before the first MFMA.
+//  * step records (word, A pointer, B pointer) are fetched from LDS BEFORE the wait and the barrier of the previous step,
+//    and arrive while the wavefront is parked there anyway;
+//  * after the barrier: fragments of k-quarter 0, its products, THEN the DMA instructions for the next slab -- the address
+//    path works in the shadow of the matrix cores and a wavefront's DMA instructions no longer queue behind fifteen others;
+//  * DMA instructions whose B piece is dead are not issued (every wait of a two-stage pipeline is vmcnt(0)).
+// ---------------------------------------------------------------------------------------------------------------
+#define TV_STEPS (TL_WINDOW * 16)
+__global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb, const SsssmWorkD *__restrict__ work,
+                                                                          unsigned long long *__restrict__ product_counter, unsigned unit)
+{
+    __shared__ __align__(16) double lds[2 * FR_STAGE_DOUBLES];
+    __shared__ unsigned long long s_spa[TV_STEPS], s_spb[TV_STEPS]; // operand mirrors of the live steps of the window, in order
+    __shared__ u32 s_step[TV_STEPS];                                // task << 20 | slab << 16 | bbits << 8 | abits
+    __shared__ u32 s_cnt[FR_THREADS / 64];
+#if PG_PLANES > 1
+    __shared__ double s_sign[TL_WINDOW];
+#endif
+    const int tiles = nb / FR_TILE;
+    const unsigned bid = logical_block_id(unit ? unit : (unsigned)(tiles * tiles));
+    const SsssmWorkD G = work[bid];
+    const int tile = (int)G.tile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M0 = (tile % tiles) * FR_TILE, N0 = (tile / tiles) * FR_TILE;
+    const int wr = wave & 1, wc = wave >> 1; // row pieces 2 mi + wr, column pieces wc + 4 ni
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ntask = (int)(G.task_end - G.task_begin);
+    const int nslab = nb / FR_KS;
+    const SsssmTaskD *my_tasks = tasks + G.task_begin;
+
+    const unsigned a_voff = (unsigned)lane * 16u;
+    const int a_piece = lane >> 3;
+    const int bc = lane >> 3, bj = lane & 7;
+    const unsigned b_voff = ((unsigned)bc * (unsigned)nb + 2u * (unsigned)(bj ^ ((4 * (wave & 1) + (bc >> 1)) & 7))) * 8u;
+
+    v4f64 acc[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+            acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    unsigned touched = 0, nprod = 0;
+
+    const int a_frag = l4 * FR_LDA + wr * 16 + l15; // + kq * 4 * FR_LDA + mi * 32
+    int b_frag[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++)
+    {
+        const int n = (wc + 4 * ni) * 16 + l15;
+        b_frag[ni][0] = FR_KS * FR_LDA + n * 16 + (l4 & 1);
+        b_frag[ni][1] = (n >> 1) & 7;
+    }
+    const bool all_live = G.pad_ != 0;
+    const int slab_shift = nb == 256 ? 4 : 3;
+
+    auto uniform64 = [&](unsigned long long v) -> fr_gptr
+    { return (fr_gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v)); };
+    auto issue = [&](unsigned w, fr_gptr pa, fr_gptr pb, int stage_no)
+    {
+        const unsigned ab = w & 0xFFu, bb = (w >> 8) & 0xFFu;
+        const int k0 = (int)((w >> 16) & 15u) * FR_KS;
+        double *stage = lds + stage_no * FR_STAGE_DOUBLES;
+        const bool a_live = (ab >> a_piece) & 1u;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int k = wave + 8 * h;
+            const unsigned off = a_live ? (unsigned)(((k0 + k) * nb + M0) * 8) + a_voff : 0u;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dg_scalar_base(pa) + off), (fr_lptr)(stage + k * FR_LDA), 16, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int g = wave + 8 * h;
+            if (!((bb >> (g >> 1)) & 1u))
+                continue;
+            const unsigned off = (unsigned)(((N0 + 8 * g) * nb + k0) * 8) + b_voff;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dg_scalar_base(pb) + off), (fr_lptr)(stage + FR_KS * FR_LDA + g * 128), 16, 0, 0);
+        }
+    };
+
+    double __attribute__((address_space(1))) *C = (double __attribute__((address_space(1))) *)reinterpret_cast<double *>(G.cdense);
+    const unsigned c_voff = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
+#define TL_C(ni_, mi_, r_)                                                                           \
+    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((const char __attribute__((address_space(1))) *)C +                    \
+                                                                  ((size_t)(N0 + (wc + 4 * (ni_)) * 16 + 4 * (r_)) * nb + M0 + wr * 16) * 8) + \
+                                                   dg_lane_offset(c_voff) + (mi_) * 256))
+    unsigned pre = 0;
+    const bool may_preload = !G.atomic && ntask <= TL_WINDOW;
+
+    int stage_head = 0;
+    for (int win0 = 0; win0 < ntask; win0 += TL_WINDOW)
+    {
+        // ---- the window's step list (no DMA is in flight here: plain barriers) --------------------------------------
+        __syncthreads();
+        int T;
+        if (all_live)
+        {
+            // step e = slab e & (nslab - 1) of task e >> slab_shift, every piece live
+            T = min(TL_WINDOW, ntask - win0) * nslab;
+            if (tid < T)
+            {
+                const int t_ = tid >> slab_shift;
+                const SsssmTaskD &Tm = my_tasks[win0 + t_];
+                s_step[tid] = ((unsigned)t_ << 20) | ((unsigned)(tid & (nslab - 1)) << 16) | 0xFFFFu;
+                s_spa[tid] = (unsigned long long)reinterpret_cast<const double *>(Tm.a.val);
+                s_spb[tid] = (unsigned long long)reinterpret_cast<const double *>(Tm.b.val);
+#if PG_PLANES > 1
+                if ((tid & (nslab - 1)) == 0)
+                    s_sign[t_] = Tm.sign;
+#endif
+            }
+            __syncthreads();
+        }
+        else
+        {
+            unsigned v = 0;
+            unsigned long long pa_v = 0, pb_v = 0;
+            const int t_ = tid >> 4, s_ = tid & 15;
+            if (tid < TL_WINDOW * 16 && win0 + t_ < ntask && s_ < nslab)
+            {
+                const SsssmTaskD &Tm = my_tasks[win0 + t_];
+                const double *pa_ = reinterpret_cast<const double *>(Tm.a.val), *pb_ = reinterpret_cast<const double *>(Tm.b.val);
+                pa_v = (unsigned long long)pa_;
+                pb_v = (unsigned long long)pb_;
+                unsigned ab_, bb_ = 0;
+                if (Tm.has_map)
+                {
+                    ab_ = ((unsigned)Tm.amap[s_] >> (M0 / 16)) & 0xFFu;
+                    bb_ = ((unsigned)Tm.bmap_t[s_] >> (N0 / 16)) & 0xFFu;
+                }
+                else
+                {
+                    ab_ = ((unsigned)mirror_map(pa_, nb)[s_] >> (M0 / 16)) & 0xFFu;
+                    const uint4 mb_ = *reinterpret_cast<const uint4 *>(mirror_map(pb_, nb) + N0 / 16);
+                    const unsigned w_[4] = {mb_.x, mb_.y, mb_.z, mb_.w};
+#pragma unroll
+                    for (int c_ = 0; c_ < 8; c_++)
+                        bb_ |= (((w_[c_ >> 1] >> (16 * (c_ & 1))) >> s_) & 1u) << c_;
+                }
+                if (ab_ && bb_ && (!G.slab_mask || ((G.slab_mask >> s_) & 1u)))
+                    v = (bb_ << 8) | ab_ | ((unsigned)s_ << 16) | ((unsigned)t_ << 20);
+#if PG_PLANES > 1
+                if (s_ == 0)
+                    s_sign[t_] = Tm.sign;
+#endif
+            }
+            const unsigned long long bal = __ballot(v != 0);
+            if (lane == 0)
+                s_cnt[wave] = (u32)__builtin_popcountll(bal);
+            __syncthreads();
+            unsigned at = (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), all = 0;
+#pragma unroll
+            for (int w_i = 0; w_i < FR_THREADS / 64; w_i++)
+            {
+                const unsigned c_ = s_cnt[w_i];
+                at += w_i < wave ? c_ : 0u;
+                all += c_;
+            }
+            if (v)
+            {
+                s_step[at] = v;
+                s_spa[at] = pa_v;
+                s_spb[at] = pb_v;
+            }
+            __syncthreads();
+            T = __builtin_amdgcn_readfirstlane((int)all);
+        }
+        if (T == 0)
+            continue;
+
+        // (the destination first: its loads are then older than every DMA, and the waits below cover them)
+        if (may_preload)
+        {
+            unsigned m = 0;
+            if (all_live)
+                m = 0xFFu;
+            else
+            {
+                for (int e = lane; e < T; e += 64)
+                {
+                    const unsigned w = s_step[e];
+                    const unsigned ab = w & 0xFFu, bb = (w >> 8) & 0xFFu;
+                    const unsigned a4 = ((ab >> wr) & 1u) | (((ab >> (2 + wr)) & 1u) << 1) | (((ab >> (4 + wr)) & 1u) << 2) | (((ab >> (6 + wr)) & 1u) << 3);
+                    if ((bb >> wc) & 1u)
+                        m |= a4;
+                    if ((bb >> (wc + 4)) & 1u)
+                        m |= a4 << 4;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+                    m |= (unsigned)__shfl_xor((int)m, off, 64);
+            }
+            pre = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++)
+                    if ((pre >> (4 * ni + mi)) & 1u)
+                    {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            acc[ni][mi][r] = TL_C(ni, mi, r);
+                    }
+        }
+        // ---- the pipeline over the window's T live steps -------------------------------------------------------------
+        // wC: word of the step being consumed; (wN, paN, pbN): record of the step whose slab is fetched during it
+        unsigned wC = (unsigned)__builtin_amdgcn_readfirstlane((int)s_step[0]), wN = 0;
+        fr_gptr paN = uniform64(s_spa[0]), pbN = uniform64(s_spb[0]);
+        issue(wC, paN, pbN, stage_head);
+        if (T > 1)
+        {
+            wN = (unsigned)__builtin_amdgcn_readfirstlane((int)s_step[1]);
+            paN = uniform64(s_spa[1]);
+            pbN = uniform64(s_spb[1]);
+        }
+        TL_PROBE_DECL
+        for (int st = 0; st < T; st++)
+        {
+            TL_MARK(6)
+            TL_PROBE_STEP
+            // (record of step st + 2: in flight across the wait and the barrier)
+            const int e2 = min(st + 2, T - 1);
+            const unsigned v_w = s_step[e2];
+            const unsigned long long v_pa = s_spa[e2], v_pb = s_spb[e2];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TL_MARK(0)
+            __builtin_amdgcn_s_barrier();
+            TL_MARK(1)
+            const unsigned w2 = (unsigned)__builtin_amdgcn_readfirstlane((int)v_w);
+            const fr_gptr pa2 = uniform64(v_pa), pb2 = uniform64(v_pb);
+            const double *sA = lds + ((stage_head + st) & 1) * FR_STAGE_DOUBLES;
+            const unsigned ab = wC & 0xFFu, bb = (wC >> 8) & 0xFFu;
+            const unsigned a4 = ((ab >> wr) & 1u) | (((ab >> (2 + wr)) & 1u) << 1) | (((ab >> (4 + wr)) & 1u) << 2) | (((ab >> (6 + wr)) & 1u) << 3);
+            const unsigned b2 = ((bb >> wc) & 1u) | (((bb >> (wc + 4)) & 1u) << 1);
+            const bool live = a4 && b2;
+#if PG_PLANES > 1
+            const bool add = s_sign[wC >> 20] < 0;
+#define TV_MFMA(buf_)                                                                                                                       \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ni++)                                                                                       \
+    {                                                                                                                                       \
+        if (!((b2 >> ni) & 1u))                                                                                                             \
+            continue;                                                                                                                       \
+        _Pragma("unroll") for (int mi = 0; mi < 4; mi++) if ((a4 >> mi) & 1u)                                                              \
+        {                                                                                                                                   \
+            if (add)                                                                                                                        \
+                acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni], fa[buf_][mi], acc[ni][mi], 0, 0, 0);                       \
+            else                                                                                                                            \
+                acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni], fa[buf_][mi], acc[ni][mi], 0, 0, DG_NEG_A);                \
+        }                                                                                                                                   \
+    }
+#else
+#define TV_MFMA(buf_)                                                                                                                       \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ni++)                                                                                       \
+    {                                                                                                                                       \
+        if (!((b2 >> ni) & 1u))                                                                                                             \
+            continue;                                                                                                                       \
+        _Pragma("unroll") for (int mi = 0; mi < 4; mi++) if ((a4 >> mi) & 1u)                                                              \
+            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni], fa[buf_][mi], acc[ni][mi], 0, 0, DG_NEG_A);                    \
+    }
+#endif
+#define TV_READ(buf_, kq_)                                                                            \
+    {                                                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < 4; mi++) fa[buf_][mi] = sA[a_frag + (kq_) * 4 * FR_LDA + mi * 32]; \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ni++) fb[buf_][ni] = sA[b_frag[ni][0] + 2 * ((2 * (kq_) + (l4 >> 1)) ^ b_frag[ni][1])]; \
+    }
+            double fa[2][4], fb[2][2];
+            if (live)
+            {
+                nprod += (unsigned)(__builtin_popcount(a4) * __builtin_popcount(b2));
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+                    if ((b2 >> ni) & 1u)
+                        touched |= a4 << (4 * ni);
+                TV_READ(0, 0)
+                TV_READ(1, 1)
+                TV_MFMA(0)
+            }
+            TL_MARK(2)
+            // the next slab, behind this wavefront's first products
+            if (st + 1 < T)
+                issue(wN, paN, pbN, (stage_head + st + 1) & 1);
+            TL_MARK(3)
+            if (live)
+            {
+                TV_READ(0, 2)
+                TV_MFMA(1)
+                TV_READ(1, 3)
+                TV_MFMA(0)
+                TV_MFMA(1)
+            }
+#undef TV_READ
+#undef TV_MFMA
+            wC = wN;
+            wN = w2;
+            paN = pa2;
+            pbN = pb2;
+            TL_MARK(4)
+        }
+        TL_PROBE_FLUSH
+        stage_head = (stage_head + T) & 1;
+    }
+    if (product_counter && lane == 0 && nprod)
+        atomicAdd(product_counter, (unsigned long long)nprod);
+
+    if (pre)
+    {
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+                if ((pre >> (4 * ni + mi)) & 1u)
+                {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        TL_C(ni, mi, r) = acc[ni][mi][r];
+                }
+        touched = 0;
+    }
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
     {

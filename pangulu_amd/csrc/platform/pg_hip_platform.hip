@@ -1802,8 +1802,9 @@ struct Backend
     long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15: 1 = inside the general launch (no step list), 2..4 = own kernel
     long long opt_front_min_wgs = 8192; // PANGULU_HIP_FRONT_MIN_WGS: ... from this many qualifying workgroups in a launch on (sweep: fem27(112) 842.8 / 845.0 / 849.0 ms at 8192 / 2048 / never)
     long long opt_front_unit = 1;   // PANGULU_HIP_FRONT_UNIT: consecutive destinations of the front launch that share an XCD
-    // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 2 / 3 / 4 = the
-    // LDS-DMA pipeline with that many stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h)
+    // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 1 / 3 / 4 = the
+    // LDS-DMA pipeline with 2 / 3 / 4 stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h), 2 = its
+    // two-stage form with the per-step fixed cost taken out of the chain (ssssm_tilesv_f64_kernel)
     long long opt_tiles_stages = 2; // PANGULU_HIP_TILES_STAGES / option 16
     long long opt_tiles_unit = 1;   // PANGULU_HIP_TILES_UNIT: consecutive destinations of the general launch that share an XCD
     unsigned long long front_workgroups = 0, general_workgroups = 0;
@@ -2628,7 +2629,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 // products (every 16 x 16 piece of every operand live, no K-split) go to the front kernel's list
                 int tiles = nb / DG_TILE;
                 size_t nw = 0, nf = 0, nfm = 0;
-                const bool front_on = B.opt_front_stages >= 1 && (nb == 128 || nb == 256) && (B.opt_front_stages >= 2 || B.opt_tiles_stages >= 2);
+                const bool front_on = B.opt_front_stages >= 1 && (nb == 128 || nb == 256) && (B.opt_front_stages >= 2 || B.opt_tiles_stages >= 1);
                 // (first pass: which pairs qualify, and how many -- a front launch of its own pays from a few thousand workgroups
                 //  on: fem27(112) 883.8 ms with it against 892.1 with the pairs inside the general launch, shell(398) 39.2 against 38.5)
                 static std::vector<unsigned char> full_g;
@@ -2644,7 +2645,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                     full_g[gi] = (unsigned char)all_full;
                     nfull += (size_t)__builtin_popcount(all_full);
                 }
-                const bool own_launch = B.opt_front_stages >= 2 && (B.opt_tiles_stages < 2 || nfull >= (size_t)B.opt_front_min_wgs);
+                const bool own_launch = B.opt_front_stages >= 2 && (B.opt_tiles_stages < 1 || nfull >= (size_t)B.opt_front_min_wgs);
                 for (size_t gi = 0; gi < gd; gi++)
                 {
                     const SsssmGroupD &Gd = groups_d[gi];
@@ -2705,8 +2706,15 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                         PG_LAUNCH((ssssm_tiles_f64_kernel<4>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
                     else if (B.opt_tiles_stages == 3)
                         PG_LAUNCH((ssssm_tiles_f64_kernel<3>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
-                    else
-                        PG_LAUNCH((ssssm_tiles_f64_kernel<2>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                    else if (B.opt_tiles_stages == 2)
+                        // (the default: two stages, step records prefetched, DMA issue behind the first products)
+                        PG_LAUNCH(ssssm_tilesv_f64_kernel, dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                }
+                else if (nw && B.opt_tiles_stages == 1)
+                {
+                    // (the first two-stage version: DMA issue right behind the barrier)
+                    const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_tiles_unit);
+                    PG_LAUNCH((ssssm_tiles_f64_kernel<2>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
                 }
                 else if (nw)
                     PG_LAUNCH(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb, pc,

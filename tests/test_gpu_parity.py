@@ -107,7 +107,7 @@ def test_dense_front_kernel(n, nb, stages):
     assert gpu["hip_stats"]["ssssm_dense_mfma"]["mfma_flops_executed"] == 2.0 * nb ** 3 * st["tasks"]
 
 
-@pytest.mark.parametrize("tiles_stages", [0, 2, 3, 4])
+@pytest.mark.parametrize("tiles_stages", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("name,gen,nb", [("fem27_20_nb128", lambda: M.fem27(20), 128), ("fem27_24_nb256", lambda: M.fem27(24), 256),
                                          ("shell_40_nb256", lambda: M.shell(40, 40), 256)])
 def test_general_update_kernels(name, gen, nb, tiles_stages):

@@ -32,6 +32,14 @@ __device__ inline unsigned logical_block_id(unsigned per_unit)
     const unsigned x = b & 7, idx = b >> 3;
     return (x + 8u * (idx / per_unit)) * per_unit + idx % per_unit;
 }
+#ifdef TL_PROBE
+// cycle probes inside ssssm_tiles_f64_kernel (wavefronts 0 and 5 of every workgroup): where does a slab step spend its time?
+__device__ unsigned long long g_probe[8];
+#define TL_PROBE_DECL unsigned long long pr_t = __builtin_readcyclecounter(), pr_sum[7] = {0, 0, 0, 0, 0, 0, 0};
+#define TL_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); pr_sum[i] += n_ - pr_t; pr_t = n_; }
+#define TL_PROBE_FLUSH if (lane == 0 && (wave == 0 || wave == 5)) { for (int i_ = 0; i_ < 7; i_++) atomicAdd(&g_probe[i_], pr_sum[i_]); }
+#define TL_PROBE_STEP pr_sum[5]++;
+#endif
 #include "../../pangulu_amd/csrc/platform/pg_hip_dense.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_front.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -60,8 +68,27 @@ struct Problem
 // that multiplies them fails the check
 static unsigned long long rng_state = 0x9E3779B97F4A7C15ull;
 static unsigned rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (unsigned)(rng_state >> 33); }
-void random_map(unsigned short *map, int fill)
+// fill = -k: every slab live with exactly k contiguous 16-row pieces in each 128-row half (`transposed`: the map of a B operand,
+// k live column pieces per half in every row slab) -- every slab step of every tile then has k x k live products
+void random_map(unsigned short *map, int fill, bool transposed = false)
 {
+    if (fill < 0)
+    {
+        const int k = -fill;
+        unsigned short w[16];
+        for (int c = 0; c < 16; c++)
+        {
+            const unsigned lo = ((1u << k) - 1u) << (rnd() % (unsigned)(9 - k)), hi = ((1u << k) - 1u) << (rnd() % (unsigned)(9 - k));
+            w[c] = (unsigned short)(lo | (hi << 8));
+        }
+        for (int c = 0; c < 16; c++)
+        {
+            if (!transposed) { map[c] = w[c]; continue; }
+            map[c] = 0;
+            for (int r = 0; r < 16; r++) map[c] |= (unsigned short)(((w[r] >> c) & 1u) << r);
+        }
+        return;
+    }
     for (int c = 0; c < 16; c++)
     {
         if (fill >= 100) { map[c] = 0xFFFF; continue; }
@@ -86,7 +113,7 @@ void build(Problem &X, int P, int Q, bool keep_host, int fill = 100)
     {
         for (size_t i = 0; i < (size_t)X.nb * X.nb; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; one[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
         unsigned short *map = reinterpret_cast<unsigned short *>(one.data() + (size_t)X.nb * X.nb);
-        random_map(map, m < (size_t)2 * Q * P ? fill : 100);
+        random_map(map, m < (size_t)2 * Q * P ? fill : 100, m >= (size_t)Q * P);
         X.maps.insert(X.maps.end(), map, map + 16);
         CK(hipMemcpy(X.d + m * X.mb, one.data(), sizeof(double) * X.mb, hipMemcpyHostToDevice));
         if (keep_host) memcpy(X.h.data() + m * X.mb, one.data(), sizeof(double) * X.mb);
@@ -120,11 +147,18 @@ void build(Problem &X, int P, int Q, bool keep_host, int fill = 100)
 // which: 0 = general kernel; otherwise 100 * unit_destinations + 10 * prefetch + stages
 void launch(int which, Problem &X)
 {
-    const unsigned grid = (unsigned)X.nwork;
+    static const unsigned cap = getenv("GRID_CAP") ? (unsigned)atoi(getenv("GRID_CAP")) : 0u; // (timing experiments: only the first workgroups)
+    const unsigned grid = cap && cap < X.nwork ? cap : (unsigned)X.nwork;
     unsigned long long *none = nullptr;
     if (which == 0)
     {
         hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3(grid), dim3(DG_THREADS), 0, 0, X.dT, X.nb, none, none, X.dW);
+        CK(hipGetLastError());
+        return;
+    }
+    if (which >= 20000)
+    {
+        hipLaunchKernelGGL(ssssm_tilesv_f64_kernel, dim3(grid), dim3(FR_THREADS), 0, 0, X.dT, X.nb, X.dW, none, 4u * (unsigned)((which / 100) % 100));
         CK(hipGetLastError());
         return;
     }
@@ -156,6 +190,11 @@ const char *name_of(int which)
 {
     if (which == 0)
         return "round-2 kernel (pg_hip_dense.h)";
+    if (which >= 20000)
+    {
+        snprintf(name_buf, sizeof(name_buf), "tiles kernel, DMA issue behind the first products, XCD unit %d dest.", (which / 100) % 100);
+        return name_buf;
+    }
     if (which >= 10000)
     {
         snprintf(name_buf, sizeof(name_buf), "tiles kernel (DMA, strided pieces), %d LDS stages, XCD unit %d dest.", which % 10, (which / 100) % 100);
@@ -197,7 +236,7 @@ int main(int argc, char **argv)
         build(X, 3, 2, true, cf);
         const int nb = X.nb;
         std::vector<double> ref((size_t)nb * nb), got((size_t)X.mb);
-        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104} : std::vector<int>{0, 10102, 10103, 10104, 10802};
+        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802};
         for (int which : kinds)
         {
             for (int i = 0; i < X.P; i++)
@@ -226,9 +265,16 @@ int main(int argc, char **argv)
     const double flop = 8192.0 * X.products;
     printf("front %d x %d destinations of 256 x 256, %d update(s) queued on each, %d%% fill pattern: %zu workgroups, %.3f TFLOP of live 16x16x16 products per launch (%.1f%% of dense)\n", P, P, Q,
            fill, X.nwork, flop / 1e12, 100.0 * flop / (2.0 * 256 * 256 * 256 * (double)P * P * Q));
-    std::vector<int> kinds = fill >= 100 ? std::vector<int>{0, 112, 10102, 10103, 10802, 0, 112, 10102, 10103, 10802} : std::vector<int>{0, 10102, 10103, 10104, 10802, 0, 10102, 10103, 10104, 10802};
+    std::vector<int> kinds = fill >= 100 ? std::vector<int>{0, 112, 10102, 20102, 10802, 20802, 0, 112, 10102, 20102, 10802, 20802} : std::vector<int>{0, 10102, 20102, 10802, 20802, 0, 10102, 20102, 10802, 20802};
+#ifdef TL_PROBE
+    kinds = {10102, 20102, 10102, 20102};
+#endif
     for (int which : kinds)
     {
+#ifdef TL_PROBE
+        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zero, sizeof(zero)));
+#endif
         float best = 1e30f, sum = 0;
         for (int rep = 0; rep < 5; rep++)
         {
@@ -242,6 +288,17 @@ int main(int argc, char **argv)
             if (rep) sum += ms;
         }
         printf("time   %-66s best %8.3f ms = %6.2f TFLOP/s executed, mean of 4 %8.3f ms = %6.2f\n", name_of(which), best, flop / best / 1e9, sum / 4, flop / (sum / 4) / 1e9);
+#ifdef TL_PROBE
+        unsigned long long pr[8];
+        CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr)));
+        const double st = (double)pr[5];
+        if (which >= 20000)
+            printf("probe  cycles per slab step and wavefront (%.0f steps sampled): record reads + wait for the slab %.0f, barrier %.0f, fragments + first quarter %.0f, issue of the next slab %.0f, other three quarters %.0f, between steps %.0f: %.0f in all\n",
+                   st, pr[0] / st, pr[1] / st, pr[2] / st, pr[3] / st, pr[4] / st, pr[6] / st, (pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[6]) / st);
+        else
+            printf("probe  cycles per slab step and wavefront (%.0f steps sampled): wait for the slab %.0f, barrier %.0f, issue of the next slab %.0f, step word + fragments + matrix cores %.0f, between steps %.0f: %.0f in all\n",
+                   st, pr[0] / st, pr[1] / st, pr[2] / st, pr[3] / st, pr[4] / st, (pr[0] + pr[1] + pr[2] + pr[3] + pr[4]) / st);
+#endif
     }
     return 0;
 }
