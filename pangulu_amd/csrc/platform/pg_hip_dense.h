@@ -616,7 +616,7 @@ __device__ inline void mirror_put(double *dense, size_t at, int nb, val_t v)
 __device__ inline val_t mirror_get(const double *dense, size_t at, int nb)
 {
 #if PG_PLANES > 1
-    return val_t{dense[at], dense[at + mirror_plane_stride(nb)]};
+    return val_t{(real_t)dense[at], (real_t)dense[at + mirror_plane_stride(nb)]};
 #else
     (void)nb;
     return dense[at];

@@ -253,7 +253,7 @@ bool mirror_is_ahead(slot_t *s)
     return st.brow == s->brow_pos && st.bcol == s->bcol_pos && st.mirror && !st.sparse_current;
 }
 
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
 // dense LU image of the diagonal block `half` belongs to, if GETRF left one
 const double *lu_image_of(slot_t *half)
 {

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     unsigned *flags = smap + 16;    // [0] diagonal tile published, [1] tile factorised, [2] priority tiles in the images
     unsigned char *tlist = reinterpret_cast<unsigned char *>(flags + 4); // per compute wavefront: its tiles of the current step (ti << 4 | tj)
     const GetrfTaskD T = tasks[blockIdx.x];
-    double *__restrict__ D = T.dense;
+    double *__restrict__ D = reinterpret_cast<double *>(T.dense);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int nt = nb / 16;

@@ -131,11 +131,16 @@ __device__ inline val_t clamp_pivot(val_t p)
 }
 
 // Dense-mode updates (mirrors + the f64 MFMA update kernel): R64, and CR64 as two real planes per mirror (pg_hip_dense.h).
-// Dense-mode PANELS (blocked GETRF, dense TSTRF/GESSM on LU images) exist for R64 only.
-#if defined(CALCULATE_TYPE_R64) || defined(CALCULATE_TYPE_CR64)
+// Dense-mode PANELS (blocked GETRF, dense TSTRF/GESSM on LU images) exist for the real types.
+// R32 / CR32 (round 3): the mirrors and LU images of single-precision blocks are DOUBLE -- densify widens, sparsify rounds --
+// and every dense kernel is the f64 one: the arithmetic between two rounding points is at least the reference's (cuBLAS
+// sgemm / cgemm on densified blocks, ...0201000.cu:778-816), one code path serves all four types, and the f64 matrix
+// cores of gfx950 run at half the f32 rate, not at a fraction of it.
 #define PG_DENSE_UPDATES 1
+#if defined(CALCULATE_TYPE_R64) || defined(CALCULATE_TYPE_R32)
+#define PG_DENSE_PANELS 1
 #endif
-#if defined(CALCULATE_TYPE_CR64)
+#if defined(CALCULATE_TYPE_CR64) || defined(CALCULATE_TYPE_CR32)
 #define PG_PLANES 2
 #else
 #define PG_PLANES 1
@@ -225,7 +230,7 @@ struct GetrfTaskD
     const u32 *urp;
     const u16 *uci;
     val_t *uval;
-    val_t *dense; // nb*nb scratch, only touched on the pattern
+    val_t *dense; // nb*nb scratch, only touched on the pattern (the blocked kernels: a DOUBLE image, whatever val_t is)
     u32 preloaded; // blocked kernel: `dense` already holds the block (a dense-mode mirror): skip zero + scatter
     u32 invert_tiles; // blocked kernel: the image will serve the dense solves -- replace its 16 x 16 diagonal tiles by their
                       // inverses before leaving (pg_hip_trsm_dense.h), after the factors have been gathered / the tiles saved
@@ -271,10 +276,10 @@ __device__ inline val_t cdense_get(const val_t *cd, size_t at, int nb)
 {
 #if PG_PLANES > 1
     const double *p = reinterpret_cast<const double *>(cd);
-    return val_t{p[at], p[at + cdense_plane_stride(nb)]};
+    return val_t{(real_t)p[at], (real_t)p[at + cdense_plane_stride(nb)]};
 #else
     (void)nb;
-    return cd[at];
+    return (val_t) reinterpret_cast<const double *>(cd)[at]; // (the mirror of a single-precision block is double as well)
 #endif
 }
 __device__ inline void cdense_put(val_t *cd, size_t at, int nb, val_t v)
@@ -285,7 +290,7 @@ __device__ inline void cdense_put(val_t *cd, size_t at, int nb, val_t v)
     p[at + cdense_plane_stride(nb)] = v.im;
 #else
     (void)nb;
-    cd[at] = v;
+    reinterpret_cast<double *>(cd)[at] = v;
 #endif
 }
 __device__ inline void cdense_atomic_add(val_t *cd, size_t at, int nb, val_t v)
@@ -293,12 +298,13 @@ __device__ inline void cdense_atomic_add(val_t *cd, size_t at, int nb, val_t v)
 #if PG_PLANES > 1
     double *p = reinterpret_cast<double *>(cd);
     if (v.re != 0)
-        atomicAdd(&p[at], v.re);
+        atomicAdd(&p[at], (double)v.re);
     if (v.im != 0)
-        atomicAdd(&p[at + cdense_plane_stride(nb)], v.im);
+        atomicAdd(&p[at + cdense_plane_stride(nb)], (double)v.im);
 #else
     (void)nb;
-    v_atomic_add(&cd[at], v);
+    if (v != 0)
+        atomicAdd(&reinterpret_cast<double *>(cd)[at], (double)v);
 #endif
 }
 
@@ -510,7 +516,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #include "pg_hip_dense.h"
 #include "pg_hip_front.h"
 #endif
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
 #include "pg_hip_trsm_dense.h"
 #endif
 
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(GETRF_THREADS) void getrf_kernel(const GetrfTaskD *
 // The trailing product is formed transposed (A operand = -S^T, B operand = P^T) so that each accumulator register
 // maps to 16 consecutive rows of one column of D: loads and stores of the trailing block are 128-byte segments.
 // -----------------------------------------------------------------------------------------------------------------
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
 #define GETRF_PANEL 16
 #define GETRF_BLOCKED_ROWS 256 // one row thread per row: nb <= 256
 
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(GETRF_BLOCKED_THREADS) __attribute__((amdgpu_waves_
     u32 *sLcp = reinterpret_cast<u32 *>(Rb + GETRF_PANEL * GETRF_PANEL); // column pointer of the lower half (nb + 1 entries)
     u32 *sUrp = sLcp + nb + 1;                                           // row pointer of the upper half
     const GetrfTaskD T = tasks[blockIdx.x];
-    double *__restrict__ D = T.dense;
+    double *__restrict__ D = reinterpret_cast<double *>(T.dense);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = GETRF_BLOCKED_THREADS / 64;
 
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     u32 *sUrp = sLcp + nb + 1;                                           // row pointer of the upper half
     unsigned *la_count = sUrp + nb + 1;                                  // arrivals at the look-ahead wavefronts' own barrier
     const GetrfTaskD T = tasks[blockIdx.x];
-    double *__restrict__ D = T.dense;
+    double *__restrict__ D = reinterpret_cast<double *>(T.dense);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = 1024 / 64;
 
@@ -2770,7 +2776,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         TrsmTaskD *ftasks = seg.alloc<TrsmTaskD>(take, &d_ftasks); // sparse views of the dense-path tasks (flop counting)
         double by_t = 0, by_g = 0;
         size_t nt = 0, ng = 0, nsparse = 0, ndense = 0;
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
         TrsmDenseTaskD *d_dtasks;
         TrsmDenseTaskD *dtasks = seg.alloc<TrsmDenseTaskD>(take, &d_dtasks);
         u32 *d_dwork;
@@ -2829,7 +2835,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 ng++;
             }
             bool dense = false;
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
             // dense path: the diagonal block left a dense LU image with inverted diagonal tiles (launch_getrf) and the
             // block being solved is well filled or already lives in its mirror
             if (dense_ok && (nb == 128 || nb == 256) && B.opt_trsm_dense_permille <= 1000)
@@ -2880,7 +2886,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         if (!MP.to_densify.empty())
             flush_mirror_jobs(nb, MP.to_densify, true);
 #endif
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
         if (!g_half_image_jobs.empty())
         {
             // images of remote diagonal blocks: build, then invert their diagonal tiles (main stream, before the solves)
@@ -2912,7 +2918,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         }
 #endif
         commit_segment(seg);
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
         if (ndense && nsparse && B.opt_two_streams)
             pg_event_record(B.ev_fork, B.stream); // mirrors and sparse records are current from here on
 #endif
@@ -2926,7 +2932,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 PG_LAUNCH(trsm_sparse_kernel, dim3((unsigned)(nsparse * vblocks)), dim3(TRSM_WAVES * 64), lds, B.stream, d_tasks,
                                    nb, B.d_flops + 2, B.d_flops + 3);
             }
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
             if (ndense)
             {
                 // the dense solves run beside the sparse ones (other blocks, same diagonal operands)
@@ -2962,7 +2968,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
 #endif
             HIP_CHECK(hipGetLastError());
         }
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
         if (ndense)
         {
             if (B.opt_count_flops)
@@ -2972,7 +2978,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         }
 #endif
         release_pending_segments();
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
         // the solutions live in the mirrors: bring the sparse records (the authoritative form of a finished block) up
         // to date at once; the mirrors stay valid as MFMA operands
         for (slot_t *s : solved_dense)
@@ -3019,12 +3025,12 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             HIP_CHECK(hipStreamSynchronize(B.stream));
             HIP_CHECK(hipFree(B.getrf_scratch));
         }
-        HIP_CHECK(hipMalloc((void **)&B.getrf_scratch, sizeof(val_t) * (size_t)nb * nb * max_slots));
+        HIP_CHECK(hipMalloc((void **)&B.getrf_scratch, std::max(sizeof(val_t), sizeof(double)) * (size_t)nb * nb * max_slots)); // (a slot holds a double image)
         B.getrf_scratch_slots = max_slots;
         B.nb_cfg = nb;
     }
     bool blocked_kernel = false;
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
     blocked_kernel = !B.opt_getrf_strict && (nb % 16 == 0) && nb <= GETRF_BLOCKED_ROWS;
 #endif
     size_t i = 0;
@@ -3034,7 +3040,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
         size_t take = std::min(n - i, (size_t)B.getrf_scratch_slots);
         GetrfTaskD *d_tasks;
         GetrfTaskD *tasks = seg.alloc<GetrfTaskD>(take, &d_tasks);
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
         std::vector<double *> lu_images; // dense images that will hold L\\U after this launch
         std::vector<MirrorJobD> deferred; // their sparse records are written by sparsify jobs on the records stream
 #endif
@@ -3050,11 +3056,11 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             T.urp = up->d_rowpointer;
             T.uci = up->d_columnindex;
             T.uval = up->d_value;
-            T.dense = B.getrf_scratch + (size_t)k * nb * nb;
+            T.dense = reinterpret_cast<val_t *>(reinterpret_cast<char *>(B.getrf_scratch) + std::max(sizeof(val_t), sizeof(double)) * (size_t)k * nb * nb);
             T.preloaded = 0;
             T.defer_gather = 0;
             T.invert_tiles = 0;
-#if defined(PG_DENSE_UPDATES) && !defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_UPDATES) && !defined(PG_DENSE_PANELS)
             {
                 // (CR64: no blocked kernel) updates may have accumulated in the block's mirror: the record catches up first,
                 // and the mirror is stale once the block is factorised
@@ -3065,7 +3071,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 st.mirror_current = false;
             }
 #endif
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
             {
                 // work on the block's own mirror whenever the pool has one: it may already hold the block (updates
                 // accumulated there), and the dense LU it is left with serves the dense TSTRF/GESSM of this level
@@ -3075,7 +3081,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                     double *m = dense_mode_available(nb) ? obtain_mirror(st, nb) : nullptr;
                     if (m)
                     {
-                        T.dense = m;
+                        T.dense = reinterpret_cast<val_t *>(m);
                         T.preloaded = (st.mirror_current && !st.sparse_current) ? 1u : 0u;
                         T.invert_tiles = 1;
                         if (B.opt_records_stream && nb <= 256)
@@ -3120,7 +3126,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
         {
             LaunchTimer lt(1, ks);
             bool blocked = blocked_kernel;
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
             if (blocked)
             {
                 size_t lds = sizeof(double) * (2 * GETRF_PANEL * (size_t)(nb + 2) + GETRF_PANEL * GETRF_PANEL) + sizeof(u32) * 2 * (size_t)(nb + 1);
@@ -3177,7 +3183,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             }
             HIP_CHECK(hipGetLastError());
         }
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
         if (!deferred.empty())
             pg_event_record(B.ev_rec_fork, ks); // behind the factorisation
 #endif
@@ -3190,7 +3196,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 pg_stream_wait(B.stream, B.ev_join3);
         }
         release_pending_segments(ks); // (the descriptors are read on ks, which the main stream may not have joined yet)
-#if defined(CALCULATE_TYPE_R64)
+#if defined(PG_DENSE_PANELS)
         if (!deferred.empty())
             flush_mirror_jobs(nb, deferred, false, true, nullptr, true);
 #endif

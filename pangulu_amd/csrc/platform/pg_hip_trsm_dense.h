@@ -91,10 +91,10 @@ struct HalfImageJobD
 {
     const u32 *lcp; // lower half, CSC (nullptr: not here)
     const u16 *lri;
-    const double *lval;
+    const val_t *lval;
     const u32 *urp; // upper half, CSR (nullptr: not here)
     const u16 *uci;
-    const double *uval;
+    const val_t *uval;
     double *dense;
 };
 
