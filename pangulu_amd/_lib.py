@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-LIB_DIR = os.path.join(_HERE, "lib")
+LIB_DIR = os.environ.get("PANGULU_AMD_LIB_DIR") or os.path.join(_HERE, "lib")  # (the override: A/B runs of two builds on one box)
 
 # value type tag -> (numpy dtype, sizeof, is_complex)
 VALUE_TYPES = {

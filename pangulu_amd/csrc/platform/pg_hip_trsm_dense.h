@@ -412,12 +412,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
         }                                                                           \
         (out_) = my_lv & fl_;                                                       \
     }
-    // Factor tiles in flight: two register sets of two tiles each, used in turn by the stages of a panel (two products per
-    // stage; the loops are fully unrolled, so the set index is static and nothing is copied), and the inverted diagonal tile
-    // of the panel (two sets, by panel parity).  The first tiles of panel p+1 and its diagonal tile are requested at the end
-    // of panel p, before its diagonal multiply: without that every panel began with a full round trip to L2 (16 per
-    // wavefront, a third of a lone workgroup's 70 us).
-    double at[2][2][4], adb[2][4];
+    // Factor tiles in flight: TRSM_SETS register sets of two tiles each, used in turn by the stages of a panel (two products
+    // per stage; the loops are fully unrolled, so the set index is static and nothing is copied), and the inverted diagonal
+    // tile of the panel (two sets, by panel parity).  The first tiles of panel p+1 and its diagonal tile are requested at
+    // the end of panel p, before its diagonal multiply: without that every panel began with a full round trip to L2 (16 per
+    // wavefront, a third of a lone workgroup's 70 us).  -DTRSM_SETS=3 requests the tiles of stage s + 2 at stage s (24 more
+    // registers): measured, no difference (shell(398) solves 9.28 against 9.27 ms summed, fem27(112) 69.7 against 69.5;
+    // profiles/r03y_trsm_prefetch_ab.log) -- the solves are not bound by the depth of their own load queue.
+#ifndef TRSM_SETS
+#define TRSM_SETS 2
+#endif
+    double at[TRSM_SETS][2][4], adb[2][4];
     bool fetched = false; // the first loads of the coming panel have been issued by the one before
     int set0 = 0;         // set of the coming panel's first stage (static after unrolling)
 #define TRSM_FIRST_LOADS(p_, lq_, set_)                                             \
@@ -427,12 +432,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
             TRSM_A_LOAD(at[set_][0], 0, p_)                                         \
         if ((p_) > 1 && (((lq_) >> 1) & 1u))                                        \
             TRSM_A_LOAD(at[set_][1], 1, p_)                                         \
+        if (TRSM_SETS > 2 && (p_) > 2 && (((lq_) >> 2) & 1u))                       \
+            TRSM_A_LOAD(at[((set_) + 1) % TRSM_SETS][0], 2, p_)                     \
+        if (TRSM_SETS > 2 && (p_) > 3 && (((lq_) >> 3) & 1u))                       \
+            TRSM_A_LOAD(at[((set_) + 1) % TRSM_SETS][1], 3, p_)                     \
     }
 #pragma unroll
     for (int p = 0; p < NP; p++)
     {
         const int st = set0;
-        set0 = (set0 + (p + 1) / 2) & 1; // a panel has (p + 1) / 2 stages
+        set0 = (set0 + (p + 1) / 2) % TRSM_SETS; // a panel has (p + 1) / 2 stages
         if (!((my_lv >> p) & 1u))
         {
             fetched = false;
@@ -448,11 +457,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
 #pragma unroll
         for (int q = 0; q < p; q += 2)
         {
-            const int cur = (st + (q >> 1)) & 1, nxt = cur ^ 1;
-            if (q + 2 < p && ((lq >> (q + 2)) & 1u))
-                TRSM_A_LOAD(at[nxt][0], q + 2, p)
-            if (q + 3 < p && ((lq >> (q + 3)) & 1u))
-                TRSM_A_LOAD(at[nxt][1], q + 3, p)
+            const int cur = (st + (q >> 1)) % TRSM_SETS, nxt = (cur + TRSM_SETS - 1) % TRSM_SETS; // (the set of stage s + SETS - 1)
+            constexpr int ahead = 2 * (TRSM_SETS - 1);
+            if (q + ahead < p && ((lq >> (q + ahead)) & 1u))
+                TRSM_A_LOAD(at[nxt][0], q + ahead, p)
+            if (q + ahead + 1 < p && ((lq >> (q + ahead + 1)) & 1u))
+                TRSM_A_LOAD(at[nxt][1], q + ahead + 1, p)
             if ((lq >> q) & 1u)
             {
 #pragma unroll
