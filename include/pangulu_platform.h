@@ -347,6 +347,8 @@ extern "C"
         unsigned long long trsm_dense_tasks; /* TSTRF/GESSM tasks that took the dense MFMA path */
         /* class 5: workgroups (destination tile x update queue) launched on the dense-front kernel / on the general MFMA kernel */
         unsigned long long ssssm_front_workgroups, ssssm_general_workgroups;
+        /* GETRF -> dense-solve chase: launches that carried a level's factorisations AND its dense solves, and the solves in them */
+        unsigned long long chase_launches, chase_solves;
     } pangulu_hip_stats_t;
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset);
 

@@ -111,6 +111,8 @@ class HipStats(ctypes.Structure):
         ("trsm_dense_tasks", ctypes.c_ulonglong),
         ("ssssm_front_workgroups", ctypes.c_ulonglong),
         ("ssssm_general_workgroups", ctypes.c_ulonglong),
+        ("chase_launches", ctypes.c_ulonglong),
+        ("chase_solves", ctypes.c_ulonglong),
     ]
 
 

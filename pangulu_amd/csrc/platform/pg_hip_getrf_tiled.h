@@ -45,7 +45,8 @@ __host__ __device__ inline size_t gt_lds_bytes(int nb)
 {
     return sizeof(double) * (4 * 16 * (size_t)(nb + 2) + 16 * 17 + 16 + 256) // panel / strip images, Td, rdiag, rd_all
            + sizeof(unsigned) * (2 * (size_t)(nb + 1) + 16 + 4)           // pointer arrays, occupancy map, flags
-           + 64 * GT_COMPUTE_WAVES;                                       // tile lists
+           + 64 * GT_COMPUTE_WAVES                                        // tile lists
+           + sizeof(double) * 3 * 16 * 17;                                // chase variant: factorised tile + its two inversion images
 }
 
 __device__ inline double gt_refined_rcp(double p)
@@ -71,8 +72,21 @@ __device__ inline double gt_readlane(double v, int lane)
     return x.d;
 }
 
-__global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void getrf_tiled_f64_kernel(
-    const GetrfTaskD *__restrict__ tasks, int nb, unsigned long long *flop_counter, unsigned long long *dbg)
+// stores of what another workgroup reads WHILE this kernel runs (CHASE: the dense solves of the level start on panel p as soon
+// as this factorisation has published it -- pg_hip_platform.hip, getrf_trsm_chase_kernel): `sc1`, the producer half of the
+// hand-off MI355X_MICROARCH.md tabulates (sc1 stores, every storing wave waits vmcnt(0), one lane stores the flag sc1 behind a
+// workgroup barrier; the consumer polls the flag and loads the bytes sc1)
+template <bool CHASE>
+__device__ __forceinline__ void gt_publish(double *p, double v)
+{
+    if (CHASE)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+template <bool CHASE>
+__device__ __forceinline__ void getrf_tiled_body(const GetrfTaskD &T, int nb, unsigned long long *flop_counter, unsigned long long *dbg, unsigned *progress)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int ldp = nb + 2;
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     unsigned *smap = sUrp + nb + 1; // smap[tj] bit ti: tile (ti, tj) holds pattern entries
     unsigned *flags = smap + 16;    // [0] diagonal tile published, [1] tile factorised, [2] priority tiles in the images
     unsigned char *tlist = reinterpret_cast<unsigned char *>(flags + 4); // per compute wavefront: its tiles of the current step (ti << 4 | tj)
-    const GetrfTaskD T = tasks[blockIdx.x];
+    double *Tk = reinterpret_cast<double *>(tlist + 64 * GT_COMPUTE_WAVES); // CHASE: the tile factorised last, [row][17]; then [plain, reversed][16][17]
     double *__restrict__ D = reinterpret_cast<double *>(T.dense);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -139,7 +153,13 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     __syncthreads();
     // the image is a mirror: the dense solves of this level skip structurally empty factor tiles by this map
-    if (T.invert_tiles && tid < 16)
+    if (CHASE)
+    {
+        if (T.invert_tiles && tid < 8)
+            __hip_atomic_store(reinterpret_cast<unsigned *>(D + (size_t)nb * nb) + tid, (smap[2 * tid] & 0xFFFFu) | (smap[2 * tid + 1] << 16), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    else if (T.invert_tiles && tid < 16)
         reinterpret_cast<unsigned short *>(D + (size_t)nb * nb)[tid] = (unsigned short)smap[tid];
     GETRF_STAMP(0)
 
@@ -179,6 +199,55 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const unsigned rf = ((unsigned)l15 * (unsigned)nb + (unsigned)l4) * 8u; // row form:    register g of lane l is (r0 + l4 + 4g, c0 + l15)
     auto gd = [&](unsigned byteoff) -> double &
     { return *reinterpret_cast<double *>(reinterpret_cast<char *>(D) + byteoff); };
+    // inverse of one triangular factor of diagonal tile pt by a quarter wavefront (lane groups 0 / 2: U via the index-reversed
+    // image M2[1], groups 1 / 3: L via the plain image M2[0]), written over the tile in the image
+    auto invert_quarter = [&](const double *M2, int pt)
+    {
+        const int grp = (lane >> 4) & 1, c = l15;
+        const double *M = M2 + (grp ? 0 : 1) * 272;
+        const int cc = grp ? c : 15 - c;
+        double z[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            double s0 = (r == cc) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < r; k++)
+            {
+                if (k & 1)
+                    s1 = __builtin_fma(-M[r * 17 + k], z[k], s1);
+                else
+                    s0 = __builtin_fma(-M[r * 17 + k], z[k], s0);
+            }
+            z[r] = grp ? s0 + s1 : (s0 + s1) * rd_all[pt * 16 + 15 - r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int row = grp ? r : 15 - r;
+            if (grp ? (row > c) : (row <= c))
+                gt_publish<CHASE>(&D[(size_t)(16 * pt + c) * nb + 16 * pt + row], z[r]);
+        }
+    };
+    // CHASE, factorisation wavefront: the tile it factorised last (kept in Tk) -> both inversion images -> inverses into the image
+    auto invert_kept_tile = [&](int pt)
+    {
+        double v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            v4[u] = Tk[((lane + 64 * u) & 15) * 17 + ((lane + 64 * u) >> 4)]; // entry (rr, cc) of the tile, e = cc << 4 | rr
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int e = lane + 64 * u, cc = e >> 4, rr = e & 15;
+            Tk[272 + rr * 17 + cc] = v4[u];
+            Tk[2 * 272 + (15 - rr) * 17 + (15 - cc)] = v4[u];
+        }
+        wave_lds_fence();
+        if (lane < 32)
+            invert_quarter(Tk + 272, pt);
+    };
 
     // phase stamps (PANGULU_HIP_DEBUG_GETRF): block 0 only; slots 1..4 by compute wavefront 0, slot 7 by the factorisation wavefront
     unsigned long long ph_ = 0;
@@ -205,6 +274,8 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if (wave == GT_COMPUTE_WAVES)
         {
             // ---- factorisation wavefront: LU of the diagonal tile (it, it) ------------------------------------------
+            if (CHASE && it > 0 && T.invert_tiles)
+                invert_kept_tile(it - 1); // (while the owner of tile (it, it) is still updating it)
             wait_flag(0, (unsigned)it + 1);
             if (dbg)
                 ph_ = __builtin_amdgcn_s_memtime();
@@ -245,6 +316,12 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int c = 0; c < 16; c++)
                     Td[lane][c] = x[c];
+                if (CHASE)
+                {
+#pragma unroll
+                    for (int c = 0; c < 16; c++)
+                        Tk[lane * 17 + c] = x[c];
+                }
             }
             post_flag(1, false, (unsigned)it + 1);
             GT_PHASE(7)
@@ -456,7 +533,7 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int c = 0; c < 16; c++)
                 {
                     Pn[c * ldp + r] = x[c];
-                    gd((unsigned)((k0 + c) * nb + r) * 8u) = x[c];
+                    gt_publish<CHASE>(&gd((unsigned)((k0 + c) * nb + r) * 8u), x[c]);
                 }
             }
         }
@@ -478,9 +555,18 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                             s[rr] = __builtin_fma(-Td[rr][kk], s[kk], s[rr]);
                 }
                 double2 *dst = reinterpret_cast<double2 *>(D + (size_t)c * nb + k0);
+                if (CHASE)
+                {
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    dst[q] = make_double2(s[2 * q], s[2 * q + 1]);
+                    for (int k = 0; k < 16; k++)
+                        gt_publish<true>(D + (size_t)c * nb + k0 + k, s[k]);
+                }
+                else
+                {
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        dst[q] = make_double2(s[2 * q], s[2 * q + 1]);
+                }
 #pragma unroll
                 for (int k = 0; k < 16; k++)
                     Sn[k * ldp + c] = s[k];
@@ -490,7 +576,11 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         {
             GT_PHASE(4)
         }
+        if (CHASE)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (every storing wave, before the word that announces the stores)
         __syncthreads(); // images of panel `it` complete; everyone is done with the images of panel it-1
+        if (CHASE && tid == 0 && it > 0)
+            __hip_atomic_store(progress, (unsigned)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // panels < it: factors and tile inverses are in memory
     }
     GETRF_STAMP(5)
 
@@ -548,7 +638,17 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
     __syncthreads();
-    if (T.invert_tiles)
+    if (CHASE)
+    {
+        // the last tile's inverses, then the final word: every panel is there
+        if (wave == GT_COMPUTE_WAVES && T.invert_tiles)
+            invert_kept_tile(nt - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(progress, (unsigned)nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    else if (T.invert_tiles)
     {
         // The dense TSTRF/GESSM of this level want the INVERSES of the diagonal tiles in the image (U11^-1 on and above
         // the diagonal, L11^-1 below: pg_hip_trsm_dense.h).  One pass: every wavefront takes two tiles, a quarter
@@ -566,37 +666,20 @@ __global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
         wave_lds_fence();
-        const int t = lane >> 5, grp = (lane >> 4) & 1, c = l15, pt = 2 * wave + t;
+        const int t = lane >> 5, pt = 2 * wave + t;
         if (pt < nt)
-        {
-            const double *M = Tw + (t * 2 + (grp ? 0 : 1)) * 272;
-            const int cc = grp ? c : 15 - c;
-            double z[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                double s0 = (r == cc) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < r; k++)
-                {
-                    if (k & 1)
-                        s1 = __builtin_fma(-M[r * 17 + k], z[k], s1);
-                    else
-                        s0 = __builtin_fma(-M[r * 17 + k], z[k], s0);
-                }
-                z[r] = grp ? s0 + s1 : (s0 + s1) * rd_all[pt * 16 + 15 - r];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int row = grp ? r : 15 - r;
-                if (grp ? (row > c) : (row <= c))
-                    D[(size_t)(16 * pt + c) * nb + 16 * pt + row] = z[r];
-            }
-        }
+            invert_quarter(Tw + (size_t)t * 2 * 272, pt);
     }
     GETRF_STAMP(6)
     ops = wave_sum(ops);
     if (lane == 0 && ops)
         atomicAdd(flop_counter, ops);
+}
+
+
+__global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void getrf_tiled_f64_kernel(
+    const GetrfTaskD *__restrict__ tasks, int nb, unsigned long long *flop_counter, unsigned long long *dbg)
+{
+    const GetrfTaskD T = tasks[blockIdx.x];
+    getrf_tiled_body<false>(T, nb, flop_counter, dbg, nullptr);
 }

@@ -1473,6 +1473,49 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         atomicAdd(flop_counter, ops);
 }
 #include "pg_hip_getrf_tiled.h"
+
+// -----------------------------------------------------------------------------------------------------------------
+// GETRF of a level's diagonal blocks and the dense TSTRF/GESSM against them in ONE launch (the reference runs them as
+// dependent tasks one behind the other, src/pangulu_numeric.c:655-769; near the root of the elimination tree that chain of
+// two ~200 us kernels per level IS the factorisation).  Workgroups 0 .. ngetrf-1 factorise (they are dispatched first: a
+// launch hands out its workgroups in index order), every other workgroup solves two (task, 64-wide slab) items, one per
+// half of its eight wavefronts, and each wavefront starts panel p of its strip when the factorisation of its diagonal
+// block has published panel p: the solves end one or two panel steps behind the factorisation instead of starting there.
+// Hand-off: `sc1` stores + `sc1` loads + one progress word per diagonal block (pg_hip_getrf_tiled.h, gt_publish).
+// MEASURED (profiles/r03z_chase.log, shell(398), one box): correct -- same factors, residual, factor check -- and NOT faster:
+// a two-in-one launch takes 363 us where the lone factorisation takes 205-215 and the level's few dense solves about 100
+// behind it (the factorisation pays for the hand-off: a vmcnt(0) drain and a flag per panel step, sc1 stores, the tile
+// inverses inside the loop; the solves trail it by a full step and finish their longest panel after it); the factorisation
+// goes from 36.9 to 37.7 / 38.9 / 41.1 ms with at most 1 / 4 / 16 factorisations per chased launch.  OFF by default
+// (PANGULU_HIP_CHASE=1, PANGULU_HIP_CHASE_MAX_GETRF); kept with its parity test as the hand-off mechanism a cheaper
+// producer side could reuse.
+// -----------------------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(GT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void getrf_trsm_chase_kernel(
+    const GetrfTaskD *__restrict__ gtasks, unsigned ngetrf, unsigned *__restrict__ progress, unsigned long long *flop_counter,
+    const TrsmDenseTaskD *__restrict__ ttasks, const u32 *__restrict__ work, unsigned nwork)
+{
+    // (both roles inlined: as called functions they were slower still, 457 against 363 us per launch on shell(398))
+    if (blockIdx.x < ngetrf)
+    {
+        const GetrfTaskD T = gtasks[blockIdx.x];
+        getrf_tiled_body<true>(T, NP * 16, flop_counter, nullptr, progress + blockIdx.x);
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned w = (blockIdx.x - ngetrf) * 2u + (unsigned)(wave >> 2);
+    if (w >= nwork)
+        return;
+    const u32 item = work[w];
+    const TrsmDenseTaskD T = ttasks[item >> 2];
+    trsm_dense_direct_body<NP, true>(T, (int)(item & 3u), wave & 3, (int)(threadIdx.x & 63));
+}
+
+__global__ void zero_words_kernel(unsigned *p, unsigned n)
+{
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+        p[i] = 0u;
+}
 #endif
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1830,6 +1873,9 @@ struct Backend
     double mfma_flops_executed = 0;
     // resources
     Ring ring;
+    unsigned *d_progress = nullptr;        // progress words of the GETRF -> dense-solve chase (one per held factorisation task)
+    size_t progress_next = 0;
+    unsigned long long chase_launches = 0, chase_solves = 0;
     unsigned long long *d_flops = nullptr; // [6]
     val_t *getrf_scratch = nullptr;
     int getrf_scratch_slots = 0;
@@ -1873,6 +1919,35 @@ struct Recorder
 };
 Recorder REC;
 
+// GETRF -> dense-solve chase (recorded schedules only).  A launch of the tiled GETRF on the main stream is HELD until the next
+// platform call: if that call is the level's dense TSTRF/GESSM against exactly these diagonal blocks, both go out as ONE launch
+// (getrf_trsm_chase_kernel: the solves of panel p start when the factorisation has published panel p); anything else launches
+// the held factorisation first, as it was.  `hold` keeps the preparatory launches of launch_trsm (densify of the panel blocks:
+// independent of the factorisation) from doing that.
+#define PROGRESS_WORDS 8192
+struct PendingGetrf
+{
+    bool active = false, hold = false;
+    int nb = 0;
+    size_t take = 0;
+    const void *d_tasks = nullptr;       // GetrfTaskD * (device view)
+    unsigned *d_progress = nullptr;      // one word per task
+    std::vector<const double *> images;  // LU images the held factorisation will leave, in task order
+    std::function<void()> plain;         // the launch as it would have been
+    std::function<void()> post;          // what follows the launch (record-stream fork, deferred sparsify jobs, statistics)
+};
+PendingGetrf PEND;
+inline void flush_pending_getrf()
+{
+    if (!PEND.active || PEND.hold)
+        return;
+    PEND.active = false;
+    PEND.plain();
+    PEND.post();
+    PEND.plain = nullptr;
+    PEND.post = nullptr;
+}
+
 // a kernel argument as the replay will pass it: pointers into a recorded descriptor segment move to the segment's HBM twin
 template <class T>
 inline T rec_xl(T v)
@@ -1890,6 +1965,7 @@ inline T rec_xl(T v)
 template <class K, class... A>
 inline void pg_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, A... args)
 {
+    flush_pending_getrf();
     if (REC.mode != 0)
     {
         auto targs = std::make_tuple(rec_xl(args)...);
@@ -1906,6 +1982,7 @@ inline void pg_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t
 
 inline void pg_event_record(hipEvent_t e, hipStream_t s)
 {
+    flush_pending_getrf();
     if (REC.mode != 0)
         REC.ops.emplace_back([e, s]() { HIP_CHECK(hipEventRecord(e, s)); });
     if (REC.mode != 2)
@@ -1913,6 +1990,7 @@ inline void pg_event_record(hipEvent_t e, hipStream_t s)
 }
 inline void pg_stream_wait(hipStream_t s, hipEvent_t e)
 {
+    flush_pending_getrf();
     if (REC.mode != 0)
         REC.ops.emplace_back([e, s]() { HIP_CHECK(hipStreamWaitEvent(s, e, 0)); });
     if (REC.mode != 2)
@@ -2755,6 +2833,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
 {
     HostTimer ht(1);
     size_t i = 0;
+    PEND.hold = PEND.active; // (a held factorisation waits until this call knows whether its solves can chase it)
     while (i < n)
     {
         Segment seg = acquire_segment();
@@ -2919,6 +2998,21 @@ void launch_trsm(int nb, task_t **list, size_t n)
 #endif
         commit_segment(seg);
 #if defined(PG_DENSE_PANELS)
+        // chase: every solve of this call is a dense one against an image the held factorisation is going to leave
+        static const bool direct_solves = getenv("PANGULU_HIP_TRSM_DIRECT") ? atoi(getenv("PANGULU_HIP_TRSM_DIRECT")) != 0 : true;
+        bool chase = PEND.active && PEND.hold && i == 0 && take == n && ndense > 0 && nsparse == 0 && direct_solves && PEND.nb == nb;
+        for (size_t t = 0; t < ndense && chase; t++)
+        {
+            size_t at = 0;
+            while (at < PEND.images.size() && PEND.images[at] != dtasks[t].lu)
+                at++;
+            chase = at < PEND.images.size();
+            if (chase)
+                dtasks[t].progress = PEND.d_progress + at;
+        }
+        PEND.hold = false;
+        if (!chase)
+            flush_pending_getrf(); // (as it was: the factorisation, then this call's kernels)
         if (ndense && nsparse && B.opt_two_streams)
             pg_event_record(B.ev_fork, B.stream); // mirrors and sparse records are current from here on
 #endif
@@ -2949,7 +3043,33 @@ void launch_trsm(int nb, task_t **list, size_t n)
                     for (int w = 0; w < nb / 64; w++)
                         if ((dlive[t] >> (4 * w)) & 0xFu)
                             dwork[nw++] = (u32)(t << 2) | (u32)w;
-                if (!nw)
+                if (chase)
+                {
+                    // one launch: the held factorisation's workgroups first, then two (task, slab) items per workgroup
+                    const size_t lds_t = gt_lds_bytes(nb);
+                    static size_t c_allowed = 0;
+                    if (lds_t > c_allowed)
+                    {
+                        HIP_CHECK(hipFuncSetAttribute((const void *)getrf_trsm_chase_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+                        HIP_CHECK(hipFuncSetAttribute((const void *)getrf_trsm_chase_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+                        c_allowed = lds_t;
+                    }
+                    PendingGetrf P = std::move(PEND);
+                    PEND = PendingGetrf();
+                    const unsigned ng_ = (unsigned)P.take, nwg = ng_ + (unsigned)((nw + 1) / 2);
+                    const GetrfTaskD *gt_ = static_cast<const GetrfTaskD *>(P.d_tasks);
+                    PG_LAUNCH(zero_words_kernel, dim3(1), dim3(256), 0, ds, P.d_progress, ng_);
+                    if (nb == 256)
+                        PG_LAUNCH(getrf_trsm_chase_kernel<16>, dim3(nwg), dim3(GT_THREADS), lds_t, ds, gt_, ng_, P.d_progress, B.d_flops + 1, (const TrsmDenseTaskD *)d_dtasks,
+                                  (const u32 *)d_dwork, (unsigned)nw);
+                    else
+                        PG_LAUNCH(getrf_trsm_chase_kernel<8>, dim3(nwg), dim3(GT_THREADS), lds_t, ds, gt_, ng_, P.d_progress, B.d_flops + 1, (const TrsmDenseTaskD *)d_dtasks,
+                                  (const u32 *)d_dwork, (unsigned)nw);
+                    P.post();
+                    B.chase_launches++;
+                    B.chase_solves += ndense;
+                }
+                else if (!nw)
                     ;
                 else if (direct && nb == 256)
                     PG_LAUNCH(trsm_dense_direct_f64_kernel<16>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, d_dwork);
@@ -3002,6 +3122,8 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 mirror_to_host(list[i + k]->opdst, nb);
         i += take;
     }
+    PEND.hold = false;
+    flush_pending_getrf(); // (nothing stays held past the call that could have used it)
 }
 
 // ---- GETRF -------------------------------------------------------------------------------------------------------
@@ -3043,6 +3165,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
 #if defined(PG_DENSE_PANELS)
         std::vector<double *> lu_images; // dense images that will hold L\\U after this launch
         std::vector<MirrorJobD> deferred; // their sparse records are written by sparsify jobs on the records stream
+        bool held = false;                // the launch waits for the next platform call (PendingGetrf)
 #endif
         double by = 0;
         for (size_t k = 0; k < take; k++)
@@ -3153,8 +3276,39 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         HIP_CHECK(hipFuncSetAttribute((const void *)getrf_tiled_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
                         t_allowed = lds_t;
                     }
-                    PG_LAUNCH(getrf_tiled_f64_kernel, dim3((unsigned)take), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, B.d_flops + 1,
-                                       debug_stamps ? B.d_flops + 8 : nullptr);
+                    // (held for the chase when it could serve the dense solves of its level: see PendingGetrf)
+                    static const bool chase_on = getenv("PANGULU_HIP_CHASE") && atoi(getenv("PANGULU_HIP_CHASE")) != 0; // (off by default: see getrf_trsm_chase_kernel)
+                    bool all_images = !lu_images.empty() && lu_images.size() == take;
+                    for (size_t k = 0; k < take && all_images; k++)
+                        all_images = tasks[k].invert_tiles && tasks[k].defer_gather;
+                    // (near the root only: a level with many diagonal blocks is bound by throughput, and there the two-in-one launch costs
+                    //  more than the chain it removes -- PANGULU_HIP_CHASE_MAX_GETRF)
+                    static const size_t chase_max = getenv("PANGULU_HIP_CHASE_MAX_GETRF") ? (size_t)atol(getenv("PANGULU_HIP_CHASE_MAX_GETRF")) : 4;
+                    if (chase_on && REC.mode != 0 && ks == B.stream && i == 0 && take == n && take <= chase_max && all_images && !debug_stamps && !B.opt_profile &&
+                        !B.opt_host_mirror && (nb == 128 || nb == 256))
+                    {
+                        held = true;
+                        PEND.nb = nb;
+                        PEND.take = take;
+                        PEND.d_tasks = d_tasks;
+                        PEND.images.assign(lu_images.begin(), lu_images.end());
+                        if (!B.d_progress)
+                        {
+                            HIP_CHECK(hipMalloc((void **)&B.d_progress, sizeof(unsigned) * PROGRESS_WORDS));
+                            HIP_CHECK(hipMemset(B.d_progress, 0, sizeof(unsigned) * PROGRESS_WORDS));
+                        }
+                        if (B.progress_next + take > PROGRESS_WORDS)
+                            B.progress_next = 0;
+                        PEND.d_progress = B.d_progress + B.progress_next;
+                        B.progress_next += take;
+                        unsigned long long *fc = B.d_flops + 1;
+                        const unsigned ntake = (unsigned)take;
+                        PEND.plain = [=]()
+                        { PG_LAUNCH(getrf_tiled_f64_kernel, dim3(ntake), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, fc, (unsigned long long *)nullptr); };
+                    }
+                    else
+                        PG_LAUNCH(getrf_tiled_f64_kernel, dim3((unsigned)take), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, B.d_flops + 1,
+                                           debug_stamps ? B.d_flops + 8 : nullptr);
                 }
                 else if (lookahead_kernel)
                 {
@@ -3184,6 +3338,23 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             HIP_CHECK(hipGetLastError());
         }
 #if defined(PG_DENSE_PANELS)
+        if (held)
+        {
+            // (everything that follows the launch follows it when it is made: PendingGetrf)
+            PEND.post = [=]() mutable
+            {
+                if (!deferred.empty())
+                    pg_event_record(B.ev_rec_fork, ks); // behind the factorisation
+                release_pending_segments(ks);
+                if (!deferred.empty())
+                    flush_mirror_jobs(nb, deferred, false, true, nullptr, true);
+                B.stats.launches[1]++;
+                B.stats.tasks[1] += take;
+                B.stats.alg_bytes[1] += by;
+            };
+            PEND.active = true;
+            return; // (take == n)
+        }
         if (!deferred.empty())
             pg_event_record(B.ev_rec_fork, ks); // behind the factorisation
 #endif
@@ -3250,6 +3421,8 @@ void process_run(int nb, task_t *tasks, size_t n, std::vector<task_t *> &getrf, 
             exit(EXIT_FAILURE);
         }
     }
+    if (!(getrf.empty() && ssssm.empty() && !trsm.empty()))
+        flush_pending_getrf(); // (only the solves of its own level may chase a held factorisation)
     if (!B.opt_assume_independent && ssssm.size() > 1)
     {
         // updates of one destination must be adjacent (they share one LDS accumulator pass)
@@ -3329,6 +3502,7 @@ extern "C"
     void pangulu_platform_0201001_synchronize(void)
     {
         ensure_ready();
+        flush_pending_getrf();
         join_records(B.stream);
         join_background(B.stream);
         HIP_CHECK(hipStreamSynchronize(B.stream));
@@ -3337,6 +3511,7 @@ extern "C"
     void pangulu_platform_0201001_memset(void *s, int c, size_t n)
     {
         ensure_ready();
+        flush_pending_getrf();
         HIP_CHECK(hipMemsetAsync(s, c, n, B.stream));
         HIP_CHECK(hipStreamSynchronize(B.stream));
     }
@@ -3366,6 +3541,7 @@ extern "C"
     void pangulu_platform_0201001_memcpy(void *dst, const void *src, size_t count, unsigned int kind)
     {
         ensure_ready();
+        flush_pending_getrf();
         // ordered after everything queued on the back-end stream, complete on return
         join_records(B.stream);
         join_background(B.stream);
@@ -3376,6 +3552,7 @@ extern "C"
     void pangulu_platform_0201001_memcpy_async(void *dst, const void *src, size_t count, unsigned int kind, void *stream)
     {
         ensure_ready();
+        flush_pending_getrf();
         // stream == NULL is what the reference host passes from its receive thread
         // (src/pangulu_communication.c:1850,1880): use the back-end stream so later kernels are ordered behind it
         hipStream_t s = stream ? (hipStream_t)stream : B.stream;
@@ -3391,6 +3568,7 @@ extern "C"
 
     void pangulu_platform_0201001_free(void *devptr)
     {
+        flush_pending_getrf();
         if (!devptr)
             return;
         hipPointerAttribute_t attr;
@@ -3579,6 +3757,7 @@ extern "C"
 
     void pangulu_platform_0201001_ssssm_batched(pangulu_inblock_idx nb, pangulu_uint64_t ntask, pangulu_task_t *tasks)
     {
+        flush_pending_getrf();
         // as the reference's dispatcher does (src/pangulu_kernel_interface.c:302), kernel ids in the array decide
         pangulu_platform_0201001_hybrid_batched(nb, ntask, tasks);
     }
@@ -3621,6 +3800,7 @@ extern "C"
     void pangulu_platform_0201001_spmv(pangulu_inblock_idx nb, pangulu_storage_slot_t *a, calculate_type *x, calculate_type *y)
     {
         ensure_ready();
+        flush_pending_getrf();
         join_records(B.stream);
         hipLaunchKernelGGL(spmv_kernel, dim3(1), dim3(256), 0, B.stream, (int)nb, a->d_columnpointer, a->d_rowindex, a->d_value, x, y);
         HIP_CHECK(hipGetLastError());
@@ -3629,6 +3809,7 @@ extern "C"
     void pangulu_platform_0201001_vecadd(pangulu_int64_t length, calculate_type *bval, calculate_type *xval)
     {
         ensure_ready();
+        flush_pending_getrf();
         if (length <= 0)
             return;
         hipLaunchKernelGGL(vecadd_kernel, dim3((unsigned)((length + 255) / 256)), dim3(256), 0, B.stream, (long long)length, bval, xval);
@@ -3638,6 +3819,7 @@ extern "C"
     void pangulu_platform_0201001_sptrsv(pangulu_inblock_idx nb, pangulu_storage_slot_t *s, calculate_type *xval, pangulu_int64_t uplo)
     {
         ensure_ready();
+        flush_pending_getrf();
         size_t lds = sizeof(val_t) * (size_t)nb;
         join_records(B.stream);
         if (uplo == PANGULU_LOWER)
@@ -3652,6 +3834,7 @@ extern "C"
     void *pangulu_platform_0201001_marker_record(void)
     {
         ensure_ready();
+        flush_pending_getrf();
         std::lock_guard<std::mutex> g(B.mutex);
         HIP_CHECK(hipSetDevice(B.device));
         static std::vector<hipEvent_t> ring;
@@ -3683,6 +3866,7 @@ extern "C"
 
     void pangulu_platform_0201001_marker_wait(void *marker)
     {
+        flush_pending_getrf();
         HIP_CHECK(hipSetDevice(B.device));
         HIP_CHECK(hipEventSynchronize((hipEvent_t)marker));
     }
@@ -3690,6 +3874,7 @@ extern "C"
     void pangulu_platform_0201001_prepare_diag(pangulu_inblock_idx nb, pangulu_storage_slot_t *diag)
     {
         ensure_ready();
+        flush_pending_getrf();
         std::lock_guard<std::mutex> g(B.mutex);
         slot_t *up, *lo;
         diag_halves(diag, &up, &lo);
@@ -3698,6 +3883,7 @@ extern "C"
 
     void pangulu_platform_0201001_prepare_blocks(pangulu_inblock_idx nb, pangulu_uint64_t nslot, pangulu_storage_slot_t **slots)
     {
+        flush_pending_getrf();
 #if defined(PG_DENSE_UPDATES)
         if (nb > 256 || nb % 16 != 0 || nslot == 0)
             return;
@@ -3850,6 +4036,7 @@ extern "C"
                                              const pangulu_exblock_idx *blk_bcol, calculate_type *x, pangulu_uint64_t xlen)
     {
         ensure_ready();
+        flush_pending_getrf();
         std::lock_guard<std::mutex> g(B.mutex);
         HIP_CHECK(hipSetDevice(B.device));
         join_records(B.stream); // the sparse records of finished blocks are written on the records stream
@@ -3920,6 +4107,7 @@ extern "C"
                                                  const calculate_type *x, calculate_type *y, pangulu_uint64_t xlen)
     {
         ensure_ready();
+        flush_pending_getrf();
         std::lock_guard<std::mutex> g(B.mutex);
         HIP_CHECK(hipSetDevice(B.device));
         join_records(B.stream); // the sparse records of finished blocks are written on the records stream
@@ -3988,6 +4176,7 @@ extern "C"
     // and the eager host mirror, whose copies and event pairs are not part of the list.
     long long pangulu_platform_0201001_schedule(int cmd, const void *owner)
     {
+        flush_pending_getrf();
         ensure_ready();
         std::lock_guard<std::mutex> g(B.mutex);
         HIP_CHECK(hipSetDevice(B.device));
@@ -4046,6 +4235,7 @@ extern "C"
 
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset)
     {
+        flush_pending_getrf();
         if (reset && getenv("PANGULU_HIP_HOST_TIMING"))
         {
             fprintf(stderr, "[PanguLU-AMD] host seconds in the back-end: calls %.4f (ssssm %.4f, trsm %.4f, getrf %.4f, mirror jobs %.4f, staging waits %.4f)\n",
@@ -4075,6 +4265,8 @@ extern "C"
         B.stats.mfma_flops_executed = 8192.0 * (double)f[6]; // 16 x 16 x 16 products counted by the MFMA update kernels
         B.stats.ssssm_front_workgroups = B.front_workgroups;
         B.stats.ssssm_general_workgroups = B.general_workgroups;
+        B.stats.chase_launches = B.chase_launches;
+        B.stats.chase_solves = B.chase_solves;
         if (out)
             *out = B.stats;
         if (reset)
@@ -4082,6 +4274,7 @@ extern "C"
             memset(&B.stats, 0, sizeof(B.stats));
             B.mfma_flops_executed = 0;
             B.front_workgroups = B.general_workgroups = 0;
+            B.chase_launches = B.chase_solves = 0;
             HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(f)));
         }
     }

@@ -23,6 +23,7 @@ struct TrsmDenseTaskD
     u32 is_tstrf;
     u32 lu_map; // 1: the occupancy map behind `lu` describes the factorised block (written by getrf_tiled_f64_kernel / densify):
                 // products with structurally empty factor tiles are skipped; 0: every tile of the factor counts as live
+    const unsigned *progress; // chase launches only (getrf_trsm_chase_kernel): panels of `lu` the factorisation has published so far
 };
 
 // one wavefront per 16 x 16 diagonal tile: lane c < 16 computes column c of inv(U_pp) (back substitution) and of
@@ -336,17 +337,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
 //   TSTRF  A'[i = c][k] = U(16q + k, 16p + c)  = LU[(16p + c) nb + 16q + k]
 //   GESSM  A [i = r][k] = L(16p + r, 16q + k)  = LU[(16q + k) nb + 16p + r]
 // -----------------------------------------------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_direct_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks, const u32 *__restrict__ work)
+// CHASE: the image is being factorised by another workgroup of the same launch (getrf_trsm_chase_kernel): panel p of the solve
+// starts when the factorisation has published panel p (T.progress > p), and everything read from the image -- factor tiles,
+// inverted diagonal tiles, occupancy map -- is read `sc1` (the consumer half of the hand-off in pg_hip_getrf_tiled.h)
+template <int NP, bool CHASE>
+__device__ __forceinline__ void trsm_dense_direct_body(const TrsmDenseTaskD &T, int slab, int wave, int lane)
 {
     constexpr int nb = NP * 16;
-    const int slabs = nb / 64;
-    // (task, slab) from the launch's work list: slabs without pattern entries are left out
-    const u32 item = work[logical_block_id((unsigned)slabs)];
-    const unsigned bid = (item >> 2) * (unsigned)slabs + (item & 3u);
-    const TrsmDenseTaskD T = tasks[bid / slabs];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int o0 = (bid % slabs) * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int o0 = slab * 64 + wave * 16; // this wavefront's 16 rows (TSTRF) / columns (GESSM)
+    auto wait_for_panels = [&](unsigned n)
+    {
+        if (!CHASE)
+            return;
+        unsigned spins = 0;
+        while (__hip_atomic_load(T.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n)
+        {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) // (seconds: a factorisation that never publishes must abort the launch, not hang the device)
+                __builtin_trap();
+        }
+    };
     double *__restrict__ Bm = T.b;
     const double *__restrict__ LU = T.lu;
     const bool tstrf = T.is_tstrf != 0;
@@ -372,9 +383,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
     const bool use_fmap = T.lu_map != 0;
     // (the map words as scalars: the bit tests below then cost no vector instructions)
     unsigned fm[NP];
+    wait_for_panels(1u); // (the factorisation writes the map before its first panel)
 #pragma unroll
     for (int c = 0; c < NP; c++)
-        fm[c] = use_fmap ? (unsigned)__builtin_amdgcn_readfirstlane((int)fmap[c]) : 0xFFFFu;
+    {
+        if (CHASE)
+        {
+            const unsigned w2 = use_fmap ? __hip_atomic_load(reinterpret_cast<const unsigned *>(fmap) + (c >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+            fm[c] = (unsigned)__builtin_amdgcn_readfirstlane((int)((w2 >> (16 * (c & 1))) & 0xFFFFu));
+        }
+        else
+            fm[c] = use_fmap ? (unsigned)__builtin_amdgcn_readfirstlane((int)fmap[c]) : 0xFFFFu;
+    }
     // factor tile (q, p): the four k-quarters of this lane's A operand.  Addresses are scalar bases (tile, k-quarter) plus one
     // constant lane offset: an f64 MFMA holds the SIMD's vector ALU for its 64 cycles, so vector address arithmetic is paid
     // for in matrix-pipe time (pg_hip_dense.h, dg_scalar_base)
@@ -385,7 +405,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
     {                                                                                                               \
         const gbytes ab_ = (gbytes)LU + (tstrf ? (size_t)(16 * (p_)) * nb + 16 * (q_) : (size_t)(16 * (q_)) * nb + 16 * (p_)) * 8; \
         _Pragma("unroll") for (int kq_ = 0; kq_ < 4; kq_++)                                                         \
-            (dst_)[kq_] = *(gdouble_c)(dg_scalar_base(ab_ + (tstrf ? (size_t)(4 * kq_) : (size_t)(4 * kq_) * nb) * 8) + dg_lane_offset(a_voff)); \
+        {                                                                                                           \
+            const gdouble_c src_ = (gdouble_c)(dg_scalar_base(ab_ + (tstrf ? (size_t)(4 * kq_) : (size_t)(4 * kq_) * nb) * 8) + dg_lane_offset(a_voff)); \
+            (dst_)[kq_] = CHASE ? __hip_atomic_load(src_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src_;      \
+        }                                                                                                           \
     }
     // element g of this lane in solution tile p (TSTRF: X^T tiles, GESSM: X tiles; see the header)
     const unsigned x_voff = (unsigned)(tstrf ? l4 * nb + l15 : l15 * nb + l4) * 8u;
@@ -450,7 +473,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
         unsigned lq;
         TRSM_LIVE_Q(lq, p)
         if (!fetched)
+        {
+            wait_for_panels((unsigned)p + 1u);
             TRSM_FIRST_LOADS(p, lq, st)
+        }
         v4f64 part[4];
         part[0] = xs[p];
         part[1] = part[2] = part[3] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -481,6 +507,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
         {
             unsigned lqn;
             TRSM_LIVE_Q(lqn, p + 1)
+            wait_for_panels((unsigned)p + 2u);
             TRSM_FIRST_LOADS(p + 1, lqn, set0)
             fetched = true;
         }
@@ -514,6 +541,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 
             TRSM_X(p, g) = xs[p][g];
     }
 #undef TRSM_X
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP >= 16 ? 2 : 3))) void trsm_dense_direct_f64_kernel(const TrsmDenseTaskD *__restrict__ tasks, const u32 *__restrict__ work)
+{
+    constexpr int slabs = NP * 16 / 64;
+    // (task, slab) from the launch's work list: slabs without pattern entries are left out
+    const u32 item = work[logical_block_id((unsigned)slabs)];
+    const TrsmDenseTaskD T = tasks[item >> 2];
+    trsm_dense_direct_body<NP, false>(T, (int)(item & 3u), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63));
 }
 
 // structural flops of the solves that ran on the dense path (src/pangulu_kernel_interface.c:84-159): one workgroup

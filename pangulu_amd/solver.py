@@ -212,4 +212,6 @@ def hip_stats(h_or_lib, reset=False):
     out["tstrf"]["dense_path_tasks"] = int(st.trsm_dense_tasks)  # TSTRF + GESSM tasks solved on the matrix cores
     out["ssssm_dense_mfma"]["front_workgroups"] = int(st.ssssm_front_workgroups)      # dense-front kernel (pg_hip_front.h)
     out["ssssm_dense_mfma"]["general_workgroups"] = int(st.ssssm_general_workgroups)  # general MFMA kernel (pg_hip_dense.h)
+    out["getrf"]["chase_launches"] = int(st.chase_launches)  # launches that carried a level's factorisations and its dense solves
+    out["tstrf"]["chase_solves"] = int(st.chase_solves)
     return out

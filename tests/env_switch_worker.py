@@ -23,7 +23,7 @@ def main():
         "residual": gpu["residual"], "lu_check": lu_check(mat, gpu), "factor_check_device": gpu["factor_check"],
         "flop_counted": sum(v["flops"] for v in st.values()), "flop": gpu["info"]["flop"],
         "dense_updates": st["ssssm_dense_mfma"]["tasks"], "dense_solves": st["tstrf"]["dense_path_tasks"],
-        "getrf_launches": st["getrf"]["launches"]}))
+        "getrf_launches": st["getrf"]["launches"], "chase_launches": st["getrf"]["chase_launches"], "chase_solves": st["tstrf"]["chase_solves"]}))
 
 
 if __name__ == "__main__":

@@ -40,6 +40,9 @@ SWITCHES = [
     {"PG_TEST_HIP_OPTIONS": "6=0,3=0", "HSA_ENABLE_INTERRUPT": "0"},
     {"PG_TEST_HIP_OPTIONS": "6=0,3=0,10=0,13=0"},  # ... and bench.py's profile-pass stream layout: everything on one stream
     {"PG_TEST_HIP_OPTIONS": "3=1,10=0,13=0"},      # the profile pass itself
+    # GETRF -> dense-solve chase (off by default): a level's factorisations and its dense solves in one launch
+    {"PANGULU_HIP_CHASE": "1", "PANGULU_HIP_CHASE_MAX_GETRF": "4"},
+    {"PANGULU_HIP_CHASE": "1", "PANGULU_HIP_CHASE_MAX_GETRF": "256", "_matrix": "fem27"},
 ]
 
 
@@ -60,3 +63,5 @@ def test_backend_switch_keeps_parity(env):
     if "6=0" not in env.get("PG_TEST_HIP_OPTIONS", ""):
         assert r["flop_counted"] == r["flop"], r
     assert r["dense_updates"] > 0 and r["dense_solves"] > 0 and r["getrf_launches"] > 0, r
+    if env.get("PANGULU_HIP_CHASE") == "1":
+        assert r["chase_launches"] > 0 and r["chase_solves"] > 0, r
