@@ -253,7 +253,7 @@ bool mirror_is_ahead(slot_t *s)
     return st.brow == s->brow_pos && st.bcol == s->bcol_pos && st.mirror && !st.sparse_current;
 }
 
-#if defined(PG_DENSE_PANELS)
+#if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
 // dense LU image of the diagonal block `half` belongs to, if GETRF left one
 const double *lu_image_of(slot_t *half)
 {
@@ -272,6 +272,8 @@ bool lu_image_has_map(slot_t *half)
     const BlockState *found = MP.blocks.find(block_key(lo));
     return found && found->lu_image && found->lu_map;
 }
+#endif
+#if defined(PG_DENSE_PANELS)
 
 // A diagonal block factorised on another rank has no image here: queue one to be built from the halves that have
 // arrived (pg_hip_trsm_dense.h, half_image_kernel).  Returns the mirror, or nullptr when the pool is exhausted.

@@ -141,6 +141,7 @@ __device__ inline val_t clamp_pivot(val_t p)
 #define PG_DENSE_PANELS 1
 #endif
 #if defined(CALCULATE_TYPE_CR64) || defined(CALCULATE_TYPE_CR32)
+#define PG_COMPLEX_PANELS 1 // GETRF / TSTRF / GESSM of dense-mode blocks on the two-plane mirrors (pg_hip_panels_complex.h)
 #define PG_PLANES 2
 #else
 #define PG_PLANES 1
@@ -516,8 +517,11 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #include "pg_hip_dense.h"
 #include "pg_hip_front.h"
 #endif
-#if defined(PG_DENSE_PANELS)
+#if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
 #include "pg_hip_trsm_dense.h"
+#endif
+#if defined(PG_COMPLEX_PANELS)
+#include "pg_hip_panels_complex.h"
 #endif
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1518,6 +1522,25 @@ __global__ void zero_words_kernel(unsigned *p, unsigned n)
 }
 #endif
 
+#if defined(PG_COMPLEX_PANELS)
+// structural flops of the GETRFs that ran in their mirrors (what the reference counts, src/pangulu_kernel_interface.c:4-82:
+// per column, entries below the diagonal x (1 + 2 x entries right of the diagonal in that row)); one workgroup per block
+__global__ void getrf_flop_count_kernel(const GetrfTaskD *__restrict__ tasks, int nb, unsigned long long *counter)
+{
+    const GetrfTaskD T = tasks[blockIdx.x];
+    unsigned long long ops = 0;
+    for (int c = threadIdx.x; c < nb; c += blockDim.x)
+    {
+        const u32 nl = T.lcp[c + 1] - ptr0(T.lcp, c), nu = T.urp[c + 1] - ptr0(T.urp, c);
+        if (nu > 0)
+            ops += (unsigned long long)nl * (1ull + 2ull * (nu - 1));
+    }
+    ops = wave_sum(ops);
+    if ((threadIdx.x & 63) == 0 && ops)
+        atomicAdd(counter, ops);
+}
+#endif
+
 // -----------------------------------------------------------------------------------------------------------------
 // solve-side kernels (device pointers x, y), semantics of ...0100000.c:435-506
 // -----------------------------------------------------------------------------------------------------------------
@@ -1876,6 +1899,7 @@ struct Backend
     unsigned *d_progress = nullptr;        // progress words of the GETRF -> dense-solve chase (one per held factorisation task)
     size_t progress_next = 0;
     unsigned long long chase_launches = 0, chase_solves = 0;
+    unsigned long long zgetrf_tasks = 0; // complex types: diagonal blocks factorised in their mirrors
     unsigned long long *d_flops = nullptr; // [6]
     val_t *getrf_scratch = nullptr;
     int getrf_scratch_slots = 0;
@@ -2865,6 +2889,12 @@ void launch_trsm(int nb, task_t **list, size_t n)
         std::vector<slot_t *> solved_dense;
         const bool dense_ok = dense_mode_available(nb);
 #endif
+#if defined(PG_COMPLEX_PANELS)
+        static const bool zpanels_on = !(getenv("PANGULU_HIP_COMPLEX_PANELS") && atoi(getenv("PANGULU_HIP_COMPLEX_PANELS")) == 0);
+        std::vector<ZTrsmTaskD> zt; // (block, 64-wide slab) items of the solves that run on mirrors (ztrsm_planes_kernel)
+        std::vector<slot_t *> solved_dense;
+        const bool dense_ok = dense_mode_available(nb);
+#endif
         for (size_t k = 0; k < take; k++)
         {
             if (i + k + PREFETCH_SLOTS_AHEAD < n)
@@ -2949,6 +2979,33 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 }
             }
 #endif
+#if defined(PG_COMPLEX_PANELS)
+            // complex types: the diagonal block was factorised in its mirror (launch_getrf) and the block being solved is well filled
+            // or already lives in its mirror: solve it there, one workgroup per 64-wide slab that holds pattern entries
+            if (zpanels_on && dense_ok && (nb == 128 || nb == 256) && B.opt_trsm_dense_permille <= 1000 && !B.opt_host_mirror)
+            {
+                const double *lu = lu_image_of(half);
+                const bool filled = (u64)nnz_b * 1000ull >= (u64)B.opt_trsm_dense_permille * (u64)nb * (u64)nb;
+                if (lu && (filled || mirror_is_ahead(dst)))
+                {
+                    double *bm = current_mirror(dst, nb);
+                    if (bm)
+                    {
+                        const BlockState *sd = MP.blocks.find(block_key(dst));
+                        const unsigned live = (sd && sd->occ_valid) ? (T.is_tstrf ? sd->occ_rows : sd->occ_cols) : 0xFFFFu;
+                        for (int w = 0; w < nb / 64; w++)
+                            if ((live >> (4 * w)) & 0xFu)
+                                zt.push_back(ZTrsmTaskD{bm, lu, (u32)T.is_tstrf, (u32)w});
+                        // the flop counter wants the CSC view of the block in both cases
+                        T.vptr = dst->d_columnpointer;
+                        T.vidx = dst->d_rowindex;
+                        ftasks[ndense++] = T;
+                        solved_dense.push_back(dst);
+                        dense = true;
+                    }
+                }
+            }
+#endif
             if (!dense)
             {
                 require_sparse(dst, nb); // updates may have been accumulating in the block's mirror
@@ -2996,6 +3053,19 @@ void launch_trsm(int nb, task_t **list, size_t n)
             HIP_CHECK(hipGetLastError());
         }
 #endif
+#if defined(PG_COMPLEX_PANELS)
+        ZTrsmTaskD *d_zt = nullptr;
+        if (!zt.empty())
+        {
+            ZTrsmTaskD *hz = seg.alloc<ZTrsmTaskD>(zt.size(), &d_zt);
+            if (!hz)
+            {
+                fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
+                exit(EXIT_FAILURE);
+            }
+            memcpy(hz, zt.data(), sizeof(ZTrsmTaskD) * zt.size());
+        }
+#endif
         commit_segment(seg);
 #if defined(PG_DENSE_PANELS)
         // chase: every solve of this call is a dense one against an image the held factorisation is going to leave
@@ -3026,6 +3096,19 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 PG_LAUNCH(trsm_sparse_kernel, dim3((unsigned)(nsparse * vblocks)), dim3(TRSM_WAVES * 64), lds, B.stream, d_tasks,
                                    nb, B.d_flops + 2, B.d_flops + 3);
             }
+#if defined(PG_COMPLEX_PANELS)
+            if (!zt.empty())
+            {
+                const size_t lds_z = sizeof(double) * 2 * ZP_PANEL * (size_t)nb;
+                static size_t zt_allowed = 0;
+                if (lds_z > zt_allowed)
+                {
+                    HIP_CHECK(hipFuncSetAttribute((const void *)ztrsm_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_z));
+                    zt_allowed = lds_z;
+                }
+                PG_LAUNCH(ztrsm_planes_kernel, dim3((unsigned)zt.size()), dim3(ZT_THREADS), lds_z, B.stream, (const ZTrsmTaskD *)d_zt, nb);
+            }
+#endif
 #if defined(PG_DENSE_PANELS)
             if (ndense)
             {
@@ -3088,7 +3171,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
 #endif
             HIP_CHECK(hipGetLastError());
         }
-#if defined(PG_DENSE_PANELS)
+#if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
         if (ndense)
         {
             if (B.opt_count_flops)
@@ -3098,7 +3181,7 @@ void launch_trsm(int nb, task_t **list, size_t n)
         }
 #endif
         release_pending_segments();
-#if defined(PG_DENSE_PANELS)
+#if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
         // the solutions live in the mirrors: bring the sparse records (the authoritative form of a finished block) up
         // to date at once; the mirrors stay valid as MFMA operands
         for (slot_t *s : solved_dense)
@@ -3167,6 +3250,15 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
         std::vector<MirrorJobD> deferred; // their sparse records are written by sparsify jobs on the records stream
         bool held = false;                // the launch waits for the next platform call (PendingGetrf)
 #endif
+#if defined(PG_COMPLEX_PANELS)
+        // complex types: diagonal blocks that have a mirror are factorised THERE (zgetrf_planes_kernel), the others by the
+        // pattern-driven kernel; PANGULU_HIP_COMPLEX_PANELS=0: all of them by the pattern-driven kernel
+        static const bool zpanels_on = !(getenv("PANGULU_HIP_COMPLEX_PANELS") && atoi(getenv("PANGULU_HIP_COMPLEX_PANELS")) == 0);
+        std::vector<ZGetrfTaskD> ztasks;
+        std::vector<GetrfTaskD> zcount; // their pattern views, for the structural flop count
+        std::vector<MirrorJobD> deferred; // sparse records of the blocks factorised in their mirrors: sparsify jobs behind the kernel
+#endif
+        size_t nsp = 0; // tasks of the pattern-driven / blocked launch
         double by = 0;
         for (size_t k = 0; k < take; k++)
         {
@@ -3183,15 +3275,36 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
             T.preloaded = 0;
             T.defer_gather = 0;
             T.invert_tiles = 0;
-#if defined(PG_DENSE_UPDATES) && !defined(PG_DENSE_PANELS)
+#if defined(PG_COMPLEX_PANELS)
             {
-                // (CR64: no blocked kernel) updates may have accumulated in the block's mirror: the record catches up first,
-                // and the mirror is stale once the block is factorised
                 BlockState &st = block_state(lo, nb);
+                double *m = (zpanels_on && !B.opt_getrf_strict && !B.opt_host_mirror && (nb == 128 || nb == 256) && dense_mode_available(nb)) ? obtain_mirror(st, nb) : nullptr;
+                if (m)
+                {
+                    // in the mirror: bring it up to date if the record is ahead, factorise it there, and let a sparsify job write
+                    // the record behind the kernel; the image serves the dense solves of this level (ztrsm_planes_kernel)
+                    if (!st.mirror_current)
+                    {
+                        MP.to_densify.push_back(mirror_job(lo, m, nb));
+                        st.mirror_current = true;
+                    }
+                    ztasks.push_back(ZGetrfTaskD{m});
+                    zcount.push_back(T);
+                    deferred.push_back(mirror_job(lo, m, nb));
+                    st.sparse_current = true; // (once the deferred job has run: everything that reads the record waits for it)
+                    st.lu_image = true;
+                    st.lu_map = false;
+                    st.image_halves = 3;
+                    by += (2 * SV + 2) * ((double)host_nnz(lo, nb) + host_nnz(up, nb)) + 8.0 * (nb + 1);
+                    continue;
+                }
+                // (no mirror to be had) updates may have accumulated in the block's mirror: the record catches up first,
+                // and the mirror is stale once the block is factorised
                 if (!st.sparse_current && st.mirror)
                     MP.to_sparsify.push_back(mirror_job(lo, st.mirror, nb));
                 st.sparse_current = true;
                 st.mirror_current = false;
+                st.lu_image = false;
             }
 #endif
 #if defined(PG_DENSE_PANELS)
@@ -3232,7 +3345,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 st.mirror_current = false;
             }
 #endif
-            tasks[k] = T;
+            tasks[nsp++] = T;
             by += (2 * SV + 2) * ((double)host_nnz(lo, nb) + host_nnz(up, nb)) + 8.0 * (nb + 1);
         }
         hipStream_t ks = gs;
@@ -3241,6 +3354,27 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
         {
             flush_mirror_jobs(nb, MP.to_sparsify, false); // (main stream) these blocks must see it: stay on the main stream
             ks = B.stream;
+        }
+#endif
+#if defined(PG_COMPLEX_PANELS)
+        ZGetrfTaskD *d_ztasks = nullptr;
+        GetrfTaskD *d_zcount = nullptr;
+        if (!ztasks.empty())
+        {
+            if (!MP.to_densify.empty() || !B.opt_records_stream)
+                ks = B.stream; // (mirror jobs run on the main stream: the factorisation follows them there)
+            if (!MP.to_densify.empty())
+                flush_mirror_jobs(nb, MP.to_densify, true);
+            ZGetrfTaskD *hz = seg.alloc<ZGetrfTaskD>(ztasks.size(), &d_ztasks);
+            GetrfTaskD *hc = seg.alloc<GetrfTaskD>(zcount.size(), &d_zcount);
+            if (hc)
+                memcpy(hc, zcount.data(), sizeof(GetrfTaskD) * zcount.size());
+            if (!hz || !hc)
+            {
+                fprintf(stderr, "[PanguLU-AMD ERROR] descriptor staging segment too small\n");
+                exit(EXIT_FAILURE);
+            }
+            memcpy(hz, ztasks.data(), sizeof(ZGetrfTaskD) * ztasks.size());
         }
 #endif
         commit_segment(seg);
@@ -3330,13 +3464,33 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                                        B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
             }
 #endif
-            if (!blocked)
+            if (!blocked && nsp)
             {
                 size_t lds = (sizeof(val_t) * 2 + sizeof(u16) * 2) * (size_t)nb;
-                PG_LAUNCH(getrf_kernel, dim3((unsigned)take), dim3(GETRF_THREADS), lds, ks, d_tasks, nb, B.d_flops + 1);
+                PG_LAUNCH(getrf_kernel, dim3((unsigned)nsp), dim3(GETRF_THREADS), lds, ks, d_tasks, nb, B.d_flops + 1);
             }
+#if defined(PG_COMPLEX_PANELS)
+            if (!ztasks.empty())
+            {
+                const size_t lds_z = sizeof(double) * 4 * ZP_PANEL * (size_t)nb;
+                static size_t z_allowed = 0;
+                if (lds_z > z_allowed)
+                {
+                    HIP_CHECK(hipFuncSetAttribute((const void *)zgetrf_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_z));
+                    z_allowed = lds_z;
+                }
+                PG_LAUNCH(zgetrf_planes_kernel, dim3((unsigned)ztasks.size()), dim3(ZG_THREADS), lds_z, ks, (const ZGetrfTaskD *)d_ztasks, nb);
+                if (B.opt_count_flops)
+                    PG_LAUNCH(getrf_flop_count_kernel, dim3((unsigned)ztasks.size()), dim3(256), 0, ks, (const GetrfTaskD *)d_zcount, nb, B.d_flops + 1);
+                B.zgetrf_tasks += ztasks.size();
+            }
+#endif
             HIP_CHECK(hipGetLastError());
         }
+#if defined(PG_COMPLEX_PANELS)
+        if (!deferred.empty())
+            pg_event_record(B.ev_rec_fork, ks); // behind the factorisation
+#endif
 #if defined(PG_DENSE_PANELS)
         if (held)
         {
@@ -3367,7 +3521,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 pg_stream_wait(B.stream, B.ev_join3);
         }
         release_pending_segments(ks); // (the descriptors are read on ks, which the main stream may not have joined yet)
-#if defined(PG_DENSE_PANELS)
+#if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
         if (!deferred.empty())
             flush_mirror_jobs(nb, deferred, false, true, nullptr, true);
 #endif

@@ -99,6 +99,7 @@ struct HalfImageJobD
     double *dense;
 };
 
+#if defined(PG_DENSE_PANELS) // (real types: images of diagonal blocks factorised on another rank)
 __global__ __launch_bounds__(1024) void half_image_kernel(const HalfImageJobD *__restrict__ jobs, int nb)
 {
     extern __shared__ u32 s_ptr[]; // nb + 1 entries
@@ -125,6 +126,8 @@ __global__ __launch_bounds__(1024) void half_image_kernel(const HalfImageJobD *_
             J.dense[(size_t)J.uci[p] * nb + mirror_column_of(s_ptr, nb, p)] = J.uval[p];
     }
 }
+
+#endif
 
 // grid = tasks * (nb / 64); workgroup = 4 wavefronts; every wavefront solves 16 rows (TSTRF) or 16 columns (GESSM) of
 // the block on its own and keeps ALL its finished 16 x 16 solution tiles in registers (NP tiles x 4 f64): a finished
