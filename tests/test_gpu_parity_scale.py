@@ -165,8 +165,9 @@ def test_cr64_updates_on_the_matrix_cores(name, gen, nb, permille):
 def test_dense_paths_of_every_value_type_at_nb256(vtype):
     """Round 3: the mirrors and LU images of R32 / CR32 blocks are double (densify widens, sparsify rounds) and every dense kernel
     is the f64 one -- the reference densifies + cuBLAS/cuSOLVER for every type (...0201000.cu:547-641, 778-816).  At nb = 256 on
-    a 3D problem all four types must put their updates on the matrix cores, the real types their panels on the dense solves,
-    and give the oracle's factors within the type's tolerance."""
+    a 3D problem all four types must put their updates on the matrix cores and their panels on the dense kernels (real types:
+    tiled GETRF + MFMA solves; complex types: GETRF and solves on the two-plane mirrors), and give the oracle's factors within the
+    type's tolerance."""
     dt = {"r64": np.float64, "r32": np.float32, "cr64": np.complex128, "cr32": np.complex64}[vtype]
     cplx = np.issubdtype(dt, np.complexfloating)
     mat = M.fem27(20, dtype=dt) if not cplx else M.poisson3d(20, dtype=dt, shift=0.5j)
@@ -174,8 +175,7 @@ def test_dense_paths_of_every_value_type_at_nb256(vtype):
     ref = factorize(mat, 256, oracle_library(vtype), vtype=vtype)
     st = gpu["hip_stats"]
     assert st["ssssm_dense_mfma"]["tasks"] > 0, st
-    if not cplx:
-        assert st["tstrf"]["dense_path_tasks"] > 0, st
+    assert st["tstrf"]["dense_path_tasks"] > 0, st  # (complex types: solves on the two-plane mirrors, pg_hip_panels_complex.h)
     single = vtype in ("r32", "cr32")
     tol = 1e-5 if single else 1e-12
     for f in ("L", "U"):
