@@ -88,9 +88,20 @@ __global__ __launch_bounds__(ZG_THREADS) void zgetrf_planes_kernel(const ZGetrfT
     double *Si = Sr + ZP_PANEL * nb;
     double *Dr = tasks[blockIdx.x].dense, *Di = Dr + mirror_plane_stride(nb);
     __shared__ double s_rcp[2 * ZP_PANEL]; // reciprocals of the panel's (clamped) pivots
+    __shared__ unsigned s_gmap[16];        // s_gmap[tc] bit tr: tile (tr, tc) of the block holds pattern entries (closed under elimination)
     const int tid = threadIdx.x;
+    if (tid < 16)
+        s_gmap[tid] = tid < nb / 16 ? (unsigned)mirror_map(Dr, nb)[tid] : 0u;
+    __syncthreads();
+    // (the mirror of a diagonal block is cleared as a whole before its entries are scattered: a dead tile holds zeros and stays
+    //  zero, so the map only saves work here -- most diagonal blocks of the lower tree levels are a few tiles wide)
     for (int k0 = 0; k0 < nb; k0 += ZP_PANEL)
     {
+        const int tk = k0 >> 4;
+        unsigned row_tiles = 0; // tile row tk: bit tc = tile (tk, tc) live
+        for (int tc = 0; tc < nb / 16; tc++)
+            row_tiles |= ((s_gmap[tc] >> tk) & 1u) << tc;
+        const unsigned col_tiles = s_gmap[tk]; // tile column tk: bit tr
         // (1) panel columns k0 .. k0+15, rows k0 .. nb-1
         for (int e = tid; e < ZP_PANEL * (nb - k0); e += ZG_THREADS)
         {
@@ -145,6 +156,8 @@ __global__ __launch_bounds__(ZG_THREADS) void zgetrf_planes_kernel(const ZGetrfT
         __syncthreads();
         for (int r = k0 + ZP_PANEL + tid; r < nb; r += ZG_THREADS)
         {
+            if (!((col_tiles >> (r >> 4)) & 1u))
+                continue; // (zeros: nothing to solve)
             double xr[ZP_PANEL], xi[ZP_PANEL];
 #pragma unroll
             for (int c = 0; c < ZP_PANEL; c++)
@@ -191,6 +204,8 @@ __global__ __launch_bounds__(ZG_THREADS) void zgetrf_planes_kernel(const ZGetrfT
         // (4) strip: rows k0 .. k0+15 of the columns right of the tile, Y = L11^-1 T (unit lower)
         for (int c = m0 + tid; c < nb; c += ZG_THREADS)
         {
+            if (!((row_tiles >> (c >> 4)) & 1u))
+                continue; // (zeros; the trailing update skips this column)
             double sr[ZP_PANEL], si[ZP_PANEL];
 #pragma unroll
             for (int k = 0; k < ZP_PANEL; k++)
@@ -223,6 +238,8 @@ __global__ __launch_bounds__(ZG_THREADS) void zgetrf_planes_kernel(const ZGetrfT
             const int rl = tid & 63, cg = tid >> 6; // rows m0 + rl + 64 i, columns m0 + cg + 16 j
             for (int r = m0 + rl; r < nb; r += 64)
             {
+                if (!((col_tiles >> (r >> 4)) & 1u))
+                    continue; // (L(r, panel) = 0)
                 double lr[ZP_PANEL], li[ZP_PANEL];
 #pragma unroll
                 for (int k = 0; k < ZP_PANEL; k++)
@@ -234,18 +251,20 @@ __global__ __launch_bounds__(ZG_THREADS) void zgetrf_planes_kernel(const ZGetrfT
                 for (int c = m0 + cg; c < nb; c += 4 * (ZG_THREADS / 64))
                 {
                     double xr[4], xi[4];
+                    bool on[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++)
                     {
                         const int cc = c + u * (ZG_THREADS / 64);
-                        xr[u] = cc < nb ? Dr[(size_t)cc * nb + r] : 0.0;
-                        xi[u] = cc < nb ? Di[(size_t)cc * nb + r] : 0.0;
+                        on[u] = cc < nb && ((row_tiles >> (cc >> 4)) & 1u); // (U(panel, cc) = 0 otherwise)
+                        xr[u] = on[u] ? Dr[(size_t)cc * nb + r] : 0.0;
+                        xi[u] = on[u] ? Di[(size_t)cc * nb + r] : 0.0;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++)
                     {
                         const int cc = c + u * (ZG_THREADS / 64);
-                        if (cc >= nb)
+                        if (!on[u])
                             continue;
 #pragma unroll
                         for (int k = 0; k < ZP_PANEL; k++)

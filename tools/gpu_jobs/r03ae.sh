@@ -1,0 +1,20 @@
+#!/bin/bash
+# thresholds that were tuned with the previous general update kernel, re-checked with the current one (one box)
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+mkdir -p gpurun_out
+run() {
+  env "$@" timeout 900 python bench.py --gpu-worker --workload fem27 --size 112 --steps 3 --warmup 1 --no-profile-pass 2>/dev/null | grep '"metric"' | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('%-60s %.1f ms  residual %.2e' % ('$*', d['ms_per_step'], d['residual']))"
+}
+{
+run PANGULU_AMD_X=0
+run PANGULU_HIP_FRONT_MIN_WGS=2048
+run PANGULU_HIP_FRONT_MIN_WGS=32768
+run PANGULU_HIP_FRONT_MIN_WGS=1000000000
+run PANGULU_HIP_DENSE_PERMILLE=1
+run PANGULU_HIP_DENSE_PERMILLE=5
+} 2>&1 | tee gpurun_out/r03ae_threshold_recheck.log
