@@ -1,5 +1,5 @@
 #!/bin/bash
-# tilesv kernel (DMA issue behind the first products, step records prefetched) against the tiles kernel: checks, step cost, probes
+# LDS counters instead of the per-step barrier in the tilesv kernel: checks, step cost, probes
 cd /root/repo/tools/microbench
 {
 timeout 120 ./front_gemm.bin 8 2 100 2>&1 | grep -E "^check"

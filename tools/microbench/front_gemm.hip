@@ -40,7 +40,6 @@ __device__ unsigned long long g_probe[8];
 #define TL_PROBE_FLUSH if (lane == 0 && (wave == 0 || wave == 5)) { for (int i_ = 0; i_ < 7; i_++) atomicAdd(&g_probe[i_], pr_sum[i_]); }
 #define TL_PROBE_STEP pr_sum[5]++;
 #endif
-#define TV_PRIO_EXPERIMENT 1
 #include "../../pangulu_amd/csrc/platform/pg_hip_dense.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_front.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -157,20 +156,10 @@ void launch(int which, Problem &X)
         CK(hipGetLastError());
         return;
     }
-    if (which >= 30000)
-    {
-        // stream kernel: chunks of at most (which / 100) % 100 work items (a power of two), XCD units of one destination
-        const unsigned per = (unsigned)((which / 100) % 100);
-        int nlog = 0;
-        while ((2u << nlog) <= per) nlog++;
-        const unsigned n_units = (grid + 3u) / 4u, tp = ((n_units + 7u) / 8u) * 4u;
-        hipLaunchKernelGGL(ssssm_stream_f64_kernel, dim3(8u * stream_chunks(tp, nlog)), dim3(FR_THREADS), 0, 0, X.dT, X.nb, X.dW, grid, none, 2u, nlog, which >= 40000 ? 1u : 0u);
-        CK(hipGetLastError());
-        return;
-    }
     if (which >= 20000)
     {
-        hipLaunchKernelGGL(ssssm_tilesv_f64_kernel, dim3(grid), dim3(FR_THREADS), 0, 0, X.dT, X.nb, X.dW, none, (4u * (unsigned)((which / 100) % 100)) | ((unsigned)(which % 10 - 2) << 16));
+        // (tools/experiments/ssssm_lds_counters_for_barriers.patch adds a variant `which % 10 == 3`)
+        hipLaunchKernelGGL(ssssm_tilesv_f64_kernel, dim3(grid), dim3(FR_THREADS), 0, 0, X.dT, X.nb, X.dW, none, 4u * (unsigned)((which / 100) % 100));
         CK(hipGetLastError());
         return;
     }
@@ -202,14 +191,9 @@ const char *name_of(int which)
 {
     if (which == 0)
         return "round-2 kernel (pg_hip_dense.h)";
-    if (which >= 30000)
-    {
-        snprintf(name_buf, sizeof(name_buf), "stream kernel, chunks of at most %d work items%s", (which / 100) % 100, which >= 40000 ? ", C += by atomics" : "");
-        return name_buf;
-    }
     if (which >= 20000)
     {
-        snprintf(name_buf, sizeof(name_buf), "tiles kernel, DMA issue behind the first products, XCD unit %d dest., priority mode %d", (which / 100) % 100, which % 10 - 2);
+        snprintf(name_buf, sizeof(name_buf), "tiles kernel, DMA issue behind the first products, XCD unit %d dest.", (which / 100) % 100);
         return name_buf;
     }
     if (which >= 10000)
@@ -253,7 +237,7 @@ int main(int argc, char **argv)
         build(X, 3, 2, true, cf);
         const int nb = X.nb;
         std::vector<double> ref((size_t)nb * nb), got((size_t)X.mb);
-        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102, 30102, 30802, 40802} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802, 30102, 30202, 30802, 40802};
+        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802};
         for (int which : kinds)
         {
             for (int i = 0; i < X.P; i++)
@@ -282,9 +266,9 @@ int main(int argc, char **argv)
     const double flop = 8192.0 * X.products;
     printf("front %d x %d destinations of 256 x 256, %d update(s) queued on each, %d%% fill pattern: %zu workgroups, %.3f TFLOP of live 16x16x16 products per launch (%.1f%% of dense)\n", P, P, Q,
            fill, X.nwork, flop / 1e12, 100.0 * flop / (2.0 * 256 * 256 * 256 * (double)P * P * Q));
-    std::vector<int> kinds = fill >= 100 ? std::vector<int>{112, 20102, 20103, 20104, 20105, 20106, 112, 20102, 20103, 20104, 20105, 20106} : std::vector<int>{20102, 20103, 20104, 20105, 20106, 20102, 20103, 20104, 20105, 20106};
+    std::vector<int> kinds = fill >= 100 ? std::vector<int>{0, 112, 10102, 20102, 0, 112, 10102, 20102} : std::vector<int>{0, 10102, 20102, 20802, 0, 10102, 20102, 20802};
 #ifdef TL_PROBE
-    kinds = {20102, 30802, 20102, 30802};
+    kinds = {10102, 20102, 10102, 20102};
 #endif
     for (int which : kinds)
     {
