@@ -2754,8 +2754,48 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                     nfull += (size_t)__builtin_popcount(all_full);
                 }
                 const bool own_launch = B.opt_front_stages >= 2 && (B.opt_tiles_stages < 1 || nfull >= (size_t)B.opt_front_min_wgs);
-                for (size_t gi = 0; gi < gd; gi++)
+                // Longest queues first (PANGULU_HIP_HEAVY_FIRST): a launch ends with its last workgroup, and a queue of 128 live slab
+                // steps that starts when the others are done is a tail of its own length.  Classes by the live steps of a group's
+                // busiest tile -- sixteen of 16 steps each (2, the default), or four (1) --, the scheduler's order kept inside a class
+                // (neighbours share operands: L2).  fem27(112), one box: 810.3-811.6 / 813.3 / 815.4 ms with 2 / 1 / 0
+                // (profiles/r03ak_heavy_first.log); shell(398) indifferent.
+                static const int heavy_mode = getenv("PANGULU_HIP_HEAVY_FIRST") ? atoi(getenv("PANGULU_HIP_HEAVY_FIRST")) : 2;
+                static const bool heavy_first = heavy_mode != 0;
+                static std::vector<u32> g_order;
+                g_order.resize(gd);
+                if (heavy_first && gd > 1)
                 {
+                    static std::vector<unsigned char> g_class;
+                    g_class.resize(gd);
+                    size_t count[16] = {0};
+                    for (size_t gi = 0; gi < gd; gi++)
+                    {
+                        const SsssmGroupD &Gd = groups_d[gi];
+                        const unsigned kmask = Gd.slab_mask ? Gd.slab_mask : 0xFFFFu;
+                        unsigned steps[4] = {0, 0, 0, 0};
+                        for (u32 t = Gd.task_begin; t < Gd.task_end; t++)
+                            for (int tl = 0; tl < tiles * tiles; tl++)
+                                steps[tl] += (unsigned)__builtin_popcount(live_k[(size_t)t * 4 + tl] & kmask);
+                        const unsigned most = std::max(std::max(steps[0], steps[1]), std::max(steps[2], steps[3]));
+                        if (heavy_mode == 2)
+                            g_class[gi] = (unsigned char)(15 - std::min(15u, most / 16u));
+                        else
+                            g_class[gi] = most >= 96 ? 0 : most >= 48 ? 1 : most >= 24 ? 2 : 3;
+                        count[g_class[gi]]++;
+                    }
+                    size_t at[16];
+                    at[0] = 0;
+                    for (int c = 1; c < 16; c++)
+                        at[c] = at[c - 1] + count[c - 1];
+                    for (size_t gi = 0; gi < gd; gi++)
+                        g_order[at[g_class[gi]]++] = (u32)gi;
+                }
+                else
+                    for (size_t gi = 0; gi < gd; gi++)
+                        g_order[gi] = (u32)gi;
+                for (size_t go = 0; go < gd; go++)
+                {
+                    const size_t gi = g_order[go];
                     const SsssmGroupD &Gd = groups_d[gi];
                     const unsigned all_full = full_g[gi];
                     for (int tl = 0; tl < tiles * tiles; tl++)
