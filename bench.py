@@ -117,14 +117,16 @@ def workload_key(args):
 
 
 def kernel_source_hash():
-    """sha256 over the HIP kernel sources: a committed PMC pass is only quoted for the build it profiled."""
+    """sha256 over the native sources (kernels and host): a committed PMC pass is only quoted for the build it profiled."""
     import hashlib
 
-    d = os.path.join(ROOT, "pangulu_amd", "csrc", "platform")
     hsh = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            hsh.update(open(os.path.join(d, f), "rb").read())
+    # (the host sources too: ordering, mapping and the scheduler decide which launches a workload is made of)
+    for sub in ("platform", "host"):
+        d = os.path.join(ROOT, "pangulu_amd", "csrc", sub)
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h", ".cpp")):
+                hsh.update(open(os.path.join(d, f), "rb").read())
     return hsh.hexdigest()[:16]
 
 
