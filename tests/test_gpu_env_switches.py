@@ -43,6 +43,8 @@ SWITCHES = [
     # GETRF -> dense-solve chase (off by default): a level's factorisations and its dense solves in one launch
     {"PANGULU_HIP_CHASE": "1", "PANGULU_HIP_CHASE_MAX_GETRF": "4"},
     {"PANGULU_HIP_CHASE": "1", "PANGULU_HIP_CHASE_MAX_GETRF": "256", "_matrix": "fem27"},
+    {"PANGULU_AMD_SEPARATOR_ORDER": "natural", "_matrix": "fem27"},  # separators in the mesh's numbering (default: k-d order)
+    {"PANGULU_HIP_HEAVY_FIRST": "0", "_matrix": "fem27"},              # update work items in the scheduler's order
 ]
 
 
