@@ -199,7 +199,7 @@ extern "C"
      *   PANGULU_HIP_OPT_HOST_MIRROR (default 1): after GETRF/TSTRF/GESSM copy the block's values back into
      *     slot->value like …0201000.cu:639-640,680,714 does (the reference host's MPI send and SpTRSV read
      *     host memory).  The native host keeps factors device-resident and sets 0.
-     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 5): an update C -= A*B whose operands have a
+     *   PANGULU_HIP_OPT_DENSE_THRESHOLD_PERMILLE (default 2): an update C -= A*B whose operands have a
      *     geometric-mean fill sqrt(dA*dB) of at least this many per mille runs on the f64 MFMA kernel on dense
      *     mirrors of the three blocks (kept in HBM, built once per block); a destination that has a mirror
      *     accumulates all its updates there.  1000 = only completely full operands (the reference's
@@ -232,7 +232,7 @@ extern "C"
      *     cut into chunks of this size that run concurrently and add their partial sums with floating-point
      *     atomics (results then vary in the last bits from run to run).  0 = never split. */
 #define PANGULU_HIP_OPT_SSSSM_GROUP_CHUNK 8
-    /*   PANGULU_HIP_OPT_TRSM_DENSE_PERMILLE (default 10): TSTRF/GESSM on a block with at least this fill (or whose
+    /*   PANGULU_HIP_OPT_TRSM_DENSE_PERMILLE (default 5): TSTRF/GESSM on a block with at least this fill (or whose
      *     updates already live in a dense mirror) run as panel-wise dense solves on the matrix cores against the dense
      *     LU image GETRF leaves behind; 1001 keeps every solve on the sparse kernel. */
 #define PANGULU_HIP_OPT_TRSM_DENSE_PERMILLE 9
@@ -316,10 +316,14 @@ extern "C"
     /* Optional: the static schedule of a factorisation.  For a host whose call sequence is a pure function of the block
      * pattern (one rank, dependency-free batches in a fixed order -- the native scheduler's) the launches of one
      * factorisation can be recorded once and replayed for every later factorisation of the same pattern, with no host
-     * work per task.  cmd 1: start recording everything hybrid_batched issues, for `owner` (an opaque token); 2: stop
-     * (returns the number of recorded operations); 3: replay (0 = replayed, 1 = nothing valid: other owner, other
-     * options, nothing recorded); 0: drop (the owner's blocks are about to be freed).  Profiled runs and the eager host
-     * mirror are not recorded (cmd 1 returns -1). */
+     * work per task.  cmd 1: start recording everything hybrid_batched issues, for `owner` (an opaque token); 4: like 1,
+     * but RECORD ONLY -- the calls that follow go through the back-end's launch code and build their descriptors, nothing is
+     * launched and no block is touched (the native host's dry run of its scheduler at pangulu_init); 2: stop (returns the
+     * number of recorded operations); 3: replay (0 = replayed, 1 = nothing valid: other owner, other options, nothing
+     * recorded, or a resource of the back-end the recorded launches point into -- GETRF scratch, mirror pool -- has been
+     * re-allocated since, e.g. by a handle with another block order); 0: drop (the owner's blocks are about to be freed).
+     * Profiled runs and the eager host mirror are not recorded (cmd 1 / 4 return -1).  The host-side counters of get_stats
+     * (launches, tasks, alg_bytes, workgroup counts) count a dry run not at all and every replay once. */
     long long pangulu_platform_0201001_schedule(int cmd, const void *owner);
     /* stream all numeric kernels are launched on (a hipStream_t); for event timing in bench.py */
     void *pangulu_platform_0201001_get_stream(void);

@@ -107,7 +107,15 @@ struct NearDevice
     explicit NearDevice(Platform &p) : plat(p)
     {
         if (!plat.host_memory && plat.bind_near_device)
+        {
+            // Threads created while the mask is narrowed keep it for good.  The scheduler's launcher thread is meant to (it ends
+            // with the call); OpenMP pool workers are not -- they outlive the call and serve the host application's own parallel
+            // regions.  Make sure the pool exists, with the caller's mask, before the mask changes.
+#pragma omp parallel
+            {
+            }
             bound = plat.bind_near_device(1) == 0;
+        }
     }
     ~NearDevice()
     {
@@ -262,6 +270,13 @@ extern "C"
         {
             set_world(nullptr);
             return 0;
+        }
+        if (size > 64)
+        {
+            // consumer sets and forwarding masks are one bit per rank in a 64-bit word (Solver::consumers, pg_model.cpp); the
+            // scope is one node of 8 GPUs (the reference's grids: 1x1 ... 2x4, src/pangulu.c:83-90)
+            fprintf(stderr, "[PanguLU-AMD ERROR] %d ranks requested: at most 64 are supported\n", size);
+            return 1;
         }
         // the device transports capture the calling thread's current device: select this rank's GPU first, by the same
         // rule pangulu_init uses (LOCAL_RANK, else the rank, modulo the visible devices)

@@ -170,7 +170,8 @@ double *obtain_mirror(BlockState &st, int nb)
     size_t mb = PG_PLANES * (sizeof(double) * (size_t)nb * nb + MIRROR_MAP_BYTES + sizeof(double) * 16 * (size_t)nb);
     if (MP.mirror_bytes != mb)
     {
-        // block order changed (or first use): start over
+        // block order changed (or first use): start over (a recorded schedule's launches point into the old chunks)
+        B.generation++;
         for (char *c : MP.chunks)
             HIP_CHECK(hipFree(c));
         MP.chunks.clear();

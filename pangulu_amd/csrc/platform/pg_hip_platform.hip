@@ -1882,6 +1882,9 @@ struct Backend
     unsigned long long front_workgroups = 0, general_workgroups = 0;
     long long opt_records_stream = 1; // PANGULU_HIP_RECORDS_STREAM=0: sparsify on the main stream as before
     int nb_cfg = 0;
+    // Bumped whenever a process-global resource that recorded launches point into is freed or re-assigned (the GETRF scratch,
+    // the mirror pool, the chase's progress words): a recorded schedule is only replayed under the generation it ended in.
+    unsigned long long generation = 0;
     // options
     long long opt_host_mirror = 1;
     long long opt_dense_permille = 2; // (10 until the end of round 2, 5 until round 3's sweep on replayed runs: fem27(112) 887.8 / 892.1 / 906.8 ms at 2 / 5 / 10, shell(398) 37.9 / 38.5 / 39.2)
@@ -1940,6 +1943,14 @@ struct Recorder
     };
     std::vector<Seg> segs;
     size_t descriptor_bytes = 0;
+    // what else the closures depend on: the block order and the generation of the back-end's shared resources when the list
+    // was complete (B.generation)
+    int nb = 0;
+    unsigned long long generation = 0;
+    // host-side counters of ONE factorisation (launches, tasks, algorithmic bytes, workgroup counts): taken as the difference
+    // over the recording, added by every replay; a dry run (mode 2) launched nothing and leaves the live counters as they were
+    pangulu_hip_stats_t stats_before, stats_delta;
+    unsigned long long wgs_before[4] = {0, 0, 0, 0}, wgs_delta[4] = {0, 0, 0, 0}; // front, general, chase launches, chase solves
 };
 Recorder REC;
 
@@ -1971,6 +1982,9 @@ inline void flush_pending_getrf()
     PEND.plain = nullptr;
     PEND.post = nullptr;
 }
+
+// PEND is back-end state like everything else: entry points that do not hold B.mutex anyway take it for the flush
+inline void flush_pending_getrf_locked();
 
 // a kernel argument as the replay will pass it: pointers into a recorded descriptor segment move to the segment's HBM twin
 template <class T>
@@ -2019,6 +2033,14 @@ inline void pg_stream_wait(hipStream_t s, hipEvent_t e)
         REC.ops.emplace_back([e, s]() { HIP_CHECK(hipStreamWaitEvent(s, e, 0)); });
     if (REC.mode != 2)
         HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+}
+
+inline void flush_pending_getrf_locked()
+{
+    if (!PEND.active) // (only ever set under the mutex by the thread that launches; a stale read here just skips a no-op)
+        return;
+    std::lock_guard<std::mutex> g(B.mutex);
+    flush_pending_getrf();
 }
 
 void ensure_ready()
@@ -3265,9 +3287,10 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
     const int max_slots = 256;
     if (!B.getrf_scratch || B.nb_cfg != nb)
     {
+        B.generation++; // (recorded launches point into the scratch)
         if (B.getrf_scratch)
         {
-            HIP_CHECK(hipStreamSynchronize(B.stream));
+            HIP_CHECK(hipDeviceSynchronize()); // (factorisations run on side streams too)
             HIP_CHECK(hipFree(B.getrf_scratch));
         }
         HIP_CHECK(hipMalloc((void **)&B.getrf_scratch, std::max(sizeof(val_t), sizeof(double)) * (size_t)nb * nb * max_slots)); // (a slot holds a double image)
@@ -3468,6 +3491,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         PEND.images.assign(lu_images.begin(), lu_images.end());
                         if (!B.d_progress)
                         {
+                            B.generation++;
                             HIP_CHECK(hipMalloc((void **)&B.d_progress, sizeof(unsigned) * PROGRESS_WORDS));
                             HIP_CHECK(hipMemset(B.d_progress, 0, sizeof(unsigned) * PROGRESS_WORDS));
                         }
@@ -3696,7 +3720,7 @@ extern "C"
     void pangulu_platform_0201001_synchronize(void)
     {
         ensure_ready();
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         join_records(B.stream);
         join_background(B.stream);
         HIP_CHECK(hipStreamSynchronize(B.stream));
@@ -3705,7 +3729,7 @@ extern "C"
     void pangulu_platform_0201001_memset(void *s, int c, size_t n)
     {
         ensure_ready();
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         HIP_CHECK(hipMemsetAsync(s, c, n, B.stream));
         HIP_CHECK(hipStreamSynchronize(B.stream));
     }
@@ -3735,7 +3759,7 @@ extern "C"
     void pangulu_platform_0201001_memcpy(void *dst, const void *src, size_t count, unsigned int kind)
     {
         ensure_ready();
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         // ordered after everything queued on the back-end stream, complete on return
         join_records(B.stream);
         join_background(B.stream);
@@ -3746,7 +3770,7 @@ extern "C"
     void pangulu_platform_0201001_memcpy_async(void *dst, const void *src, size_t count, unsigned int kind, void *stream)
     {
         ensure_ready();
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         // stream == NULL is what the reference host passes from its receive thread
         // (src/pangulu_communication.c:1850,1880): use the back-end stream so later kernels are ordered behind it
         hipStream_t s = stream ? (hipStream_t)stream : B.stream;
@@ -3762,7 +3786,7 @@ extern "C"
 
     void pangulu_platform_0201001_free(void *devptr)
     {
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         if (!devptr)
             return;
         hipPointerAttribute_t attr;
@@ -3951,7 +3975,7 @@ extern "C"
 
     void pangulu_platform_0201001_ssssm_batched(pangulu_inblock_idx nb, pangulu_uint64_t ntask, pangulu_task_t *tasks)
     {
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         // as the reference's dispatcher does (src/pangulu_kernel_interface.c:302), kernel ids in the array decide
         pangulu_platform_0201001_hybrid_batched(nb, ntask, tasks);
     }
@@ -3994,7 +4018,7 @@ extern "C"
     void pangulu_platform_0201001_spmv(pangulu_inblock_idx nb, pangulu_storage_slot_t *a, calculate_type *x, calculate_type *y)
     {
         ensure_ready();
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         join_records(B.stream);
         hipLaunchKernelGGL(spmv_kernel, dim3(1), dim3(256), 0, B.stream, (int)nb, a->d_columnpointer, a->d_rowindex, a->d_value, x, y);
         HIP_CHECK(hipGetLastError());
@@ -4003,7 +4027,7 @@ extern "C"
     void pangulu_platform_0201001_vecadd(pangulu_int64_t length, calculate_type *bval, calculate_type *xval)
     {
         ensure_ready();
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         if (length <= 0)
             return;
         hipLaunchKernelGGL(vecadd_kernel, dim3((unsigned)((length + 255) / 256)), dim3(256), 0, B.stream, (long long)length, bval, xval);
@@ -4013,7 +4037,7 @@ extern "C"
     void pangulu_platform_0201001_sptrsv(pangulu_inblock_idx nb, pangulu_storage_slot_t *s, calculate_type *xval, pangulu_int64_t uplo)
     {
         ensure_ready();
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         size_t lds = sizeof(val_t) * (size_t)nb;
         join_records(B.stream);
         if (uplo == PANGULU_LOWER)
@@ -4028,8 +4052,8 @@ extern "C"
     void *pangulu_platform_0201001_marker_record(void)
     {
         ensure_ready();
-        flush_pending_getrf();
         std::lock_guard<std::mutex> g(B.mutex);
+        flush_pending_getrf();
         HIP_CHECK(hipSetDevice(B.device));
         static std::vector<hipEvent_t> ring;
         static size_t next = 0;
@@ -4060,7 +4084,8 @@ extern "C"
 
     void pangulu_platform_0201001_marker_wait(void *marker)
     {
-        flush_pending_getrf();
+        // (called from the transport's sender thread: no back-end state is touched here -- marker_record has launched a held
+        //  factorisation before it recorded the event this waits for)
         HIP_CHECK(hipSetDevice(B.device));
         HIP_CHECK(hipEventSynchronize((hipEvent_t)marker));
     }
@@ -4068,8 +4093,8 @@ extern "C"
     void pangulu_platform_0201001_prepare_diag(pangulu_inblock_idx nb, pangulu_storage_slot_t *diag)
     {
         ensure_ready();
-        flush_pending_getrf();
         std::lock_guard<std::mutex> g(B.mutex);
+        flush_pending_getrf();
         slot_t *up, *lo;
         diag_halves(diag, &up, &lo);
         (void)get_diag_aux(up, nb);
@@ -4077,7 +4102,7 @@ extern "C"
 
     void pangulu_platform_0201001_prepare_blocks(pangulu_inblock_idx nb, pangulu_uint64_t nslot, pangulu_storage_slot_t **slots)
     {
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
 #if defined(PG_DENSE_UPDATES)
         if (nb > 256 || nb % 16 != 0 || nslot == 0)
             return;
@@ -4230,8 +4255,8 @@ extern "C"
                                              const pangulu_exblock_idx *blk_bcol, calculate_type *x, pangulu_uint64_t xlen)
     {
         ensure_ready();
-        flush_pending_getrf();
         std::lock_guard<std::mutex> g(B.mutex);
+        flush_pending_getrf();
         HIP_CHECK(hipSetDevice(B.device));
         join_records(B.stream); // the sparse records of finished blocks are written on the records stream
         join_background(B.stream);
@@ -4301,8 +4326,8 @@ extern "C"
                                                  const calculate_type *x, calculate_type *y, pangulu_uint64_t xlen)
     {
         ensure_ready();
-        flush_pending_getrf();
         std::lock_guard<std::mutex> g(B.mutex);
+        flush_pending_getrf();
         HIP_CHECK(hipSetDevice(B.device));
         join_records(B.stream); // the sparse records of finished blocks are written on the records stream
         join_background(B.stream);
@@ -4363,16 +4388,41 @@ extern "C"
         REC = Recorder();
     }
 
+    // host-side counters a recording accounts for (everything in B.stats that the launch code, not the device, fills)
+    static void host_counters_delta(const pangulu_hip_stats_t &before, const pangulu_hip_stats_t &after, pangulu_hip_stats_t &d)
+    {
+        memset(&d, 0, sizeof(d));
+        for (int c = 0; c < PANGULU_HIP_STAT_CLASSES; c++)
+        {
+            d.launches[c] = after.launches[c] - before.launches[c];
+            d.tasks[c] = after.tasks[c] - before.tasks[c];
+            d.alg_bytes[c] = after.alg_bytes[c] - before.alg_bytes[c];
+        }
+        d.trsm_dense_tasks = after.trsm_dense_tasks - before.trsm_dense_tasks;
+    }
+    static void host_counters_add(pangulu_hip_stats_t &to, const pangulu_hip_stats_t &d)
+    {
+        for (int c = 0; c < PANGULU_HIP_STAT_CLASSES; c++)
+        {
+            to.launches[c] += d.launches[c];
+            to.tasks[c] += d.tasks[c];
+            to.alg_bytes[c] += d.alg_bytes[c];
+        }
+        to.trsm_dense_tasks += d.trsm_dense_tasks;
+    }
+
     // Static schedule of a factorisation (see Recorder).  cmd 1: start recording for `owner` (an opaque token: the handle);
-    // 2: stop, the list is complete; 3: replay the list if it belongs to `owner` and the options are those it was recorded
-    // under (returns 0 when it was replayed, 1 when there is nothing valid to replay); 0: drop it (the owner's blocks are going
-    // away).  Returns the number of recorded operations for cmd 2.  Not recorded (returns -1 on cmd 1): per-launch profiling
-    // and the eager host mirror, whose copies and event pairs are not part of the list.
+    // 4: like 1, but record only -- nothing is launched (the scheduler's dry run at pangulu_init); 2: stop, the list is complete;
+    // 3: replay the list if it belongs to `owner`, the options are those it was recorded under and none of the back-end's shared
+    // resources the closures point into (GETRF scratch, mirror pool, progress words) has been freed or re-assigned since
+    // (returns 0 when it was replayed, 1 when there is nothing valid to replay); 0: drop it (the owner's blocks are going
+    // away).  Returns the number of recorded operations for cmd 2.  Not recorded (returns -1 on cmd 1 / 4): per-launch
+    // profiling and the eager host mirror, whose copies and event pairs are not part of the list.
     long long pangulu_platform_0201001_schedule(int cmd, const void *owner)
     {
-        flush_pending_getrf();
         ensure_ready();
         std::lock_guard<std::mutex> g(B.mutex);
+        flush_pending_getrf();
         HIP_CHECK(hipSetDevice(B.device));
         switch (cmd)
         {
@@ -4386,16 +4436,23 @@ extern "C"
         case 1:
         case 4:
             HIP_CHECK(hipDeviceSynchronize());
-            drop_schedule(); // (4: like 1, but nothing is launched while recording -- the scheduler's dry run at pangulu_init)
+            drop_schedule();
             if (B.opt_profile || B.opt_host_mirror || !B.opt_assume_independent)
                 return -1;
             REC.mode = cmd == 4 ? 2 : 1;
             REC.owner = owner;
             REC.signature = options_signature();
+            REC.stats_before = B.stats;
+            REC.wgs_before[0] = B.front_workgroups;
+            REC.wgs_before[1] = B.general_workgroups;
+            REC.wgs_before[2] = B.chase_launches;
+            REC.wgs_before[3] = B.chase_solves;
             return 0;
         case 2:
+        {
             if (REC.mode == 0)
                 return -1;
+            const int mode = REC.mode;
             REC.mode = 0;
             // the recorded run's kernels have read the segments in place; the replays read the HBM twins
             HIP_CHECK(hipDeviceSynchronize());
@@ -4405,14 +4462,43 @@ extern "C"
                 HIP_CHECK(hipHostFree(sg.h));
                 sg.h = sg.d = nullptr;
             }
+            host_counters_delta(REC.stats_before, B.stats, REC.stats_delta);
+            REC.wgs_delta[0] = B.front_workgroups - REC.wgs_before[0];
+            REC.wgs_delta[1] = B.general_workgroups - REC.wgs_before[1];
+            REC.wgs_delta[2] = B.chase_launches - REC.wgs_before[2];
+            REC.wgs_delta[3] = B.chase_solves - REC.wgs_before[3];
+            if (mode == 2)
+            {
+                // a dry run launched nothing: the live counters go back to where they were (elapsed times and device-side
+                // flop counts were not touched by it)
+                for (int c = 0; c < PANGULU_HIP_STAT_CLASSES; c++)
+                {
+                    B.stats.launches[c] = REC.stats_before.launches[c];
+                    B.stats.tasks[c] = REC.stats_before.tasks[c];
+                    B.stats.alg_bytes[c] = REC.stats_before.alg_bytes[c];
+                }
+                B.stats.trsm_dense_tasks = REC.stats_before.trsm_dense_tasks;
+                B.front_workgroups = REC.wgs_before[0];
+                B.general_workgroups = REC.wgs_before[1];
+                B.chase_launches = REC.wgs_before[2];
+                B.chase_solves = REC.wgs_before[3];
+            }
+            REC.nb = B.nb_cfg;
+            REC.generation = B.generation; // (the allocations of the recording itself are behind us)
             REC.valid = true;
             return (long long)REC.ops.size();
+        }
         case 3:
-            if (!REC.valid || REC.owner != owner || REC.signature != options_signature())
+            if (!REC.valid || REC.owner != owner || REC.signature != options_signature() || REC.generation != B.generation)
                 return 1;
             for (auto &op : REC.ops)
                 op();
             HIP_CHECK(hipGetLastError());
+            host_counters_add(B.stats, REC.stats_delta);
+            B.front_workgroups += REC.wgs_delta[0];
+            B.general_workgroups += REC.wgs_delta[1];
+            B.chase_launches += REC.wgs_delta[2];
+            B.chase_solves += REC.wgs_delta[3];
             // (the records stream and the background stream may hold work the main stream has not joined: as after a real run)
             B.rec_dirty.store(true, std::memory_order_release);
             return 0;
@@ -4429,7 +4515,7 @@ extern "C"
 
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset)
     {
-        flush_pending_getrf();
+        flush_pending_getrf_locked();
         if (reset && getenv("PANGULU_HIP_HOST_TIMING"))
         {
             fprintf(stderr, "[PanguLU-AMD] host seconds in the back-end: calls %.4f (ssssm %.4f, trsm %.4f, getrf %.4f, mirror jobs %.4f, staging waits %.4f)\n",

@@ -180,8 +180,7 @@ def update_values(h, csc_value):
     the next pangulu_gstrf factorises the new matrix, re-using ordering, symbolic factorisation, records and -- on one rank --
     the recorded launch schedule."""
     if csc_value is not None:
-        va = np.ascontiguousarray(csc_value, dtype=h.dtype)
-        h._keep.append(va)
+        va = np.ascontiguousarray(csc_value, dtype=h.dtype)  # (alive until the call returns: the library copies the values)
         ptr = va.ctypes.data_as(ctypes.c_void_p)
     else:
         ptr = None

@@ -10,7 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # the dense-front kernel gets a launch of its own from this many qualifying workgroups on (2048 in production): low enough
+    # the dense-front kernel gets a launch of its own from this many qualifying workgroups on (8192 in production): low enough
     # for the test matrices to reach both the dedicated launch and the path inside the general launch
     os.environ.setdefault("PANGULU_HIP_FRONT_MIN_WGS", "64")
 

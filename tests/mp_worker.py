@@ -41,7 +41,8 @@ def main():
            "random200": lambda: M.random_pattern(200, 0.03, 5, dtype=dtype), "fem27_9": lambda: M.fem27(9, dtype=dtype),
            "shell_20x16": lambda: M.shell(20, 16, dtype=dtype),
            "poisson12c": lambda: M.poisson3d(12, dtype=dtype, shift=0.5j if np.issubdtype(dtype, np.complexfloating) else 0.0),
-           "kkt6": lambda: M.kkt(6, dtype=dtype), "shell_40x40": lambda: M.shell(40, 40, dtype=dtype)}[spec]
+           "kkt6": lambda: M.kkt(6, dtype=dtype), "shell_40x40": lambda: M.shell(40, 40, dtype=dtype),
+           "kkt8": lambda: M.kkt(8, dtype=dtype), "kkt10": lambda: M.kkt(10, dtype=dtype)}[spec]
     n, cp, ri, va, co = gen()
     ordering = "identity" if spec == "trefethen" else "nd"
     if rank == 0:

@@ -26,16 +26,24 @@ def free_port():
     return p
 
 
-def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transport="host", repeat=False, separators="cyclic"):
-    """`separators`: PANGULU_AMD_SEPARATOR_MAP of the run.  The product's default is "path" (a separator follows its heaviest
-    child: on the small test matrices that often leaves nothing to exchange); the transport tests use the reference's 2D
-    block-cyclic separators, test_separator_maps covers the others."""
+def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transport="host", repeat=False, separators="cyclic",
+              extra_env=None):
+    """`separators`: PANGULU_AMD_SEPARATOR_MAP of the run; None leaves the variable UNSET, which is what a user (and
+    `bench.py --gpus N`) gets: "group" -- proportional mapping with rank groups that shrink down the tree, heavy separators 2D
+    block-cyclic inside their group, light ones on the least loaded rank (pg_preprocess.cpp, assign_subtrees).  The transport
+    tests use "cyclic" (every separator over the reference's p x q grid of ALL ranks: the most exchange per block);
+    test_default_map_* run the default, test_separator_maps the other two ("path", "rank0")."""
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1", PANGULU_TEST_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   PANGULU_TEST_REPEAT="1" if repeat else "0", PANGULU_AMD_SEPARATOR_MAP=separators)
+                   PANGULU_TEST_REPEAT="1" if repeat else "0")
+        if separators is None:
+            env.pop("PANGULU_AMD_SEPARATOR_MAP", None)
+        else:
+            env["PANGULU_AMD_SEPARATOR_MAP"] = separators
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), spec, str(nb), out_path, vtype, platform],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -53,7 +61,62 @@ def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transpo
 
 GENS = {"fem27_6": lambda: M.fem27(6), "poisson8": lambda: M.poisson3d(8), "shell_8x7": lambda: M.shell(8, 7),
         "trefethen": lambda: M.trefethen(), "random200": lambda: M.random_pattern(200, 0.03, 5), "fem27_9": lambda: M.fem27(9),
-        "shell_20x16": lambda: M.shell(20, 16), "kkt6": lambda: M.kkt(6), "shell_40x40": lambda: M.shell(40, 40)}
+        "shell_20x16": lambda: M.shell(20, 16), "kkt6": lambda: M.kkt(6), "shell_40x40": lambda: M.shell(40, 40),
+        "kkt8": lambda: M.kkt(8), "kkt10": lambda: M.kkt(10),
+        "poisson12c": lambda: M.poisson3d(12, dtype=np.complex128, shift=0.5j)}
+
+
+def check_against_single_rank(out, spec, nb, vtype="r64", exchange=True):
+    """Factors of the N-rank run (sum over the ranks' blocks) against ONE rank on the oracle: 1e-12 of the largest entry, same
+    structural flop count, every update ran exactly once somewhere, bytes sent = bytes received."""
+    z = np.load(out)
+    n = len(z["L_ptr"]) - 1  # n_padded: a block-aligned dissection adds isolated unit rows
+    ref = factorize(GENS[spec](), nb, oracle_library(vtype), vtype=vtype, ordering="nd")
+    L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
+    U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
+    assert int(z["flop"]) == ref["info"]["flop"]
+    assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
+    assert float(z["residual"]) < 1e-12
+    assert sum(z["sent"]) == sum(z["recv"])
+    if exchange:
+        assert sum(z["recv"]) > 0
+    assert sum(z["tasks"]) == ref["info"]["ntask_ssssm"]
+    return z
+
+
+# (world, matrix, nb, value type).  The 8-rank rows are the reference's 2 x 4 grid (src/pangulu.c:83-90: p = the largest
+# divisor of the rank count not above its square root) on the classes of BASELINE configs[3] (KKT, R64) and configs[4]
+# (complex Poisson, CR64).
+DEFAULT_MAP_CASES = [(2, "fem27_6", 32, "r64"), (2, "kkt6", 16, "r64"), (3, "shell_8x7", 24, "r64"), (3, "fem27_9", 16, "r64"),
+                     (4, "fem27_9", 16, "r64"), (4, "shell_20x16", 24, "r64"), (4, "kkt6", 16, "r64"), (2, "poisson12c", 32, "cr64"),
+                     (8, "fem27_9", 16, "r64"), (8, "shell_40x40", 32, "r64"), (8, "kkt8", 16, "r64"), (8, "poisson12c", 32, "cr64")]
+
+
+@pytest.mark.parametrize("distribute_us", [None, "0"])
+@pytest.mark.parametrize("world,spec,nb,vtype", DEFAULT_MAP_CASES)
+def test_default_map_matches_single_rank(tmp_path, world, spec, nb, vtype, distribute_us):
+    """PANGULU_AMD_SEPARATOR_MAP unset (= "group", what `bench.py --gpus N` runs): rank groups that shrink down the tree, heavy
+    separators 2D block-cyclic over their group's p x q grid, light ones on the least loaded rank of the group.  With
+    PANGULU_AMD_DISTRIBUTE_US=0 EVERY separator counts as heavy, so that the small test matrices exercise the distributed
+    separators at every level of the tree (sub-groups of 4 and 2 ranks under the root's 2 x 4 grid at 8 ranks); unset, the
+    product's own threshold decides.  Forwarding: src/pangulu_numeric.c:452-517,535-600."""
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, vtype=vtype, separators=None,
+              extra_env={"PANGULU_AMD_DISTRIBUTE_US": distribute_us} if distribute_us is not None else None)
+    z = check_against_single_rank(out, spec, nb, vtype, exchange=distribute_us is not None)
+    if distribute_us is not None:
+        assert all(t > 0 for t in z["tasks"]), "a rank ran no update: %s" % list(z["tasks"])
+
+
+@pytest.mark.parametrize("world,spec,nb,vtype", [(8, "kkt10", 16, "r64"), (8, "poisson12c", 24, "cr64")])
+def test_two_by_four_block_cyclic_grid(tmp_path, world, spec, nb, vtype):
+    """The reference's own ownership rule on its 2 x 4 grid: PANGULU_AMD_SUBTREE_MAP=0 = owner(i, j) = (i mod 2) * 4 + (j mod 4)
+    for EVERY block (src/pangulu.c:83-90, src/pangulu_common.h:135), forwarding along process rows / columns restricted to the
+    ranks that consume the block."""
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, vtype=vtype, separators=None, extra_env={"PANGULU_AMD_SUBTREE_MAP": "0"})
+    z = check_against_single_rank(out, spec, nb, vtype)
+    assert all(t > 0 for t in z["tasks"])
 
 
 @pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (2, "trefethen", 4), (4, "poisson8", 32), (4, "trefethen", 4),
@@ -83,8 +146,8 @@ def test_multirank_matches_single_rank(tmp_path, world, spec, nb):
 @pytest.mark.parametrize("separators", ["path", "rank0"])
 @pytest.mark.parametrize("world,spec,nb", [(2, "shell_20x16", 24), (4, "shell_40x40", 32), (3, "fem27_9", 16), (4, "kkt6", 16)])
 def test_separator_maps(tmp_path, world, spec, nb, separators):
-    """The separators above the mapped subtrees on the rank of their heaviest child (the default) / all on rank 0: same factors
-    as one rank, bytes sent = bytes received, every update ran somewhere."""
+    """The separators above the mapped subtrees on the rank of their heaviest child ("path", round 2's default) / all on rank 0:
+    same factors as one rank, bytes sent = bytes received, every update ran somewhere."""
     out = str(tmp_path / "out.npz")
     run_ranks(world, spec, nb, out, separators=separators)
     z = np.load(out)
@@ -121,7 +184,7 @@ def test_multirank_on_the_gpu_host_staged(tmp_path, world, spec, nb):
 @pytest.mark.parametrize("separators", ["path", "rank0"])
 @pytest.mark.parametrize("world,spec,nb", [(2, "shell_40x40", 128), (4, "shell_40x40", 256), (3, "fem27_9", 128)])
 def test_separator_maps_on_the_gpu(tmp_path, world, spec, nb, separators):
-    """The default separator mapping (and "rank0") with the HIP back-end and the peer-copy transport, dense paths engaged."""
+    """The "path" and "rank0" separator mappings with the HIP back-end and the peer-copy transport, dense paths engaged."""
     out = str(tmp_path / "out.npz")
     run_ranks(world, spec, nb, out, platform="hip", transport="ipc", separators=separators)
     z = np.load(out)
@@ -134,6 +197,36 @@ def test_separator_maps_on_the_gpu(tmp_path, world, spec, nb, separators):
     assert float(z["residual"]) < 1e-12
     assert sum(z["sent"]) == sum(z["recv"])
     assert sum(z["tasks"]) == ref["info"]["ntask_ssssm"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("distribute_us", [None, "0"])
+@pytest.mark.parametrize("world,spec,nb,vtype,transport", [
+    (2, "fem27_9", 128, "r64", "ipc"), (2, "kkt6", 64, "r64", "host"), (4, "shell_40x40", 256, "r64", "ipc"), (4, "fem27_9", 128, "r64", "host"),
+    (4, "kkt8", 64, "r64", "ipc"), (2, "poisson12c", 128, "cr64", "host"),
+    (8, "fem27_9", 128, "r64", "ipc"), (8, "shell_40x40", 256, "r64", "host"), (8, "kkt10", 64, "r64", "ipc"), (8, "poisson12c", 128, "cr64", "ipc")])
+def test_default_map_on_the_gpu(tmp_path, world, spec, nb, vtype, transport, distribute_us):
+    """The default mapping (PANGULU_AMD_SEPARATOR_MAP unset = "group") with the HIP back-end, 2 / 4 / 8 ranks sharing the box's
+    GPU, over peer copies and host staging; the 8-rank rows run the root separator on the reference's 2 x 4 grid (KKT R64 and
+    complex Poisson CR64: the classes of BASELINE configs[3] and [4]).  Factors against ONE rank on the oracle at 1e-12, bytes
+    sent = received, every update ran once."""
+    from pangulu_amd import _lib
+
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, vtype=vtype, platform="hip", transport=transport, separators=None,
+              extra_env={"PANGULU_AMD_DISTRIBUTE_US": distribute_us} if distribute_us is not None else None)
+    z = check_against_single_rank(out, spec, nb, vtype, exchange=distribute_us is not None)
+    assert int(z["transport"]) == (_lib.TRANSPORT_IPC if transport == "ipc" else _lib.TRANSPORT_HOST)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,spec,nb,vtype,transport", [(8, "kkt10", 64, "r64", "ipc"), (8, "poisson12c", 128, "cr64", "host")])
+def test_two_by_four_block_cyclic_grid_on_the_gpu(tmp_path, world, spec, nb, vtype, transport):
+    """PANGULU_AMD_SUBTREE_MAP=0: every block by the reference's rule on its 2 x 4 grid, HIP back-end."""
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, vtype=vtype, platform="hip", transport=transport, separators=None,
+              extra_env={"PANGULU_AMD_SUBTREE_MAP": "0"})
+    check_against_single_rank(out, spec, nb, vtype)
 
 
 @pytest.mark.gpu
