@@ -65,6 +65,8 @@ def parse_args(argv=None):
     ap.add_argument("--rhs", default=None, help="right-hand side file (examples/example.c:167-243); default b = A*1")
     ap.add_argument("--nb", type=int, default=256)
     ap.add_argument("--ordering", default="nd", choices=["nd", "identity"])
+    ap.add_argument("--no-coords", action="store_true", help="withhold the generator's mesh coordinates from the ordering: the graph-only "
+                    "nested dissection (multilevel vertex separators) that a matrix file without coordinates gets")
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -113,7 +115,7 @@ def make_matrix(args, M):
 def workload_key(args):
     if args.mtx:
         return "file:%s" % os.path.basename(args.mtx)
-    return "%s(%s) nb=%d %s" % (args.workload, ",".join(map(str, default_sizes(args))), args.nb, args.ordering)
+    return "%s(%s) nb=%d %s%s" % (args.workload, ",".join(map(str, default_sizes(args))), args.nb, args.ordering, " no-coords" if args.no_coords else "")
 
 
 def kernel_source_hash():
@@ -241,7 +243,7 @@ def cpu_leg_main(args):
     tlib.pangulu_amd_test_set_task_sampling(stride)
     nthreads = max(1, (os.cpu_count() or 1) // R)
     h = pa.pangulu_init(n, len(va) if va is not None else 0, cp, ri, va, nb=args.nb, ordering=args.ordering,
-                        coords=co if args.ordering == "nd" else None, nthread=nthreads, lib=tlib)
+                        coords=co if args.ordering == "nd" and not args.no_coords else None, nthread=nthreads, lib=tlib)
     t0 = time.time()
     pa.pangulu_gstrf(h)
     dt = time.time() - t0
@@ -274,6 +276,8 @@ def run_cpu_leg(args, R, rank, port, stride):
     """Start this rank's child of an R-rank cpu_baseline leg; returns the Popen (rank 0's stdout carries the result)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(R), "--cpu-leg-port", str(port), "--cpu-leg-stride", str(stride),
            "--workload", args.workload, "--nb", str(args.nb), "--ordering", args.ordering]
+    if args.no_coords:
+        cmd.append("--no-coords")
     if args.size:
         cmd += ["--size"] + [str(s) for s in args.size]
     if args.mtx:
@@ -339,6 +343,8 @@ def passthrough_args(args):
         out += ["--rhs", args.rhs]
     if args.no_profile_pass:
         out.append("--no-profile-pass")
+    if args.no_coords:
+        out.append("--no-coords")
     return out
 
 
@@ -484,7 +490,7 @@ def gpu_worker_main(args):
     lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 0)
     t0 = time.time()
     h = pa.pangulu_init(n, len(va) if va is not None else 0, cp, ri, va, nb=args.nb, ordering=args.ordering,
-                        coords=coords if args.ordering == "nd" else None, nthread=nthreads)
+                        coords=coords if args.ordering == "nd" and not args.no_coords else None, nthread=nthreads)
     t_init = time.time() - t0
     # what is really in use: ipc / rccl fall back to host staging on all ranks together when their self-test fails
     effective_transport = {0: "host", 1: "rccl", 2: "ipc"}[lib.pangulu_amd_comm_transport()] if world > 1 else "none"
@@ -635,7 +641,9 @@ def gpu_worker_main(args):
             "dtype": "f64", "data": "synthetic" if not args.mtx else "file",
             "config": {
                 "workload": workload, "n": int(info["n"]), "nnz": int(info["nnz"]), "nb": int(info["nb"]),
-                "ordering": "built-in nested dissection (geometric)" if args.ordering == "nd" else "identity",
+                "ordering": "identity" if args.ordering != "nd" else
+                            ("built-in nested dissection (geometric: median cuts along 13 lattice directions, FM-refined)" if coords is not None and not args.no_coords else
+                             "built-in nested dissection (graph only: multilevel vertex separators, no coordinates)"),
                 "symbolic_nnz": int(info["symbolic_nnz"]), "flop": int(info["flop"]),
                 "parallelism": ("one rank") if world == 1 else
                                {"group": "proportional mapping of the block elimination tree with rank groups that shrink down the tree: subtrees whose group "

@@ -1,0 +1,58 @@
+"""Quality of the built-in nested dissection (pg_ordering.cpp; the reference hands the graph to METIS_NodeND,
+src/pangulu_reordering.c:1065-1089).  F = sum_k (c_k + 2 c_k^2) is the numerator of the headline metric and the work of the
+factorisation, so the ordering may not depend on the caller knowing mesh coordinates: the graph-only dissection (multilevel vertex
+separators) has to stay within 1.3x of the geometric one, and the geometric one may not lose to the graph's (7-point meshes: the
+smallest separators are diagonal, not axis planes).  Analysis-only handles on the CPU, nb = 256 as in the bench."""
+import os
+
+import pytest
+
+import pangulu_amd as pa
+from pangulu_amd import matrices as M
+
+from .helpers import library_for, oracle_library
+
+
+@pytest.fixture
+def tlib():
+    lib = library_for(oracle_library("r64"))
+    os.environ["PANGULU_AMD_ANALYSIS_ONLY"] = "1"
+    yield lib
+    os.environ.pop("PANGULU_AMD_ANALYSIS_ONLY", None)
+
+
+def analysis(lib, mat, coords):
+    n, cp, ri, va, co = mat
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=256, ordering="nd", coords=co if coords else None, lib=lib, nthread=4)
+    info = h.info()
+    perm = pa.permutation(h)
+    pa.pangulu_finalize(h)
+    assert sorted(perm.tolist()) == list(range(len(perm)))
+    return float(info["flop"]), int(info["symbolic_nnz"])
+
+
+# (matrix, F(graph) / F(coords) at most, F(coords) / F(graph) at most, F(coords) at most: the values of the round this test was written in, +3 %)
+CASES = [("fem27_40", lambda: M.fem27(40), 1.3, 1.1, 5.4e10), ("shell_120", lambda: M.shell(120, 120), 1.3, 1.1, 1.37e10),
+         ("poisson3d_48", lambda: M.poisson3d(48), 1.3, 1.1, 5.6e10), ("kkt_16", lambda: M.kkt(16), 1.3, 1.1, 1.02e8)]
+
+
+@pytest.mark.parametrize("name,gen,graph_over_coords,coords_over_graph,f_coords_max", CASES, ids=[c[0] for c in CASES])
+def test_graph_only_ordering_is_close_to_the_geometric_one(tlib, name, gen, graph_over_coords, coords_over_graph, f_coords_max):
+    mat = gen()
+    f_c, fill_c = analysis(tlib, mat, True)
+    f_g, fill_g = analysis(tlib, mat, False)
+    assert f_g <= graph_over_coords * f_c, (name, f_g, f_c)
+    assert f_c <= coords_over_graph * f_g, (name, f_c, f_g)
+    assert f_c <= f_coords_max, (name, f_c)
+
+
+def test_the_ordering_is_a_function_of_the_matrix_alone(tlib):
+    """Same matrix, different thread counts: the same permutation (the regions' random choices are seeded from their vertices,
+    never from the schedule of the OpenMP tasks that dissect them)."""
+    n, cp, ri, va, co = M.fem27(30)  # (large enough for the halves to be dissected by concurrent tasks)
+    perms = []
+    for threads in (1, 4):
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=64, ordering="nd", coords=None, lib=tlib, nthread=threads)
+        perms.append(pa.permutation(h).tolist())
+        pa.pangulu_finalize(h)
+    assert perms[0] == perms[1]

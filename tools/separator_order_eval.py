@@ -1,5 +1,5 @@
 """Effect of the ordering inside separators on the 16 x 16 pieces of the factor blocks, from the symbolic pattern alone (CPU):
-    PANGULU_AMD_SEPARATOR_ORDER=natural python tools/separator_order_eval.py 56 ; python tools/separator_order_eval.py 56 [fem27|shell]"""
+    PANGULU_AMD_SEPARATOR_ORDER=natural python tools/separator_order_eval.py 56 ; python tools/separator_order_eval.py 56 [fem27|shell|poisson3d] [nocoords]"""
 import sys,os,time; sys.path.insert(0, '.')
 import numpy as np, pangulu_amd as pa
 from pangulu_amd import matrices as M
@@ -7,7 +7,8 @@ from tests.helpers import library_for, oracle_library
 lib = library_for(oracle_library("r64"))
 N=int(sys.argv[1]); nb=256
 which=sys.argv[2] if len(sys.argv)>2 else "fem27"
-mat=M.fem27(N) if which=="fem27" else M.shell(N,N); n,cp,ri,va,co=mat
+mat={"fem27":lambda:M.fem27(N),"shell":lambda:M.shell(N,N),"poisson3d":lambda:M.poisson3d(N)}[which](); n,cp,ri,va,co=mat
+if len(sys.argv)>3 and sys.argv[3]=="nocoords": co=None  # the graph-only ordering (separators ordered by pseudo-coordinates)
 h = pa.pangulu_init(n,len(va),cp,ri,va,nb=nb,ordering="nd",coords=co,lib=lib,nthread=8)
 info=h.info()
 blocks={}
