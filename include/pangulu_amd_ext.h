@@ -136,6 +136,11 @@ extern "C"
     int pangulu_amd_update_values(void **pangulu_handle, const sparse_value_t *csc_value);
     int pangulu_amd_snapshot(void **pangulu_handle);
     int pangulu_amd_reset_numeric(void **pangulu_handle);
+    /* One rank: pangulu_gstrf replays the handle's recorded launch schedule (default, environment PANGULU_AMD_REPLAY) or runs
+     * the scheduler beside the device like a multi-rank run has to (0).  A recording stays valid while replay is off.
+     * bench.py times a few steps either way so that the N = 1 line can be compared with N > 1 like for like.  Returns the
+     * previous setting. */
+    int pangulu_amd_set_replay(int on);
 
     /* ---- factor access (tests) ------------------------------------------------------------------------ */
     /* Block records this rank owns, in storage order.  Pointers are host pointers into the record and stay

@@ -206,6 +206,8 @@ def load(vtype="r64", test_hooks=False):
     lib.pangulu_amd_snapshot.restype = ctypes.c_int
     lib.pangulu_amd_reset_numeric.argtypes = [vpp]
     lib.pangulu_amd_reset_numeric.restype = ctypes.c_int
+    lib.pangulu_amd_set_replay.argtypes = [ctypes.c_int]
+    lib.pangulu_amd_set_replay.restype = ctypes.c_int
     lib.pangulu_amd_get_perm.argtypes = [vpp]
     lib.pangulu_amd_get_perm.restype = ctypes.POINTER(ctypes.c_uint32)
     lib.pangulu_amd_apply_lu.argtypes = [vpp, vp, vp]

@@ -295,6 +295,12 @@ extern "C"
         set_world(c);
         return 0;
     }
+    int pangulu_amd_set_replay(int on)
+    {
+        const int before = g_replay_enabled < 0 ? !(getenv("PANGULU_AMD_REPLAY") && atoi(getenv("PANGULU_AMD_REPLAY")) == 0) : g_replay_enabled;
+        g_replay_enabled = on ? 1 : 0;
+        return before;
+    }
     void pangulu_amd_comm_barrier(void) { world()->barrier(); }
     void pangulu_amd_comm_allreduce_max_f64(double *values, int count) { world()->allreduce_max_f64(values, count); }
     void pangulu_amd_comm_finalize(void) { set_world(nullptr); }

@@ -388,5 +388,6 @@ double task_structural_flop(u32 nb, const task_t &t);
 // Checker's build only (oracle/pangulu_amd_test_hooks.h): execute every stride-th task of each kernel class and skip the
 // rest -- a bounded, representative sample of the SAME factorisation for bench.py's cpu_baseline leg.  1 = everything.
 extern int g_task_sample_stride;
+extern int g_replay_enabled; // pangulu_amd_set_replay (-1: the environment decides)
 
 } // namespace pg

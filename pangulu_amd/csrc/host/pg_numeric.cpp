@@ -1064,9 +1064,12 @@ struct Sched
 
 } // namespace
 
+int g_replay_enabled = -1; // pangulu_amd_set_replay; -1: not set, PANGULU_AMD_REPLAY decides (default on)
+
 static bool schedule_possible(const Solver &S, Platform &plat)
 {
-    static const bool replay_on = !(getenv("PANGULU_AMD_REPLAY") && atoi(getenv("PANGULU_AMD_REPLAY")) == 0);
+    static const bool replay_env = !(getenv("PANGULU_AMD_REPLAY") && atoi(getenv("PANGULU_AMD_REPLAY")) == 0);
+    const bool replay_on = g_replay_enabled < 0 ? replay_env : g_replay_enabled != 0;
     return replay_on && S.nproc == 1 && !plat.host_memory && plat.schedule && g_task_sample_stride <= 1 && !S.eager_host_mirror && !S.analysis_only &&
            !getenv("PANGULU_AMD_FORCE_MULTI_LOOP");
 }

@@ -1809,6 +1809,157 @@ __global__ __launch_bounds__(64) void block_trsv_level_kernel(const SolveRowD *_
         xr[i] = seg[i];
 }
 
+// ---- round 4: the same two launches per level, rebuilt around where their time went (fem27(112): 540 launches, 394 ms) --------
+// The gather kernel walked a block column by column, sixteen lanes a column, every entry a floating-point atomic on the row's
+// 256 words in HBM (hundreds of blocks of a row near the root contend for them): 98 % of its wave cycles waiting.  The level kernel
+// swept a diagonal half column by column straight from HBM: nb dependent round trips.
+//  * gather: the block's entries flat over the workgroup (coalesced loads, the column of an entry by bisection in an LDS copy of the
+//    column pointers), products accumulated in LDS (ds_add_f64), ONE global atomic per touched row of the segment at the end;
+//  * level: the diagonal half streams through LDS in chunks of `ch` columns (rows for the upper sweep), double-buffered: three
+//    wavefronts fetch chunk k + 1 while the first one sweeps chunk k out of LDS -- a dependent step costs LDS round trips, not HBM ones.
+__global__ __launch_bounds__(256) void block_trsv_gather_flat_kernel(const SolveBlkD *__restrict__ blks, int nb, val_t *__restrict__ x)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    val_t *acc = reinterpret_cast<val_t *>(smem_raw);
+    val_t *xs = acc + nb;
+    u32 *cp = reinterpret_cast<u32 *>(xs + nb);
+    const SolveBlkD B = blks[blockIdx.x];
+    const val_t *xj = x + (size_t)B.bcol * nb;
+    val_t *xr = x + (size_t)B.brow * nb;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nb; i += 256)
+    {
+        acc[i] = v_make(0);
+        xs[i] = xj[i];
+    }
+    for (int i = tid; i <= nb; i += 256)
+        cp[i] = i == 0 ? 0u : B.cp[i];
+    __syncthreads();
+    const u32 nnz = cp[nb];
+    for (u32 p = (u32)tid; p < nnz; p += 256)
+    {
+        // column of entry p: the last c with cp[c] <= p
+        int lo = 0, hi = nb;
+        while (hi - lo > 1)
+        {
+            const int mid = (lo + hi) >> 1;
+            if (cp[mid] <= p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        lds_atomic_sub(&acc[B.ri[p]], v_mul(B.val[p], xs[lo]));
+    }
+    __syncthreads();
+    for (int i = tid; i < nb; i += 256)
+        v_atomic_add(&xr[i], acc[i]);
+}
+
+template <bool UPPER>
+__global__ __launch_bounds__(256) void block_trsv_level_chunked_kernel(const SolveRowD *__restrict__ rows, int nb, val_t *__restrict__ x, int ch)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const size_t cap = (size_t)ch * (size_t)nb; // entries a chunk can hold
+    val_t *seg = reinterpret_cast<val_t *>(smem_raw);
+    val_t *bv0 = seg + nb, *bv1 = bv0 + cap;
+    u32 *ptr = reinterpret_cast<u32 *>(bv1 + cap);
+    u16 *bi0 = reinterpret_cast<u16 *>(ptr + nb + 2), *bi1 = bi0 + cap;
+    const SolveRowD R = rows[blockIdx.x];
+    val_t *xr = x + (size_t)R.brow * nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < nb; i += 256)
+        seg[i] = xr[i];
+    for (int i = tid; i <= nb; i += 256)
+        ptr[i] = (!UPPER && i == 0) ? 0u : R.dptr[i];
+    __syncthreads();
+    const int nchunk = (nb + ch - 1) / ch;
+    // chunk k: columns [k ch, (k + 1) ch) of the lower half in ascending order; rows [nb - (k + 1) ch, nb - k ch) of the upper half, descending
+    auto lo_of = [&](int k) -> int { return UPPER ? max(0, nb - (k + 1) * ch) : k * ch; };
+    auto hi_of = [&](int k) -> int { return UPPER ? nb - k * ch : min(nb, (k + 1) * ch); };
+    auto fetch = [&](int k, int first, int nthr)
+    {
+        val_t *bv = (k & 1) ? bv1 : bv0;
+        u16 *bi = (k & 1) ? bi1 : bi0;
+        const u32 p0 = ptr[lo_of(k)], p1 = ptr[hi_of(k)];
+        for (u32 p = p0 + (u32)first; p < p1; p += (u32)nthr)
+        {
+            bv[p - p0] = R.dval[p];
+            bi[p - p0] = R.didx[p];
+        }
+    };
+    fetch(0, tid, 256);
+    __syncthreads();
+    for (int k = 0; k < nchunk; k++)
+    {
+        if (wave != 0)
+        {
+            if (k + 1 < nchunk)
+                fetch(k + 1, tid - 64, 192);
+        }
+        else
+        {
+            const val_t *bv = (k & 1) ? bv1 : bv0;
+            const u16 *bi = (k & 1) ? bi1 : bi0;
+            const int c0 = lo_of(k), c1 = hi_of(k);
+            const u32 base = ptr[c0];
+            if (!UPPER)
+            {
+                for (int c = c0; c < c1; c++)
+                {
+                    const u32 p0 = ptr[c] - base, p1 = ptr[c + 1] - base;
+                    if (p0 == p1)
+                        continue;
+                    const val_t xc = seg[c];
+                    for (u32 p = p0 + lane; p < p1; p += 64)
+                        seg[bi[p]] = v_submul(seg[bi[p]], bv[p], xc);
+                    wave_lds_fence();
+                }
+            }
+            else
+            {
+                for (int r = c1 - 1; r >= c0; r--)
+                {
+                    const u32 b = ptr[r] - base, e = ptr[r + 1] - base;
+                    if (b == e)
+                        continue;
+#ifdef PANGULU_COMPLEX
+                    val_t part = v_make(0);
+                    for (u32 p = b + 1 + lane; p < e; p += 64)
+                    {
+                        const val_t m = v_mul(bv[p], seg[bi[p]]);
+                        part.re += m.re;
+                        part.im += m.im;
+                    }
+                    for (int off = 32; off > 0; off >>= 1)
+                    {
+                        part.re += __shfl_down(part.re, off, 64);
+                        part.im += __shfl_down(part.im, off, 64);
+                    }
+#else
+                    val_t part = 0;
+                    for (u32 p = b + 1 + lane; p < e; p += 64)
+                        part += bv[p] * seg[bi[p]];
+                    for (int off = 32; off > 0; off >>= 1)
+                        part += __shfl_down(part, off, 64);
+#endif
+                    if (lane == 0)
+                    {
+                        val_t d = bv[b];
+                        const real_t dr = v_realpart(d);
+                        if (!((dr < 0 ? -dr : dr) > (real_t)PANGULU_SPTRSV_TOL))
+                            d = v_make((real_t)PANGULU_SPTRSV_TOL);
+                        seg[r] = v_div(v_sub(seg[r], part), d);
+                    }
+                    wave_lds_fence();
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nb; i += 256)
+        xr[i] = seg[i];
+}
+
 struct DiagAux // column view of a diagonal block's upper (CSR) half, built on first use
 {
     u32 *d_cp = nullptr;
@@ -4301,11 +4452,41 @@ extern "C"
         HIP_CHECK(hipMemcpyAsync(d_blks, hb.data(), sizeof(SolveBlkD) * hb.size(), hipMemcpyHostToDevice, B.stream));
         HIP_CHECK(hipMemcpyAsync(d_x, x, sizeof(val_t) * (size_t)xlen, hipMemcpyHostToDevice, B.stream));
         const size_t lds = sizeof(val_t) * (size_t)nb;
+        // round 4 kernels (PANGULU_HIP_SOLVE_CHUNKED=0: the column-by-column ones): chunks of `ch` columns of a diagonal half
+        // through at most 96 KB of LDS
+        static const bool chunked_on = !(getenv("PANGULU_HIP_SOLVE_CHUNKED") && atoi(getenv("PANGULU_HIP_SOLVE_CHUNKED")) == 0);
+        const size_t per_col = 2 * (size_t)nb * (sizeof(val_t) + sizeof(u16)); // both buffers
+        int ch = (int)std::min<size_t>(16, ((size_t)96 << 10) / per_col);
+        ch = std::min(ch, (int)nb);
+        const bool chunked = chunked_on && ch >= 1;
+        const size_t lds_level = sizeof(val_t) * (size_t)nb + 2 * (size_t)ch * nb * (sizeof(val_t) + sizeof(u16)) + sizeof(u32) * ((size_t)nb + 2) + 16;
+        const size_t lds_gather = 2 * sizeof(val_t) * (size_t)nb + sizeof(u32) * ((size_t)nb + 1);
+        if (chunked)
+        {
+            static size_t allowed = 0;
+            if (lds_level > allowed)
+            {
+                HIP_CHECK(hipFuncSetAttribute((const void *)block_trsv_level_chunked_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_level));
+                HIP_CHECK(hipFuncSetAttribute((const void *)block_trsv_level_chunked_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_level));
+                HIP_CHECK(hipFuncSetAttribute((const void *)block_trsv_gather_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds_gather, (size_t)1)));
+                allowed = lds_level;
+            }
+        }
         for (size_t l = 0; l < (size_t)nlevel; l++)
         {
             const size_t n = (size_t)(level_ptr[l + 1] - level_ptr[l]), nbl = blk_level_ptr[l + 1] - blk_level_ptr[l];
             if (!n)
                 continue;
+            if (chunked)
+            {
+                if (nbl)
+                    hipLaunchKernelGGL(block_trsv_gather_flat_kernel, dim3((unsigned)nbl), dim3(256), lds_gather, B.stream, d_blks + blk_level_ptr[l], (int)nb, d_x);
+                if (upper)
+                    hipLaunchKernelGGL(block_trsv_level_chunked_kernel<true>, dim3((unsigned)n), dim3(256), lds_level, B.stream, d_rows + level_ptr[l], (int)nb, d_x, ch);
+                else
+                    hipLaunchKernelGGL(block_trsv_level_chunked_kernel<false>, dim3((unsigned)n), dim3(256), lds_level, B.stream, d_rows + level_ptr[l], (int)nb, d_x, ch);
+                continue;
+            }
             if (nbl)
                 hipLaunchKernelGGL(block_trsv_gather_kernel, dim3((unsigned)nbl), dim3(256), 0, B.stream, d_blks + blk_level_ptr[l], (int)nb, d_x);
             if (upper)
