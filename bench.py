@@ -69,6 +69,8 @@ def parse_args(argv=None):
                     "nested dissection (multilevel vertex separators) that a matrix file without coordinates gets")
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workload of the default run (the ldoor-class matrix of "
+                    "BASELINE configs[1], 3 steps): its line rides in the JSON line as `secondary`")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-sample-stride", type=int, default=0,
                     help="CPU baseline: execute every k-th task of each kernel class of the SAME factorisation (0: sized for about "
@@ -343,6 +345,8 @@ def passthrough_args(args):
         out += ["--rhs", args.rhs]
     if args.no_profile_pass:
         out.append("--no-profile-pass")
+    if args.no_secondary:
+        out.append("--no-secondary")
     if args.no_coords:
         out.append("--no-coords")
     return out
@@ -527,6 +531,7 @@ def gpu_worker_main(args):
     info = h.info()
     used = ctypes.c_size_t(0)
     lib.pangulu_platform_0201001_get_device_memory_usage(ctypes.byref(used))  # records + receive bins + mirror pool + snapshot
+    mem = pa.hip_memory(lib)
 
     # the two correctness criteria of the reference on the factors the last timed step left on the device(s)
     factor_check = pa.factor_check(h) if args.steps > 0 else None   # ||L(U 1) - A 1|| / ||A 1||  (src/pangulu_numeric.c:1082-1341)
@@ -569,6 +574,7 @@ def gpu_worker_main(args):
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_RECORDS_STREAM, 0)
         one_step()
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_PROFILE, 0)
+        lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_COUNT_FLOPS, 0)  # (back to the timed configuration: the secondary workload records under it)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_TWO_STREAMS, 1)
         lib.pangulu_platform_0201001_set_option(_lib.HIP_OPT_RECORDS_STREAM, 1)
         st = pa.hip_stats(lib, reset=True)
@@ -643,6 +649,38 @@ def gpu_worker_main(args):
         roofline["model_alg_GB"] = model["alg_GB"]
 
     pa.pangulu_finalize(h)
+
+    # Secondary workload of the DEFAULT run (one rank, default matrix): BASELINE configs[1]'s class -- ldoor, n = 952 K, one GPU --
+    # on its stand-in shell(398,398), 3 timed steps behind 1 warm-up, residual from the last one.  A latency-bound matrix (thin
+    # shell: small fronts, long chains near the root) beside the MFMA-bound headline one.
+    secondary = None
+    if world == 1 and not args.no_secondary and not args.mtx and not args.size and args.workload == "fem27" and not args.no_coords and args.steps > 0:
+        n2, cp2, ri2, va2, co2 = M.shell(398, 398)
+        t0 = time.time()
+        h2 = pa.pangulu_init(n2, len(va2), cp2, ri2, va2, nb=args.nb, ordering="nd", coords=co2, nthread=nthreads)
+        t_init2 = time.time() - t0
+        assert lib.pangulu_amd_snapshot(h2.ref) == 0
+        ts2 = []
+        for s2 in range(4):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            pa.pangulu_gstrf(h2)
+            torch.cuda.synchronize()
+            ts2.append(time.perf_counter() - t)
+            if s2 < 3:
+                lib.pangulu_amd_reset_numeric(h2.ref)
+        info2 = h2.info()
+        fc2 = pa.factor_check(h2)
+        b2 = M.rhs_of_ones(n2, cp2, ri2, va2)
+        t = time.perf_counter()
+        x2 = pa.pangulu_gstrs(h2, b2)
+        gstrs2 = time.perf_counter() - t
+        ms2 = 1e3 * sum(ts2[1:]) / 3
+        secondary = [{"workload": "ldoor-class stand-in: shell(398,398) 2 layers x 3 dofs", "n": int(info2["n"]), "nnz": int(info2["nnz"]), "nb": int(info2["nb"]),
+                      "flop": int(info2["flop"]), "steps": 3, "warmup": 1, "ms_per_step": ms2, "step_ms": [round(1e3 * t_, 2) for t_ in ts2[1:]],
+                      "value": float(info2["flop"]) / (ms2 / 1e3) / 1e9, "unit": "GFLOP/s", "residual": M.relative_residual(n2, cp2, ri2, va2, x2, b2),
+                      "factor_check": fc2, "gstrs_s": gstrs2, "init_s": round(t_init2, 2), "static_schedule_replayed": bool(info2["replayed"])}]
+        pa.pangulu_finalize(h2)
     if world > 1:
         lib.pangulu_amd_comm_barrier()
         lib.pangulu_amd_comm_finalize()
@@ -681,6 +719,12 @@ def gpu_worker_main(args):
             "checked": "residual and factor_check are from the factors of the last timed step (timed configuration)",
             "init_s": round(t_init, 2),
             "hbm_used_GB": round(used.value / 1e9, 2), "owned_records_GB": round(info["owned_bytes"] / 1e9, 2),
+            # where the memory in use is: the records (authoritative form of every block), bench.py's own device-side snapshot of
+            # them (restored between steps; a user has none), the dense mirrors, the recorded schedule's descriptors
+            "hbm_breakdown_GB": {"records": round(info["owned_bytes"] / 1e9, 2), "bench_snapshot_of_records": round(info["snapshot_device_bytes"] / 1e9, 2),
+                                 "dense_mirror_pool": round(mem["mirror_pool_bytes"] / 1e9, 2), "dense_mode_blocks": mem["dense_mode_blocks"],
+                                 "schedule_descriptors": round(mem["schedule_descriptor_bytes"] / 1e9, 2),
+                                 "getrf_scratch": round(mem["getrf_scratch_bytes"] / 1e9, 2)},
             "host_sched_s_last_step": round(info["time_numeric_host_sched"], 4),
             # one rank: the first pangulu_gstrf of the handle (a warm-up step) recorded its launches, the timed steps replay the list
             "static_schedule_replayed": bool(info["replayed"]), "schedule_record_s": round(info["time_schedule_record"], 2),
@@ -688,6 +732,7 @@ def gpu_worker_main(args):
             "roofline": roofline,
             "model": model,
             "kernels": kernels,
+            "secondary": secondary,
             "cpu_baseline": None,  # (filled in by the supervisor)
         }
         print(json.dumps(line), flush=True)

@@ -111,6 +111,7 @@ extern "C"
         double model_sent_bytes_total;        /* bytes of block records forwarded between ranks                         */
         double model_critical_path;           /* longest dependent chain of tasks, each at its own T*_t, seconds        */
         unsigned long long model_critical_path_tasks; /* ... and its length in tasks                                    */
+        unsigned long long snapshot_device_bytes;     /* bytes of device memory pangulu_amd_snapshot holds (0: none, or kept on the host) */
     } pangulu_amd_info_t;
     void pangulu_amd_get_info(void **pangulu_handle, pangulu_amd_info_t *out);
     /* evaluate T* = sum_t max(bytes_t / BW, flop_t / P) over this rank's task list (structure only) */

@@ -355,6 +355,10 @@ extern "C"
         unsigned long long chase_launches, chase_solves;
     } pangulu_hip_stats_t;
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset);
+    /* Device memory the BACK-END holds for itself, in bytes (the host's records, receive bins and snapshots are the host's
+     * allocations): [0] the dense-mirror pool (chunks allocated so far), [1] HBM twins of the descriptor segments of a recorded
+     * schedule, [2] GETRF scratch images, [3] the most mirrors (blocks in dense mode) in use at once. */
+    void pangulu_platform_0201001_get_memory(unsigned long long out[4]);
 
 #ifdef __cplusplus
 }

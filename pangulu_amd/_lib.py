@@ -91,6 +91,7 @@ class Info(ctypes.Structure):
         ("model_sent_bytes_total", ctypes.c_double),
         ("model_critical_path", ctypes.c_double),
         ("model_critical_path_tasks", ctypes.c_ulonglong),
+        ("snapshot_device_bytes", ctypes.c_ulonglong),
     ]
 
     def as_dict(self):

@@ -803,14 +803,35 @@ extern "C"
             if (plat.host_memory)
                 S->arena_snapshot = (char *)malloc(S->storage.arena_bytes);
             else
-                plat.malloc_((void **)&S->arena_snapshot, S->storage.arena_bytes);
+            {
+                // Where the copy lives (PANGULU_AMD_SNAPSHOT=device|host|auto): on the device a reset is one pass over HBM, but it
+                // doubles the footprint of the records -- with `auto` (default) only while three times the records still fit what
+                // is free now (records + copy + room for the dense mirrors); otherwise in host memory (a reset is then an upload).
+                const char *mode = getenv("PANGULU_AMD_SNAPSHOT");
+                bool on_host = mode && strcmp(mode, "host") == 0;
+                if (!mode || strcmp(mode, "auto") == 0)
+                {
+                    size_t used = 0;
+                    plat.get_device_memory_usage(&used);
+                    const size_t total = (size_t)288 << 30; // (MI355X; only the order of magnitude matters here)
+                    on_host = used + 3 * S->storage.arena_bytes > total;
+                }
+                S->snapshot_on_host = on_host;
+                if (on_host)
+                    S->arena_snapshot = (char *)malloc(S->storage.arena_bytes);
+                else
+                    plat.malloc_((void **)&S->arena_snapshot, S->storage.arena_bytes);
+                if (!S->arena_snapshot)
+                    return 1;
+            }
         }
         if (plat.host_memory)
             plat.memcpy_(S->arena_snapshot, S->storage.darena, S->storage.arena_bytes, 2);
         else
             for (size_t c = 0; c < S->storage.dchunks.size(); c++)
-                plat.memcpy_(S->arena_snapshot + c * S->storage.dchunk_bytes, S->storage.dchunks[c], S->storage.chunk_len(c), 2);
+                plat.memcpy_(S->arena_snapshot + c * S->storage.dchunk_bytes, S->storage.dchunks[c], S->storage.chunk_len(c), S->snapshot_on_host ? 1 : 2);
         plat.synchronize();
+        S->info.snapshot_device_bytes = (plat.host_memory || S->snapshot_on_host) ? 0 : S->storage.arena_bytes;
         return 0;
     }
 
@@ -825,7 +846,7 @@ extern "C"
             plat.memcpy_(S->storage.darena, S->arena_snapshot, S->storage.arena_bytes, 2);
         else
             for (size_t c = 0; c < S->storage.dchunks.size(); c++)
-                plat.memcpy_(S->storage.dchunks[c], S->arena_snapshot + c * S->storage.dchunk_bytes, S->storage.chunk_len(c), 2);
+                plat.memcpy_(S->storage.dchunks[c], S->arena_snapshot + c * S->storage.dchunk_bytes, S->storage.chunk_len(c), S->snapshot_on_host ? 0 : 2);
         plat.synchronize();
         S->remain = S->remain0;
         S->remain_diag = S->remain_diag0;

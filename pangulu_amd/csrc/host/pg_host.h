@@ -334,7 +334,8 @@ struct Solver
     u64 pending_total = 0;
     bool factored = false, host_values_current = true;
     bool schedule_recorded = false;        // the back-end holds the launch list of this handle's factorisation (one rank)
-    char *arena_snapshot = nullptr;        // pristine copy of the owned records (device side), see pangulu_amd_snapshot
+    char *arena_snapshot = nullptr;        // pristine copy of the owned records, see pangulu_amd_snapshot
+    bool snapshot_on_host = false;         // ... kept in host memory (PANGULU_AMD_SNAPSHOT, or too little HBM for a device copy)
     // statistics
     pangulu_amd_info_t info;
     TaskModel model;

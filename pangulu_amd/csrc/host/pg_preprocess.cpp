@@ -1009,7 +1009,7 @@ Solver::~Solver()
         plat.schedule(0, this); // the recorded launches point into this handle's arena and mirrors
     if (arena_snapshot)
     {
-        if (plat.host_memory)
+        if (plat.host_memory || snapshot_on_host)
             free(arena_snapshot);
         else
             plat.free_(arena_snapshot);

@@ -109,7 +109,7 @@ struct MirrorPool
 {
     std::vector<char *> chunks;
     size_t chunk_bytes = 0, cursor = 0, mirror_bytes = 0; // cursor counts mirrors handed out since the last reset
-    size_t limit_mirrors = 0;
+    size_t limit_mirrors = 0, peak = 0; // peak: most mirrors in use at once since the pool was (re)started
     BlockTable blocks; // key: d_value of the (lower half of the) block
     std::vector<MirrorJobD> to_densify, to_sparsify;
 };
@@ -179,6 +179,7 @@ double *obtain_mirror(BlockState &st, int nb)
                            { st.mirror = nullptr; });
         MP.mirror_bytes = mb;
         MP.cursor = 0;
+        MP.peak = 0;
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         const char *frac_env = getenv("PANGULU_HIP_MIRROR_FRACTION");
@@ -202,6 +203,7 @@ double *obtain_mirror(BlockState &st, int nb)
         MP.chunks.push_back(c);
     }
     MP.cursor++;
+    MP.peak = std::max(MP.peak, MP.cursor);
     st.mirror = reinterpret_cast<double *>(MP.chunks[chunk] + slot * mb);
     return st.mirror;
 }

@@ -1765,6 +1765,18 @@ extern "C"
         return (void *)B.stream;
     }
 
+    void pangulu_platform_0201001_get_memory(unsigned long long out[4])
+    {
+        std::lock_guard<std::mutex> g(B.mutex);
+        out[0] = out[1] = out[2] = out[3] = 0;
+#if defined(PG_DENSE_UPDATES)
+        out[0] = (unsigned long long)MP.chunks.size() * MP.chunk_bytes;
+        out[3] = (unsigned long long)MP.peak;
+#endif
+        out[1] = (unsigned long long)REC.descriptor_bytes;
+        out[2] = B.getrf_scratch ? (unsigned long long)B.getrf_scratch_slots * std::max(sizeof(val_t), sizeof(double)) * (size_t)B.nb_cfg * B.nb_cfg : 0ull;
+    }
+
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset)
     {
         flush_pending_getrf_locked();

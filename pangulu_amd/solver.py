@@ -199,6 +199,15 @@ def factor_check(h):
     return float(out.value)
 
 
+def hip_memory(h_or_lib):
+    """Device memory the back-end holds for itself (bytes): mirror pool, descriptor twins of a recorded schedule, GETRF scratch;
+    and the number of blocks in dense mode."""
+    lib = h_or_lib.lib if isinstance(h_or_lib, Handle) else h_or_lib
+    v = (ctypes.c_ulonglong * 4)()
+    lib.pangulu_platform_0201001_get_memory(v)
+    return {"mirror_pool_bytes": int(v[0]), "schedule_descriptor_bytes": int(v[1]), "getrf_scratch_bytes": int(v[2]), "dense_mode_blocks": int(v[3])}
+
+
 def hip_stats(h_or_lib, reset=False):
     lib = h_or_lib.lib if isinstance(h_or_lib, Handle) else h_or_lib
     st = _lib.HipStats()

@@ -45,6 +45,8 @@ SWITCHES = [
     {"PANGULU_HIP_CHASE": "1", "PANGULU_HIP_CHASE_MAX_GETRF": "256", "_matrix": "fem27"},
     {"PANGULU_AMD_SEPARATOR_ORDER": "natural", "_matrix": "fem27"},  # separators in the mesh's numbering (default: k-d order)
     {"PANGULU_HIP_HEAVY_FIRST": "0", "_matrix": "fem27"},              # update work items in the scheduler's order
+    {"PANGULU_HIP_SOLVE_CHUNKED": "0"},        # rounds 2-3's triangular-solve kernels (column by column from HBM)
+    {"PANGULU_AMD_ND_DIAGONALS": "0", "PANGULU_AMD_ND_POLISH": "0", "_matrix": "fem27"},  # rounds 1-3's geometric cuts: axes only, no FM
 ]
 
 

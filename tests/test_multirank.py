@@ -279,10 +279,13 @@ def test_multirank_snapshot_reset_and_second_factorisation(tmp_path, world, spec
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("snapshot", ["device", "host"])
 @pytest.mark.parametrize("world,spec,nb,transport", [(2, "fem27_9", 128, "ipc"), (4, "shell_40x40", 256, "ipc"), (2, "kkt6", 64, "host")])
-def test_multirank_on_the_gpu_snapshot_reset_and_second_factorisation(tmp_path, world, spec, nb, transport):
+def test_multirank_on_the_gpu_snapshot_reset_and_second_factorisation(tmp_path, world, spec, nb, transport, snapshot):
+    """`snapshot`: where pangulu_amd_snapshot keeps the pristine records (PANGULU_AMD_SNAPSHOT): a second copy in HBM, or host
+    memory (what `auto` picks when three times the records would not fit: a reset is then an upload)."""
     out = str(tmp_path / "out.npz")
-    run_ranks(world, spec, nb, out, platform="hip", transport=transport, repeat=True)
+    run_ranks(world, spec, nb, out, platform="hip", transport=transport, repeat=True, extra_env={"PANGULU_AMD_SNAPSHOT": snapshot})
     z = np.load(out)
     ref = factorize(GENS[spec](), nb, oracle_library("r64"), ordering="nd")
     n = len(z["L_ptr"]) - 1
