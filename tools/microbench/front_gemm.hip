@@ -43,6 +43,7 @@ __device__ unsigned long long g_probe[8];
 #include "../../pangulu_amd/csrc/platform/pg_hip_dense.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_front.h"
 #include "../experiments/front_k32.h"
+#include "../experiments/front_n64.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 struct Problem
@@ -157,6 +158,13 @@ void launch(int which, Problem &X)
         CK(hipGetLastError());
         return;
     }
+    if (which >= 40000)
+    {
+        // EXPERIMENT (tools/experiments/front_n64.h): 128 x 64 tiles, four wavefronts per workgroup, three workgroups per CU
+        hipLaunchKernelGGL(ssssm_front_n64_f64_kernel, dim3(2 * grid), dim3(F64N_THREADS), 0, 0, X.dT, X.nb, X.dW, none, 4u * (unsigned)((which / 100) % 100));
+        CK(hipGetLastError());
+        return;
+    }
     if (which >= 30000)
     {
         // EXPERIMENT (tools/experiments/front_k32.h): K = 32 per barrier, one workgroup of sixteen wavefronts per CU
@@ -206,6 +214,11 @@ const char *name_of(int which)
 {
     if (which == 0)
         return "round-2 kernel (pg_hip_dense.h)";
+    if (which >= 40000)
+    {
+        snprintf(name_buf, sizeof(name_buf), "front kernel 128 x 64 tiles, 4 wavefronts, 3 workgroups / CU, unit %d dest.", (which / 100) % 100);
+        return name_buf;
+    }
     if (which >= 30000)
     {
         snprintf(name_buf, sizeof(name_buf), "front kernel K = 32 per barrier, 16 wavefronts, XCD unit %d dest.", (which / 100) % 100);
@@ -257,7 +270,7 @@ int main(int argc, char **argv)
         build(X, 3, 2, true, cf);
         const int nb = X.nb;
         std::vector<double> ref((size_t)nb * nb), got((size_t)X.mb);
-        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102, 30100} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802};
+        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102, 30100, 40100} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802};
         for (int which : kinds)
         {
             for (int i = 0; i < X.P; i++)
@@ -286,7 +299,7 @@ int main(int argc, char **argv)
     const double flop = 8192.0 * X.products;
     printf("front %d x %d destinations of 256 x 256, %d update(s) queued on each, %d%% fill pattern: %zu workgroups, %.3f TFLOP of live 16x16x16 products per launch (%.1f%% of dense)\n", P, P, Q,
            fill, X.nwork, flop / 1e12, 100.0 * flop / (2.0 * 256 * 256 * 256 * (double)P * P * Q));
-    std::vector<int> kinds = fill >= 100 ? std::vector<int>{0, 112, 30100, 20102, 112, 30100, 30800} : std::vector<int>{0, 10102, 20102, 20802, 0, 10102, 20102, 20802};
+    std::vector<int> kinds = fill >= 100 ? std::vector<int>{0, 112, 40100, 30100, 20102, 112, 40100, 40800} : std::vector<int>{0, 10102, 20102, 20802, 0, 10102, 20102, 20802};
 #ifdef TL_PROBE
     kinds = {10102, 20102, 10102, 20102};
 #endif
