@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fem27", choices=["shell", "fem27", "poisson", "kkt"])
+    ap.add_argument("--workload", default="fem27", choices=["shell", "fem27", "poisson", "kkt", "elastic3d"])
     ap.add_argument("--size", type=int, nargs="*", default=None, help="generator size arguments (fem27: n [ny nz]; shell: nx ny)")
     ap.add_argument("--mtx", default=None, help="matrix file to factorise instead of the synthetic stand-in: MatrixMarket (.mtx) or the "
                                                 "reference's binary .lid (examples/example.c:112-163)")
@@ -95,7 +95,7 @@ def parse_args(argv=None):
 def default_sizes(args):
     if args.size:
         return list(args.size)
-    return {"shell": [398, 398], "fem27": [112], "poisson": [64], "kkt": [40]}[args.workload]
+    return {"shell": [398, 398], "fem27": [112], "poisson": [64], "kkt": [40], "elastic3d": [77]}[args.workload]
 
 
 def make_matrix(args, M):
@@ -111,6 +111,8 @@ def make_matrix(args, M):
         return M.fem27(*size), "Serena-class stand-in: fem27(%s)" % ",".join(map(str, size))
     if args.workload == "poisson":
         return M.poisson3d(*size), "poisson3d(%s)" % ",".join(map(str, size))
+    if args.workload == "elastic3d":
+        return M.elastic3d(*size), "Serena-class stand-in with Serena's row length: elastic3d(%s), 3 dofs x 15-point node stencil" % ",".join(map(str, size))
     return M.kkt(size[0]), "nlpkkt-class stand-in: kkt(%d)" % size[0]
 
 

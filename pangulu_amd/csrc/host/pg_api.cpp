@@ -806,7 +806,9 @@ extern "C"
             {
                 // Where the copy lives (PANGULU_AMD_SNAPSHOT=device|host|auto): on the device a reset is one pass over HBM, but it
                 // doubles the footprint of the records -- with `auto` (default) only while three times the records still fit what
-                // is free now (records + copy + room for the dense mirrors); otherwise in host memory (a reset is then an upload).
+                // is free now (records + copy + room for the dense mirrors) -- or, when the handle's schedule has been recorded and its
+                // mirrors and descriptors are therefore allocated already, while the copy fits with 16 GB to spare; otherwise in host
+                // memory (a reset is then an upload).
                 const char *mode = getenv("PANGULU_AMD_SNAPSHOT");
                 bool on_host = mode && strcmp(mode, "host") == 0;
                 if (!mode || strcmp(mode, "auto") == 0)
@@ -814,7 +816,11 @@ extern "C"
                     size_t used = 0;
                     plat.get_device_memory_usage(&used);
                     const size_t total = (size_t)288 << 30; // (MI355X; only the order of magnitude matters here)
-                    on_host = used + 3 * S->storage.arena_bytes > total;
+                    const size_t free_now = used < total ? total - used : 0;
+                    if (S->schedule_recorded) // (the dry run at init has already taken the mirrors and descriptors this handle needs)
+                        on_host = free_now < S->storage.arena_bytes + ((size_t)16 << 30);
+                    else
+                        on_host = used + 3 * S->storage.arena_bytes > total;
                 }
                 S->snapshot_on_host = on_host;
                 if (on_host)

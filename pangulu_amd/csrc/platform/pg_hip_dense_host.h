@@ -183,7 +183,7 @@ double *obtain_mirror(BlockState &st, int nb)
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         const char *frac_env = getenv("PANGULU_HIP_MIRROR_FRACTION");
-        double frac = frac_env ? atof(frac_env) : 0.6; // of what is free now; the rest stays for records and slots
+        double frac = frac_env ? atof(frac_env) : 0.85; // of what is free now (0.6 until round 4): a LIMIT -- chunks are allocated as mirrors are handed out --; the rest stays for descriptor twins, scratch, receive slots
         MP.limit_mirrors = (size_t)(frac * (double)free_b / (double)mb);
         MP.chunk_bytes = mb * 1024; // 512 MiB at nb = 256
     }

@@ -94,12 +94,36 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_front
         }
     };
 
+    // C += acc: accumulator register r of lane l is C(M0 + wm + mi*16 + (l & 15), N0 + wn + ni*16 + 4 r + (l >> 4))
+    double __attribute__((address_space(1))) *C = (double __attribute__((address_space(1))) *)reinterpret_cast<double *>(G.cdense);
+    const unsigned c_voff = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
+#define FR_C(ni_, mi_, r_)                                                                           \
+    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((const char __attribute__((address_space(1))) *)C +                    \
+                                                                  ((size_t)(N0 + wn + (ni_) * 16 + 4 * (r_)) * nb + M0 + wm) * 8) + \
+                                                   dg_lane_offset(c_voff) + (mi_) * 128))
+    // A workgroup that owns its destination (no atomics) takes the tile into the accumulators up front (round 4; the general kernel
+    // has done so since round 3): the loads are older than every DMA instruction, so the first step's wait covers them, they travel
+    // beside the first slab, the matrix cores compute C - sum A B and the epilogue is stores only -- a read-modify-write at the end
+    // is a dependent round trip nothing hides (stand-alone: FR_PRELOAD=0 for the old epilogue).
+#ifndef FR_PRELOAD
+#define FR_PRELOAD 1
+#endif
+    const bool preload = FR_PRELOAD && !G.atomic && T > 0;
     v4f64 acc[2][4]; // [ni][mi]
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
-            acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        {
+            if (preload)
+            {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    acc[ni][mi][r] = FR_C(ni, mi, r);
+            }
+            else
+                acc[ni][mi] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        }
 
     // prologue: STAGES - 1 slabs in flight
 #pragma unroll
@@ -190,13 +214,18 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_front
     if (product_counter && lane == 0 && T)
         atomicAdd(product_counter, (unsigned long long)(8 * T)); // 16 x 16 x 16 products issued by this wave
 
-    // C += acc: accumulator register r of lane l is C(M0 + wm + mi*16 + (l & 15), N0 + wn + ni*16 + 4 r + (l >> 4))
-    double __attribute__((address_space(1))) *C = (double __attribute__((address_space(1))) *)reinterpret_cast<double *>(G.cdense);
-    const unsigned c_voff = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
-#define FR_C(ni_, mi_, r_)                                                                           \
-    (*(double __attribute__((address_space(1))) *)(dg_scalar_base((const char __attribute__((address_space(1))) *)C +                    \
-                                                                  ((size_t)(N0 + wn + (ni_) * 16 + 4 * (r_)) * nb + M0 + wm) * 8) + \
-                                                   dg_lane_offset(c_voff) + (mi_) * 128))
+    if (preload)
+    {
+        // the accumulators hold C - sum A B
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    FR_C(ni, mi, r) = acc[ni][mi][r];
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 2; ni++)
     {

@@ -85,6 +85,29 @@ def shell(nx, ny, layers=2, dofs=3, dtype=np.float64):
     return _finish(A.astype(dtype), dtype, coords)
 
 
+def elastic3d(nx, ny=None, nz=None, dofs=3, dtype=np.float64):
+    """Serena-class stand-in with Serena's ROW LENGTH: a 3D solid with `dofs` unknowns per node and the 15-point node connectivity of
+    a tetrahedral mesh (the node itself, its 6 face and its 8 corner neighbours), every node pair coupled by a full dofs x dofs
+    block: 15 * dofs = 45 entries per row.  Serena itself (gas-reservoir geomechanics): n = 1 391 349, 46.1 entries per row.
+    elastic3d(77): n = 1 369 599, 61.2 M entries.  Values as in shell(): off-diagonal blocks that are not rank-one, rows strictly
+    diagonally dominant (no pivoting needed)."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    off = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if abs(a) + abs(b) + abs(c) in (1, 3)]
+    G = _stencil(nx, ny, nz, off) + sp.identity(nx * ny * nz, format="csc")
+    K = sp.kron(G, np.ones((dofs, dofs)), format="coo")
+    i, j = K.row.astype(np.int64), K.col.astype(np.int64)
+    offd = i != j
+    i, j = i[offd], j[offd]
+    v = -(1.0 + 0.25 * ((i * 7 + j * 13) % 5))
+    n = nx * ny * nz * dofs
+    A = sp.csc_matrix((v, (i, j)), shape=(n, n))
+    rowsum = np.asarray(abs(A).sum(axis=1)).ravel()
+    A = A + sp.diags(rowsum + 1.0, format="csc")
+    coords = np.repeat(_grid_coords(nx, ny, nz), dofs, axis=0)
+    return _finish(A.astype(dtype), dtype, coords)
+
+
 def kkt(nx, dtype=np.float64, delta=1e-2):
     """nlpkkt-class stand-in: [[H, J^T], [J, -delta I]] with H a 7-point operator on nx^3 and J a one-sided
     difference.  Regularised so that no pivoting is needed."""

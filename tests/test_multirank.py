@@ -43,7 +43,7 @@ def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transpo
             env.pop("PANGULU_AMD_SEPARATOR_MAP", None)
         else:
             env["PANGULU_AMD_SEPARATOR_MAP"] = separators
-        env.update(extra_env or {})
+        env.update({k: v.format(rank=r) for k, v in (extra_env or {}).items()})  # ("{rank}" in a value: this rank's number)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), spec, str(nb), out_path, vtype, platform],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -323,6 +323,32 @@ def test_rccl_transport_falls_back_on_a_host_memory_platform(tmp_path):
     z = np.load(out)
     assert int(z["transport"]) == _lib.TRANSPORT_HOST
     assert float(z["residual"]) < 1e-13
+
+
+RCCL_ON_ONE_DEVICE = {
+    # RCCL refuses two ranks of ONE host on one device ("Duplicate GPU detected": same host hash, same bus id).  With a different
+    # NCCL_HOSTID per rank the ranks look like different hosts: the check passes, and since "other hosts" are reached through the
+    # network transport, every ncclSend / ncclRecv of the data plane runs -- over RCCL's socket transport on the loopback
+    # interface instead of xGMI.  That is not a performance path; it is the only way to EXECUTE pg_comm_rccl.cpp (communicator
+    # per ordered pair, stream-gated sends, receives into device slots) on the one-GPU test box.
+    "NCCL_HOSTID": "pangulu-test-host-{rank}", "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1", "NCCL_P2P_DISABLE": "1",
+    "NCCL_SHM_DISABLE": "1", "NCCL_NET_GDR_LEVEL": "0", "PANGULU_AMD_RCCL_TIMEOUT_S": "120"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,spec,nb,vtype,separators", [(2, "fem27_6", 32, "r64", "cyclic"), (4, "shell_40x40", 256, "r64", None),
+                                                            (3, "fem27_9", 128, "r64", "cyclic"), (2, "poisson12c", 128, "cr64", None)])
+def test_rccl_data_plane_executes_on_a_shared_gpu(tmp_path, world, spec, nb, vtype, separators):
+    """The RCCL plane north_star names (MPI point-to-point -> ncclSend / ncclRecv, src/pangulu_communication.c:1902-1944,
+    :1786-1900), executed: every directed pair's communicator created and self-tested, every forwarded block record sent
+    with ncclSend behind its producer's marker and received with ncclRecv into a device slot; factors against one rank on the
+    oracle.  See RCCL_ON_ONE_DEVICE for how two ranks get past RCCL's one-rank-per-device rule."""
+    from pangulu_amd import _lib
+
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, vtype=vtype, platform="hip", transport="rccl", separators=separators, extra_env=RCCL_ON_ONE_DEVICE)
+    z = check_against_single_rank(out, spec, nb, vtype)
+    assert int(z["transport"]) == _lib.TRANSPORT_RCCL, "the RCCL transport fell back to host staging"
 
 
 @pytest.mark.gpu

@@ -25,6 +25,8 @@ def build(spec):
         return M.shell(k, k)
     if kind == "poisson3d":
         return M.poisson3d(k)
+    if kind == "elastic3d":
+        return M.elastic3d(k)
     if kind == "kkt":
         return M.kkt(k)
     raise SystemExit("unknown matrix " + spec)
