@@ -15,12 +15,15 @@ HBM; each step is bracketed by a barrier + device synchronise on both sides and 
 value = F / t with F = sum_k (c_k + 2 c_k^2) the reference's structural flop count (src/pangulu_kernel_interface.c:4-176,
 computed once from the symbolic pattern outside the timed region).  The SAME matrix at every N: strong scaling.
 
-Workload: BASELINE.json's north-star matrix is SuiteSparse Serena (n = 1.39 M, nnz = 64 M; R64, nb = 256).  It is not in
-the image and there is no network, so unless --mtx points at a MatrixMarket / .lid file the run uses the deterministic
-Serena-class stand-in pangulu_amd.matrices.fem27(112): a 27-point (trilinear FEM) stencil on a 112^3 grid, n = 1 404 928,
-37.3 M entries, diagonally dominant -- the same class (3D solid, dense top separators) and size.  `--workload shell` is the
-ldoor-class stand-in of BASELINE configs[1] (shell(398,398), n = 950 424), the default of rounds 1-2.
-Ordering: built-in geometric nested dissection (stated in the JSON line; F depends on it).
+Workload: BASELINE.json's north-star matrix is SuiteSparse Serena (n = 1 391 349, nnz = 64.1 M, 46 entries per row: a 3D geomechanics
+model with 3 unknowns per node; R64, nb = 256).  It is not in the image and there is no network, so unless --mtx points at a
+MatrixMarket / .lid file the run uses the deterministic stand-in pangulu_amd.matrices.elastic3d(77): a 77^3 node mesh, 3 unknowns
+per node, the 15-point node connectivity of a tetrahedral mesh with a full 3 x 3 block per node pair -- n = 1 369 599, 60.0 M
+entries, 45 per row, diagonally dominant: Serena's order, entry count AND row length (round 3's stand-in fem27(112) had the order
+and 27 entries per row; it stays in the line as a `secondary` workload, next to shell(398,398), the ldoor-class matrix of BASELINE
+configs[1] and default of rounds 1-2).  `--workload fem27|shell|poisson|kkt` select the other classes.
+Ordering: built-in nested dissection (geometric with the generators' coordinates, multilevel graph-only with --no-coords or a
+matrix file; stated in the JSON line: F depends on it).  The device-side snapshot moves to host memory when it would not fit.
 
 The line's residual and factor_check (the reference's two criteria, examples/example.c:304-364 and
 src/pangulu_numeric.c:1082-1341) are taken from the factors of the LAST TIMED step, in the timed configuration; kernel
@@ -58,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fem27", choices=["shell", "fem27", "poisson", "kkt", "elastic3d"])
+    ap.add_argument("--workload", default="elastic3d", choices=["shell", "fem27", "poisson", "kkt", "elastic3d"])
     ap.add_argument("--size", type=int, nargs="*", default=None, help="generator size arguments (fem27: n [ny nz]; shell: nx ny)")
     ap.add_argument("--mtx", default=None, help="matrix file to factorise instead of the synthetic stand-in: MatrixMarket (.mtx) or the "
                                                 "reference's binary .lid (examples/example.c:112-163)")
@@ -69,8 +72,8 @@ def parse_args(argv=None):
                     "nested dissection (multilevel vertex separators) that a matrix file without coordinates gets")
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workload of the default run (the ldoor-class matrix of "
-                    "BASELINE configs[1], 3 steps): its line rides in the JSON line as `secondary`")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run (the ldoor-class matrix of "
+                    "BASELINE configs[1] and round 3's headline matrix, 3 steps each): their lines ride in the JSON line as `secondary`")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-sample-stride", type=int, default=0,
                     help="CPU baseline: execute every k-th task of each kernel class of the SAME factorisation (0: sized for about "
@@ -652,37 +655,42 @@ def gpu_worker_main(args):
 
     pa.pangulu_finalize(h)
 
-    # Secondary workload of the DEFAULT run (one rank, default matrix): BASELINE configs[1]'s class -- ldoor, n = 952 K, one GPU --
-    # on its stand-in shell(398,398), 3 timed steps behind 1 warm-up, residual from the last one.  A latency-bound matrix (thin
-    # shell: small fronts, long chains near the root) beside the MFMA-bound headline one.
+    # Secondary workloads of the DEFAULT run (one rank, default matrix), 3 timed steps behind 1 warm-up each, residual and factor check
+    # from the last one: (1) BASELINE configs[1]'s class -- ldoor, n = 952 K, one GPU -- on its stand-in shell(398,398): a latency-bound
+    # matrix (thin shell: small fronts, long chains near the root) beside the MFMA-bound headline one; (2) fem27(112), the headline
+    # matrix of round 3 (27 entries per row where Serena has 46), for continuity between the rounds' lines.
     secondary = None
-    if world == 1 and not args.no_secondary and not args.mtx and not args.size and args.workload == "fem27" and not args.no_coords and args.steps > 0:
-        n2, cp2, ri2, va2, co2 = M.shell(398, 398)
-        t0 = time.time()
-        h2 = pa.pangulu_init(n2, len(va2), cp2, ri2, va2, nb=args.nb, ordering="nd", coords=co2, nthread=nthreads)
-        t_init2 = time.time() - t0
-        assert lib.pangulu_amd_snapshot(h2.ref) == 0
-        ts2 = []
-        for s2 in range(4):
-            torch.cuda.synchronize()
+    if world == 1 and not args.no_secondary and not args.mtx and not args.size and args.workload == "elastic3d" and not args.no_coords and args.steps > 0:
+        secondary = []
+        for label, gen in (("ldoor-class stand-in: shell(398,398) 2 layers x 3 dofs", lambda: M.shell(398, 398)),
+                           ("Serena-class stand-in of round 3: fem27(112)", lambda: M.fem27(112))):
+            n2, cp2, ri2, va2, co2 = gen()
+            t0 = time.time()
+            h2 = pa.pangulu_init(n2, len(va2), cp2, ri2, va2, nb=args.nb, ordering="nd", coords=co2, nthread=nthreads)
+            t_init2 = time.time() - t0
+            assert lib.pangulu_amd_snapshot(h2.ref) == 0
+            ts2 = []
+            for s2 in range(4):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                pa.pangulu_gstrf(h2)
+                torch.cuda.synchronize()
+                ts2.append(time.perf_counter() - t)
+                if s2 < 3:
+                    lib.pangulu_amd_reset_numeric(h2.ref)
+            info2 = h2.info()
+            fc2 = pa.factor_check(h2)
+            b2 = M.rhs_of_ones(n2, cp2, ri2, va2)
             t = time.perf_counter()
-            pa.pangulu_gstrf(h2)
-            torch.cuda.synchronize()
-            ts2.append(time.perf_counter() - t)
-            if s2 < 3:
-                lib.pangulu_amd_reset_numeric(h2.ref)
-        info2 = h2.info()
-        fc2 = pa.factor_check(h2)
-        b2 = M.rhs_of_ones(n2, cp2, ri2, va2)
-        t = time.perf_counter()
-        x2 = pa.pangulu_gstrs(h2, b2)
-        gstrs2 = time.perf_counter() - t
-        ms2 = 1e3 * sum(ts2[1:]) / 3
-        secondary = [{"workload": "ldoor-class stand-in: shell(398,398) 2 layers x 3 dofs", "n": int(info2["n"]), "nnz": int(info2["nnz"]), "nb": int(info2["nb"]),
-                      "flop": int(info2["flop"]), "steps": 3, "warmup": 1, "ms_per_step": ms2, "step_ms": [round(1e3 * t_, 2) for t_ in ts2[1:]],
-                      "value": float(info2["flop"]) / (ms2 / 1e3) / 1e9, "unit": "GFLOP/s", "residual": M.relative_residual(n2, cp2, ri2, va2, x2, b2),
-                      "factor_check": fc2, "gstrs_s": gstrs2, "init_s": round(t_init2, 2), "static_schedule_replayed": bool(info2["replayed"])}]
-        pa.pangulu_finalize(h2)
+            x2 = pa.pangulu_gstrs(h2, b2)
+            gstrs2 = time.perf_counter() - t
+            ms2 = 1e3 * sum(ts2[1:]) / 3
+            secondary.append({"workload": label, "n": int(info2["n"]), "nnz": int(info2["nnz"]), "nb": int(info2["nb"]),
+                              "flop": int(info2["flop"]), "steps": 3, "warmup": 1, "ms_per_step": ms2, "step_ms": [round(1e3 * t_, 2) for t_ in ts2[1:]],
+                              "value": float(info2["flop"]) / (ms2 / 1e3) / 1e9, "unit": "GFLOP/s", "residual": M.relative_residual(n2, cp2, ri2, va2, x2, b2),
+                              "factor_check": fc2, "gstrs_s": gstrs2, "init_s": round(t_init2, 2), "static_schedule_replayed": bool(info2["replayed"])})
+            pa.pangulu_finalize(h2)
+            del n2, cp2, ri2, va2, co2, b2, x2
     if world > 1:
         lib.pangulu_amd_comm_barrier()
         lib.pangulu_amd_comm_finalize()
