@@ -53,7 +53,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (v_mfma_f64_16x16x4: 64 cycles per 2048 flop per SIMD)
 XGMI_LINK_GBS = 153.0     # one xGMI link per GPU pair
-CPU_GFLOPS_GUESS = 8.0    # one core of the oracle with OpenBLAS inside SSSSM, for sizing the sample only
+CPU_GFLOPS_GUESS = 22.0   # one core of the oracle with OpenBLAS inside SSSSM (measured: 22-24 on the bench hosts), for sizing the sample only
 
 
 def parse_args(argv=None):
@@ -566,6 +566,7 @@ def gpu_worker_main(args):
             ts.append(one_step())
         lib.pangulu_amd_set_replay(before)
         ms_scheduler_in_loop = 1e3 * min(ts[1:])  # (the first one re-creates the launcher thread's buffers)
+        pa.hip_stats(lib, reset=True)  # (the profile pass below counts its own launches only)
 
     # one extra, un-timed factorisation with per-launch hipEvents to attribute time to kernels: every launch on the ONE main
     # stream (side streams and the records stream off), so that an event pair brackets its kernel and nothing else
