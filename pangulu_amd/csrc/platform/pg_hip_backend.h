@@ -65,7 +65,7 @@ struct Backend
     // dense-front kernel (pg_hip_front.h) for the (destination, tile) pairs all of whose queued updates have every 16 x 16
     // piece live: LDS stages of its operand pipeline (2, 3 or 4; 0 = off, everything through the general kernel)
     long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15: 1 = inside the general launch (no step list), 2..4 = own kernel
-    long long opt_front_min_wgs = 8192; // PANGULU_HIP_FRONT_MIN_WGS: ... from this many qualifying workgroups in a launch on (sweep: fem27(112) 842.8 / 845.0 / 849.0 ms at 8192 / 2048 / never)
+    long long opt_front_min_wgs = 2048; // PANGULU_HIP_FRONT_MIN_WGS: ... from this many qualifying workgroups in a launch on (round 3 sweep, fem27(112): 842.8 / 845.0 / 849.0 ms at 8192 / 2048 / never; round 4, with the destination preloaded: 656.9 / 655.4 / 653.6 / 659.6 ms at 8192 / 2048 / 512 / 64)
     long long opt_front_unit = 1;   // PANGULU_HIP_FRONT_UNIT: consecutive destinations of the front launch that share an XCD
     // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 1 / 3 / 4 = the
     // LDS-DMA pipeline with 2 / 3 / 4 stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h), 2 = its

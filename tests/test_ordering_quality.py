@@ -56,3 +56,21 @@ def test_the_ordering_is_a_function_of_the_matrix_alone(tlib):
         perms.append(pa.permutation(h).tolist())
         pa.pangulu_finalize(h)
     assert perms[0] == perms[1]
+
+
+def test_elastic3d_has_serenas_row_length():
+    """The default bench matrix: 3 unknowns per node, 15-point node connectivity, a full 3 x 3 block per node pair -- 45 entries per
+    interior row (Serena: 46.1), strictly diagonally dominant rows (no pivoting needed), coordinates per unknown."""
+    import numpy as np
+
+    n, cp, ri, va, co = M.elastic3d(9)
+    assert n == 3 * 9 ** 3 and co.shape == (n, 3)
+    A = M.to_scipy(n, cp, ri, va).tocsr()
+    row_len = np.diff(A.indptr)
+    assert row_len.max() == 45 and (row_len == 45).sum() == 3 * 7 ** 3  # interior nodes
+    d = A.diagonal()
+    off = np.asarray(abs(A).sum(axis=1)).ravel() - abs(d)
+    assert (d > off).all()
+    # (values are not symmetric by construction; the pattern is)
+    P = (A != 0).astype(np.int8)
+    assert (P != P.T).nnz == 0
