@@ -59,6 +59,10 @@ struct Backend
     // does: 873.1 against 887.6 ms, shell(398) 39.05 against 39.72.  On by default since then.
     hipStream_t stream_bg = nullptr;
     hipEvent_t ev_bg_fork = nullptr, ev_bg_done = nullptr;
+    // Early stream (round 4, replayed schedules only): the FIRST densify of a block whose record no kernel has written yet depends on
+    // nothing -- the recording moves such jobs out of the launch order into a prologue on this stream, which the replay starts before
+    // anything else; the main stream waits for a chunk's event where its densify launch used to be (pg_hip_dense_host.h, flush_early_jobs).
+    hipStream_t stream_early = nullptr;
     bool bg_active = false;
     std::unordered_set<const void *> bg_tiles;
     long long opt_background_updates = 1; // PANGULU_HIP_BACKGROUND_UPDATES=0 / option 14
@@ -125,6 +129,9 @@ struct Recorder
     const void *owner = nullptr;
     unsigned long long signature = 0;
     std::vector<std::function<void()>> ops;
+    std::vector<std::function<void()>> prologue; // launched by a replay before `ops` (early densify jobs on their own stream)
+    bool in_prologue = false;                    // launches and event records issued now go to `prologue`
+    std::vector<hipEvent_t> early_events;        // one per prologue chunk, owned by the recording
     // Descriptor segments of the recorded launches.  While recording, the kernels read them in place from pinned host memory
     // (h, device-visible at d) like every other run; the REPLAYS read a copy in HBM (twin), made once when the recording ends:
     // a workgroup's first two dependent reads -- its work item, its task descriptors -- then cost an L2/HBM round trip instead
@@ -200,7 +207,7 @@ inline void pg_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t
     if (REC.mode != 0)
     {
         auto targs = std::make_tuple(rec_xl(args)...);
-        REC.ops.emplace_back([=]()
+        (REC.in_prologue ? REC.prologue : REC.ops).emplace_back([=]()
                              { std::apply([&](auto... a)
                                           { hipLaunchKernelGGL(kernel, grid, block, (unsigned)shmem, st, a...); },
                                           targs); });
@@ -215,7 +222,7 @@ inline void pg_event_record(hipEvent_t e, hipStream_t s)
 {
     flush_pending_getrf();
     if (REC.mode != 0)
-        REC.ops.emplace_back([e, s]() { HIP_CHECK(hipEventRecord(e, s)); });
+        (REC.in_prologue ? REC.prologue : REC.ops).emplace_back([e, s]() { HIP_CHECK(hipEventRecord(e, s)); });
     if (REC.mode != 2)
         HIP_CHECK(hipEventRecord(e, s));
 }
@@ -288,6 +295,7 @@ void ensure_ready()
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_rec, hipEventDisableTiming));
     if (const char *e = getenv("PANGULU_HIP_RECORDS_STREAM"))
         B.opt_records_stream = atol(e);
+    HIP_CHECK(hipStreamCreateWithFlags(&B.stream_early, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&B.stream_bg, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_bg_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&B.ev_bg_done, hipEventDisableTiming));

@@ -11,6 +11,8 @@ struct BlockState
     bool sparse_current = true;  // the sparse record holds the block's current values
     bool lu_image = false;       // diagonal block: the mirror holds L\\U with inverted diagonal tiles (pg_hip_trsm_dense.h)
     bool lu_map = false;         // ... and the occupancy map behind it describes the factorised block (tiled GETRF)
+    bool written = false;        // a kernel has written the block's SPARSE RECORD in this factorisation (sparse update, sparse solve, GETRF)
+    bool densified_once = false; // the block has had a densify job in this factorisation
     unsigned char image_halves = 0; // ... of which triangles: 1 = strictly lower (L), 2 = upper (U)
     u32 brow = 0, bcol = 0, nnz = 0;
     // Host-side occupancy summary of an OWNED off-diagonal block's pattern (pangulu_platform_0201001_prepare_blocks, once
@@ -112,6 +114,12 @@ struct MirrorPool
     size_t limit_mirrors = 0, peak = 0; // peak: most mirrors in use at once since the pool was (re)started
     BlockTable blocks; // key: d_value of the (lower half of the) block
     std::vector<MirrorJobD> to_densify, to_sparsify;
+    // early densify (recorded schedules): jobs moved out of the launch order since the last wait point, and the descriptor
+    // segment the prologue's launches read them from
+    std::vector<MirrorJobD> early;
+    char *early_h = nullptr, *early_d = nullptr;
+    size_t early_cap = 0, early_used = 0;
+    unsigned long long early_jobs = 0, early_chunks = 0;
 };
 MirrorPool MP;
 
@@ -319,6 +327,19 @@ const double *request_half_image(slot_t *half, int nb)
 
 #endif // R64: LU images
 
+// Early densify (PANGULU_HIP_EARLY_DENSIFY=1; OFF by default) applies to recordings made by a dry run (nothing executes while
+// recording, so moving a launch is free of consequences for the recording run itself).
+// MEASURED (profiles/r04k_early_densify_ab.log, one box): correct -- same residuals and factor checks, 43 676 jobs in 53 chunks on
+// shell(398), 164 889 in 140 on fem27(112) -- and NOT faster: shell(398) 38.0-38.4 ms against 37.6, fem27(112) 653.1 against 650.5,
+// poisson3d(64) 26.3 against 25.2.  The 4.4 ms of exclusive densify time a kernel trace showed on the shell were largely the
+// tracer's launch gaps; untraced, the jobs cost less where they were than their 21 GB of mirror writes cost the latency-bound leaf
+// levels they now run beside.
+inline bool early_densify_on()
+{
+    static const bool on = getenv("PANGULU_HIP_EARLY_DENSIFY") && atoi(getenv("PANGULU_HIP_EARLY_DENSIFY")) != 0;
+    return on && REC.mode == 2;
+}
+
 // make sure the block has a mirror holding its current values; queues a densify job if it has to be (re)built.
 // Returns nullptr when no mirror can be had.
 double *current_mirror(slot_t *s, int nb)
@@ -329,7 +350,14 @@ double *current_mirror(slot_t *s, int nb)
         return nullptr;
     if (!st.mirror_current)
     {
-        MP.to_densify.push_back(mirror_job(s, m, nb)); // sparse_current holds whenever mirror_current does not
+        // (sparse_current holds whenever mirror_current does not)
+        // The first densify of a block whose record no kernel has written depends on nothing that happens in the factorisation: a
+        // dry-run recording moves it into the prologue (flush_early_jobs)
+        if (early_densify_on() && !st.written && !st.densified_once)
+            MP.early.push_back(mirror_job(s, m, nb));
+        else
+            MP.to_densify.push_back(mirror_job(s, m, nb));
+        st.densified_once = true;
         st.mirror_current = true;
     }
     return m;
@@ -408,6 +436,60 @@ void flush_mirror_jobs(int nb, std::vector<MirrorJobD> &jobs, bool densify, bool
     jobs.clear();
 }
 
+// The jobs moved out of the launch order since the last wait point become ONE chunk of the prologue -- a densify launch on the
+// early stream, an event behind it -- and the main stream waits for that event HERE, where the jobs' launch used to be: everything
+// that reads these mirrors is ordered behind this point of the main stream (side streams fork from it afterwards).  In a replay
+// the prologue's chunks run from the first moment on, in the order the factorisation consumes them, beside the latency-bound leaf
+// levels; by the time the main stream gets to a chunk's wait it has long completed (shell(398): densify was 4.4 of 37.5 ms
+// exclusive, tools/critical_path.py).
+void flush_early_jobs(int nb)
+{
+    if (MP.early.empty())
+        return;
+    HostTimer ht(3);
+    const size_t take = MP.early.size();
+    const size_t need = sizeof(MirrorJobD) * take + 64;
+    if (MP.early_used + need > MP.early_cap)
+    {
+        Segment seg = acquire_segment(); // (recording: a segment of its own, kept with the recording and twinned in HBM)
+        if (need > seg.cap)
+        {
+            // (more first-touch jobs at one point than a segment holds: leave them in the launch order)
+            MP.to_densify.insert(MP.to_densify.end(), MP.early.begin(), MP.early.end());
+            MP.early.clear();
+            return;
+        }
+        MP.early_h = seg.h;
+        MP.early_d = seg.d;
+        MP.early_cap = seg.cap;
+        MP.early_used = 0;
+    }
+    const size_t off = (MP.early_used + 15) & ~(size_t)15;
+    memcpy(MP.early_h + off, MP.early.data(), sizeof(MirrorJobD) * take);
+    const MirrorJobD *d_jobs = reinterpret_cast<const MirrorJobD *>(MP.early_d + off);
+    MP.early_used = off + sizeof(MirrorJobD) * take;
+    static const long target_env = getenv("PANGULU_HIP_MIRROR_JOB_WGS") ? atol(getenv("PANGULU_HIP_MIRROR_JOB_WGS")) : 16384;
+    unsigned slices = 16;
+    while (slices > 1 && (size_t)slices * take > (size_t)target_env)
+        slices >>= 1;
+    slices = std::min<unsigned>(slices, (unsigned)std::max(1, nb / 16));
+    hipEvent_t ev;
+    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    REC.early_events.push_back(ev);
+    REC.in_prologue = true;
+    PG_LAUNCH(densify_kernel, dim3((unsigned)take, slices), dim3(256), 0, B.stream_early, d_jobs, nb);
+    pg_event_record(ev, B.stream_early);
+    REC.in_prologue = false;
+    pg_stream_wait(B.stream, ev);
+    B.stats.launches[6]++;
+    B.stats.tasks[6] += take;
+    for (const MirrorJobD &J : MP.early)
+        B.stats.alg_bytes[6] += J.move_bytes;
+    MP.early_jobs += take;
+    MP.early_chunks++;
+    MP.early.clear();
+}
+
 void reset_block_states()
 {
     // everything about values and mirrors is forgotten; the identity of owned blocks and their occupancy summaries stay
@@ -430,6 +512,7 @@ void reset_block_states()
     MP.cursor = 0;
     MP.to_densify.clear();
     MP.to_sparsify.clear();
+    MP.early.clear();
 }
 
 #else // other value types have no dense mode

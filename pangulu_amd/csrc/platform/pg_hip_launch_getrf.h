@@ -137,6 +137,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                 }
                 st.sparse_current = true;
                 st.mirror_current = false;
+                st.written = true;
             }
 #endif
             tasks[nsp++] = T;
@@ -157,6 +158,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
         {
             if (!MP.to_densify.empty() || !B.opt_records_stream)
                 ks = B.stream; // (mirror jobs run on the main stream: the factorisation follows them there)
+            flush_early_jobs(nb);
             if (!MP.to_densify.empty())
                 flush_mirror_jobs(nb, MP.to_densify, true);
             ZGetrfTaskD *hz = seg.alloc<ZGetrfTaskD>(ztasks.size(), &d_ztasks);

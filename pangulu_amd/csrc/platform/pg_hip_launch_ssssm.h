@@ -102,7 +102,10 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 }
             }
             if (!cm)
+            {
                 require_sparse(dst, nb);
+                block_state(dst, nb).written = true; // (the sparse kernel updates the record: its first densify is no longer free to move)
+            }
 #endif
             if (!G.cdense)
             {
@@ -273,6 +276,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
         // mirrors that have to be (re)built for this launch, and sparse records that must catch up first
         if (!MP.to_sparsify.empty())
             flush_mirror_jobs(nb, MP.to_sparsify, false);
+        flush_early_jobs(nb);
         if (!MP.to_densify.empty())
             flush_mirror_jobs(nb, MP.to_densify, true);
 #endif

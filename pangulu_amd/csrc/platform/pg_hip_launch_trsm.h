@@ -163,12 +163,14 @@ void launch_trsm(int nb, task_t **list, size_t n)
 #if defined(PG_DENSE_UPDATES)
                 if (BlockState *found = MP.blocks.find(block_key(dst)))
                     found->mirror_current = false; // the sparse solve rewrites the record
+                block_state(dst, nb).written = true;
 #endif
             }
         }
 #if defined(PG_DENSE_UPDATES)
         if (!MP.to_sparsify.empty())
             flush_mirror_jobs(nb, MP.to_sparsify, false);
+        flush_early_jobs(nb);
         if (!MP.to_densify.empty())
             flush_mirror_jobs(nb, MP.to_densify, true);
 #endif

@@ -1637,6 +1637,13 @@ extern "C"
             if (sg.twin)
                 (void)hipFree(sg.twin);
         }
+        for (hipEvent_t e : REC.early_events)
+            (void)hipEventDestroy(e);
+#if defined(PG_DENSE_UPDATES)
+        MP.early.clear();
+        MP.early_h = MP.early_d = nullptr; // (the segment went with the recording)
+        MP.early_cap = MP.early_used = 0;
+#endif
         REC = Recorder();
     }
 
@@ -1735,6 +1742,18 @@ extern "C"
                 B.chase_launches = REC.wgs_before[2];
                 B.chase_solves = REC.wgs_before[3];
             }
+#if defined(PG_DENSE_UPDATES)
+            if (!MP.early.empty())
+            {
+                // (every launch function flushes what it moved: this cannot happen)
+                fprintf(stderr, "[PanguLU-AMD ERROR] %zu early densify jobs were never given a wait point\n", MP.early.size());
+                exit(EXIT_FAILURE);
+            }
+            if (getenv("PANGULU_AMD_TRACE") && MP.early_chunks)
+                fprintf(stderr, "[pangulu_amd trace] schedule: %llu first-touch densify jobs moved into %llu prologue chunks on the early stream\n",
+                        MP.early_jobs, MP.early_chunks);
+            MP.early_jobs = MP.early_chunks = 0;
+#endif
             REC.nb = B.nb_cfg;
             REC.generation = B.generation; // (the allocations of the recording itself are behind us)
             REC.valid = true;
@@ -1743,6 +1762,8 @@ extern "C"
         case 3:
             if (!REC.valid || REC.owner != owner || REC.signature != options_signature() || REC.generation != B.generation)
                 return 1;
+            for (auto &op : REC.prologue) // (early densify chunks, on their own stream: the main list waits for their events)
+                op();
             for (auto &op : REC.ops)
                 op();
             HIP_CHECK(hipGetLastError());

@@ -46,6 +46,8 @@ SWITCHES = [
     {"PANGULU_AMD_SEPARATOR_ORDER": "natural", "_matrix": "fem27"},  # separators in the mesh's numbering (default: k-d order)
     {"PANGULU_HIP_HEAVY_FIRST": "0", "_matrix": "fem27"},              # update work items in the scheduler's order
     {"PANGULU_HIP_SOLVE_CHUNKED": "0"},        # rounds 2-3's triangular-solve kernels (column by column from HBM)
+    {"PANGULU_HIP_EARLY_DENSIFY": "1"},        # first-touch densify jobs in a prologue on their own stream (measured: no gain; off)
+    {"PANGULU_HIP_EARLY_DENSIFY": "1", "_matrix": "fem27"},
     {"PANGULU_AMD_ND_DIAGONALS": "0", "PANGULU_AMD_ND_POLISH": "0", "_matrix": "fem27"},  # rounds 1-3's geometric cuts: axes only, no FM
 ]
 

@@ -52,6 +52,7 @@ MID = [
     ("fem27_32", lambda: M.fem27(32)),
     ("poisson_40", lambda: M.poisson3d(40)),
     ("kkt_16", lambda: M.kkt(16)),
+    ("elastic3d_14", lambda: M.elastic3d(14)),   # the default bench class (round 4): 3 unknowns per node, 45 entries per row
 ]
 
 
@@ -63,6 +64,19 @@ def test_midsize_nb256_default_thresholds(name, gen):
     _check(mat, 256, gpu, ref, res_tol=2e-12)
     st = gpu["hip_stats"]
     assert st["ssssm_dense_mfma"]["launches"] > 0 and st["tstrf"]["dense_path_tasks"] > 0 and st["getrf"]["launches"] > 0, st
+
+
+@pytest.mark.parametrize("name,gen", [("fem27_24", lambda: M.fem27(24)), ("shell_90x90", lambda: M.shell(90, 90)), ("poisson_32", lambda: M.poisson3d(32))],
+                         ids=["fem27_24", "shell_90x90", "poisson_32"])
+def test_midsize_nb256_without_coordinates(name, gen):
+    """The graph-only ordering (multilevel nested dissection, separators in k-d order on pseudo-coordinates) on the device: what a
+    matrix file without coordinates gets.  Same checks as with coordinates."""
+    n, cp, ri, va, _ = gen()
+    mat = (n, cp, ri, va, None)
+    gpu = factorize(mat, 256, "hip")
+    ref = factorize(mat, 256, oracle_library("r64"))
+    _check(mat, 256, gpu, ref, res_tol=2e-12)
+    assert gpu["hip_stats"]["ssssm_dense_mfma"]["launches"] > 0
 
 
 def test_large_getrf_batches_nb256():

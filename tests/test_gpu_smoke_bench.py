@@ -64,3 +64,36 @@ def test_bench_launches_its_own_ranks():
     # (T*(N) = max over ranks of T*_r + link term: at this size the link term is the larger part)
     assert m["T_star_ms"] >= m["sum_over_ranks_ms"] / 2 and 1.0 <= m["rank_flop_share_max_over_mean"] < 2.0
     assert m["sent_GB"] > 0 and m["link_term_ms_max"] > 0
+
+
+def test_bench_on_a_matrix_file_without_coordinates(tmp_path):
+    """`bench.py --mtx`: a MatrixMarket file and the reference's binary .lid (examples/example.c:112-163), as the real BASELINE
+    matrices would arrive -- no coordinates, so the graph-only ordering runs -- plus a right-hand side file; and `--no-coords` on
+    a generator.  Residual below 1e-10, the ordering named in the line, new keys of round 4 present."""
+    import scipy.io
+
+    from pangulu_amd import matrices as M
+
+    n, cp, ri, va, _ = M.fem27(14)
+    A = M.to_scipy(n, cp, ri, va)
+    mtx = str(tmp_path / "fem27_14.mtx")
+    scipy.io.mmwrite(mtx, A)
+    lid = str(tmp_path / "fem27_14.lid")
+    M.write_lid(lid, n, cp, ri, va)
+    rhs = str(tmp_path / "b.rhs")
+    b = M.rhs_of_ones(n, cp, ri, va)
+    with open(rhs, "w") as f:
+        f.write("%d\n" % n)
+        f.write("\n".join("%.17g" % x for x in b) + "\n")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    flops = []
+    for extra in (["--mtx", mtx], ["--mtx", lid, "--rhs", rhs], ["--workload", "fem27", "--size", "14", "--no-coords"]):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+        line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{"metric"')][-1])
+        assert line["residual"] < 1e-10 and line["factor_check"] < 1e-12 and line["value"] > 0
+        assert "graph only" in line["config"]["ordering"], line["config"]["ordering"]
+        assert line["gstrs_s"] > 0 and "hbm_breakdown_GB" in line and line["ms_per_step_scheduler_in_loop"] > 0
+        assert line["data"] == ("file" if "--mtx" in extra else "synthetic")
+        flops.append(line["config"]["flop"])
+    assert flops[0] == flops[1] == flops[2]  # the same matrix three ways: the same ordering, the same structural flops
