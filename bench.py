@@ -72,6 +72,8 @@ def parse_args(argv=None):
                     "nested dissection (multilevel vertex separators) that a matrix file without coordinates gets")
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi-replay", action="store_true", help="N > 1: every rank logs its first factorisation (a warm-up step) and replays the log "
+                    "afterwards (PANGULU_AMD_MULTI_REPLAY=1; needs --warmup >= 1 and a transport that defers sends: rccl or ipc)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run (the ldoor-class matrix of "
                     "BASELINE configs[1] and round 3's headline matrix, 3 steps each): their lines ride in the JSON line as `secondary`")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -352,6 +354,8 @@ def passthrough_args(args):
         out.append("--no-profile-pass")
     if args.no_secondary:
         out.append("--no-secondary")
+    if args.multi_replay:
+        out.append("--multi-replay")
     if args.no_coords:
         out.append("--no-coords")
     return out
@@ -448,6 +452,8 @@ def gpu_worker_main(args):
     # 44.6 ms (44.0-48.0) on one box.  A user of the library sets it the same way.
     os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     os.environ["LOCAL_RANK"] = str(local_rank)
+    if args.multi_replay:
+        os.environ["PANGULU_AMD_MULTI_REPLAY"] = "1"
 
     import torch  # device selection + the synchronise the contract asks for; not on the compute path
 

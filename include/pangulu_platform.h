@@ -325,6 +325,13 @@ extern "C"
      * Profiled runs and the eager host mirror are not recorded (cmd 1 / 4 return -1).  The host-side counters of get_stats
      * (launches, tasks, alg_bytes, workgroup counts) count a dry run not at all and every replay once. */
     long long pangulu_platform_0201001_schedule(int cmd, const void *owner);
+    /* Multi-rank hosts (round 4): cmd 5 = record like cmd 1 with the descriptor segments packed (thousands of small batches);
+     * cmd 6 = number of operations recorded so far; cmd 7 / 8 = a replay in RANGES begins (same validity rule as cmd 3; 0 = go) /
+     * ends; schedule_range replays the operations [first, last) in between -- the host waits for the blocks of other ranks
+     * between its batches --; marker_record_replay records a marker at the current point of the main stream and nothing else
+     * (the stream joins a marker needs are operations of the recorded list). */
+    int pangulu_platform_0201001_schedule_range(const void *owner, long long first, long long last);
+    void *pangulu_platform_0201001_marker_record_replay(void);
     /* stream all numeric kernels are launched on (a hipStream_t); for event timing in bench.py */
     void *pangulu_platform_0201001_get_stream(void);
     /* Cumulative per-kernel-class counters since the last reset.  Classes: 1 GETRF, 2 TSTRF, 3 GESSM,

@@ -74,6 +74,8 @@ void bind_builtin_hip(Platform &p)
     p.block_trsv = pangulu_platform_0201001_block_trsv;
     p.block_spmv_add = pangulu_platform_0201001_block_spmv_add;
     p.schedule = pangulu_platform_0201001_schedule;
+    p.schedule_range = pangulu_platform_0201001_schedule_range;
+    p.marker_record_replay = pangulu_platform_0201001_marker_record_replay;
     p.bind_near_device = pangulu_platform_0201001_bind_near_device;
 }
 

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <deque>
 #include <vector>
 
 #include "../../../include/pangulu_amd_ext.h"
@@ -76,6 +77,8 @@ struct Platform
     void (*block_trsv)(pangulu_inblock_idx, int, pangulu_uint64_t, const pangulu_uint64_t *, const pangulu_hip_solve_row_t *, slot_t *const *,
                        const pangulu_exblock_idx *, val_t *, pangulu_uint64_t) = nullptr;
     long long (*schedule)(int, const void *) = nullptr;
+    int (*schedule_range)(const void *, long long, long long) = nullptr; // ranged replay of a recorded list (multi-rank)
+    void *(*marker_record_replay)() = nullptr;
     void (*block_spmv_add)(pangulu_inblock_idx, pangulu_uint64_t, slot_t *const *, const pangulu_exblock_idx *, const pangulu_exblock_idx *, const int *,
                            const val_t *, val_t *, pangulu_uint64_t) = nullptr;
 };
@@ -146,7 +149,9 @@ struct RecvBin
 {
     size_t slot_capacity = 0;
     std::vector<slot_t> slots;
-    std::vector<i32> free_list;
+    std::deque<i32> free_list; // FIFO (round 4): a recycled slot goes to the back, so that a bin provisioned for every block the rank
+                               // receives hands out every slot ONCE per factorisation (a rank's log can only be replayed then: slot
+                               // addresses are in the recorded descriptors)
     char *hbuf = nullptr, *dbuf = nullptr;
 };
 
@@ -334,6 +339,39 @@ struct Solver
     u64 pending_total = 0;
     bool factored = false, host_values_current = true;
     bool schedule_recorded = false;        // the back-end holds the launch list of this handle's factorisation (one rank)
+    // Multi-rank replay (round 4, PANGULU_AMD_MULTI_REPLAY=1): what THIS rank did in its first factorisation, in order -- the ranges
+    // of the back-end's recorded operations its platform calls produced, the markers between them with the blocks that were
+    // announced behind each, and which blocks of other ranks had arrived (into which receive slot) before each call was made.
+    // A later factorisation replays the log: no task release, no descriptor building; it waits for arrivals where the first run
+    // had them.  The per-rank orders are what HAPPENED in one run, so together with the messages they are acyclic: no deadlock.
+    struct RankLog
+    {
+        struct Entry
+        {
+            long long op_end = 0;  // operations [previous entry's op_end, op_end) of the back-end's list belong to this entry
+            int marker = -1;       // >= 0: record marker `marker` behind them (and post the sends gated by it)
+            u32 need = 0;          // arrivals[0 .. need) of the first run must have arrived before the operations go out
+        };
+        struct Send
+        {
+            int marker;
+            slot_t *slot;
+            BlockHeader h;
+            int dst;
+        };
+        struct Arrival
+        {
+            u32 brow, bcol, is_upper;
+            slot_t *slot;
+        };
+        std::vector<Entry> entries;
+        std::vector<Send> sends;        // in posting order (grouped by marker)
+        std::vector<Arrival> arrivals;  // in the first run's order
+        int nmarkers = 0;
+        bool valid = false, slot_reused = false;
+        bool unusable = false; // a first run has been logged and cannot be replayed (slot reuse, host staging): do not record again
+    };
+    RankLog rank_log;
     char *arena_snapshot = nullptr;        // pristine copy of the owned records, see pangulu_amd_snapshot
     bool snapshot_on_host = false;         // ... kept in host memory (PANGULU_AMD_SNAPSHOT, or too little HBM for a device copy)
     // statistics

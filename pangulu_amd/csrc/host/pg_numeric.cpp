@@ -21,6 +21,8 @@
 #include <deque>
 #include <memory>
 #include <thread>
+#include <unordered_map>
+#include <unordered_set>
 #include <unistd.h>
 
 #include "pg_host.h"
@@ -151,6 +153,7 @@ struct Sched
     // announced, once a marker recorded behind the kernels that use / produce them has completed
     bool use_markers = false;
     Marker *last_marker = nullptr; // marker behind the most recent platform call (created on demand)
+    int last_marker_id = -1;
     std::deque<std::unique_ptr<Marker>> markers; // all markers of this factorisation (the transport's sender thread keeps pointers)
     struct Retired
     {
@@ -180,7 +183,23 @@ struct Sched
     {
         std::vector<task_t> tasks;
         Marker *marker = nullptr; // non-null: record a platform marker here instead of running tasks
+        int marker_id = -1;       // (recording a rank log: the marker's number)
+        u32 need = 0;             // (recording: arrivals handled when the batch was made)
     };
+    // Recording of this rank's log for later replays (Solver::RankLog): the launcher thread appends an entry behind every platform
+    // call, the scheduler thread the sends, the receive thread the arrivals.
+    bool rec_multi = false, rec_gates_ok = true;
+    int gate_marker_id = -1;
+    std::atomic<u32> arrivals_handled{0};
+    std::unordered_set<const slot_t *> rec_used_slots; // receive slots taken so far (a second use makes the log useless: slot addresses are in the descriptors)
+    void log_entry(int marker_id, u32 need)
+    {
+        Solver::RankLog::Entry e;
+        e.op_end = plat.schedule(6, &S);
+        e.marker = marker_id;
+        e.need = need;
+        S.rank_log.entries.push_back(e);
+    }
     std::deque<LItem> lq;
     std::vector<std::vector<task_t>> lq_free;
     bool forced_multi = false; // PANGULU_AMD_FORCE_MULTI_LOOP=1: one rank through the multi-rank loop (measurement aid)
@@ -242,12 +261,18 @@ struct Sched
             lk.unlock();
             double dt = 0;
             if (item.marker)
+            {
                 item.marker->ev.store(plat.marker_record(), std::memory_order_release);
+                if (rec_multi)
+                    log_entry(item.marker_id, 0);
+            }
             else
             {
                 double t0 = wall_seconds();
                 plat.hybrid_batched((pangulu_inblock_idx)S.nb, item.tasks.size(), item.tasks.data());
                 dt = wall_seconds() - t0;
+                if (rec_multi)
+                    log_entry(-1, item.need);
             }
             lk.lock();
             t_platform += dt;
@@ -363,6 +388,8 @@ struct Sched
         h.is_upper = (u32)s->is_upper;
         size_t bytes = record_bytes(S.nb, h.nnz, s->brow_pos > s->bcol_pos);
         h.bytes_lo = (u32)bytes;
+        if (rec_multi)
+            S.rank_log.sends.push_back(Solver::RankLog::Send{gate_marker_id, s, h, target});
         comm->isend_block(s, h, target);
     }
 
@@ -589,15 +616,19 @@ struct Sched
                 std::lock_guard<std::mutex> g(lq_mutex);
                 LItem item;
                 item.tasks = std::move(copy);
+                item.need = arrivals_handled.load(std::memory_order_acquire); // (everything that released these tasks has been handled)
                 lq.push_back(std::move(item));
             }
             lq_cv.notify_one();
             last_marker = nullptr;
             return;
         }
+        const u32 need = arrivals_handled.load(std::memory_order_acquire);
         double t0 = wall_seconds();
         plat.hybrid_batched((pangulu_inblock_idx)S.nb, tasks.size(), tasks.data());
         t_platform += wall_seconds() - t0;
+        if (rec_multi)
+            log_entry(-1, need);
         last_marker = nullptr;
     }
 
@@ -609,18 +640,24 @@ struct Sched
             return last_marker;
         markers.emplace_back(new Marker());
         last_marker = markers.back().get();
+        last_marker_id = (int)markers.size() - 1;
         if (async_launch)
         {
             {
                 std::lock_guard<std::mutex> g(lq_mutex);
                 LItem item;
                 item.marker = last_marker;
+                item.marker_id = last_marker_id;
                 lq.push_back(std::move(item));
             }
             lq_cv.notify_one();
         }
         else
+        {
             last_marker->ev.store(plat.marker_record(), std::memory_order_release);
+            if (rec_multi)
+                log_entry(last_marker_id, 0);
+        }
         return last_marker;
     }
 
@@ -797,8 +834,13 @@ struct Sched
         {
             // finished blocks are about to be announced: either the transport holds the announcements back until a
             // marker behind this batch has completed, or the device is drained here
-            if (!(use_markers && comm->set_send_gate(current_marker())))
+            if (use_markers && comm->set_send_gate(current_marker()))
+                gate_marker_id = last_marker_id;
+            else
+            {
                 drain_device();
+                rec_gates_ok = false; // (a transport that copies at post time: its sends cannot be replayed behind a marker)
+            }
         }
         SEC(2)
         // (3) successor release
@@ -954,6 +996,13 @@ struct Sched
         s->bcol_pos = h.bcol;
         s->is_upper = (i32)h.is_upper;
         s->data_status = PANGULU_DATA_READY;
+        struct Handled // (counted when the successors have been released, whichever way this function returns)
+        {
+            std::atomic<u32> &c;
+            ~Handled() { c.fetch_add(1, std::memory_order_release); }
+        } handled{arrivals_handled};
+        if (rec_multi)
+            S.rank_log.arrivals.push_back(Solver::RankLog::Arrival{h.brow, h.bcol, h.is_upper, s});
         if (h.brow == h.bcol)
         {
             u32 level = h.brow;
@@ -1049,6 +1098,11 @@ struct Sched
                 if (spins > 300000)
                     fatal("receive buffers exhausted for 60 s: dependency deadlock");
             }
+            if (rec_multi)
+            {
+                if (!rec_used_slots.insert(s).second)
+                    S.rank_log.slot_reused = true;
+            }
             bind_record(*s, S.nb, h.nnz, (char *)s->value - 32, (char *)s->d_value - 32, h.brow > h.bcol, h.brow == h.bcol && h.is_upper);
             s->brow_pos = h.brow;
             s->bcol_pos = h.bcol;
@@ -1126,6 +1180,180 @@ void record_schedule(Solver &S)
                 S.schedule_recorded ? "ok" : "nothing recorded");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-rank replay (round 4; PANGULU_AMD_MULTI_REPLAY=1).  A rank's FIRST factorisation runs the scheduler and records -- the
+// back-end its launches (schedule cmd 5: like a single-rank recording, descriptor segments packed), the scheduler this rank's log
+// (Solver::RankLog): the operation range of every platform call, the markers between them and the blocks announced behind each,
+// and the blocks of other ranks in the order they were handled, with the receive slot each one landed in and how many had been
+// handled when each platform call was made.  Later factorisations replay the log: the receive thread puts every announced block
+// into the slot it had (the descriptors hold slot addresses), the compute thread walks the entries -- wait until the blocks the
+// entry needed have arrived, replay its operations, record its marker, post its sends behind it.  No heap, no counters, no
+// descriptor building.  Every rank's order is what HAPPENED on it in one run, and so are the messages: the union is acyclic, a
+// replay cannot deadlock, whatever the other ranks do (they may replay or schedule).  Not replayable, and then simply not
+// replayed: a first run in which a receive slot was used twice (recycling: its address would have to be re-timed), or whose
+// transport copies at post time (host staging).  Cost of the approach: the batch boundaries of the first run, arrival-driven
+// fragmentation included, are frozen.
+// ---------------------------------------------------------------------------------------------------------------------
+static bool multi_replay_enabled()
+{
+    static const bool on = getenv("PANGULU_AMD_MULTI_REPLAY") && atoi(getenv("PANGULU_AMD_MULTI_REPLAY")) != 0;
+    return on && g_replay_enabled != 0;
+}
+
+static bool replay_rank_log(Solver &S)
+{
+    Platform &plat = active_platform();
+    Comm *comm = world();
+    Solver::RankLog &L = S.rank_log;
+    if (!L.valid || !plat.schedule || !plat.schedule_range || !plat.marker_record_replay)
+        return false;
+    comm->barrier();
+    const double t0 = wall_seconds();
+    if (plat.schedule(7, &S) != 0)
+    {
+        L.valid = false; // (options or back-end resources changed since the recording: schedule again, and record again)
+        return false;
+    }
+    const size_t narr = L.arrivals.size();
+    std::unique_ptr<std::atomic<unsigned char>[]> arrived(new std::atomic<unsigned char>[narr + 1]);
+    std::unordered_map<u64, u32> index; // (brow, bcol, is_upper) -> position in the first run's arrival order
+    index.reserve(narr * 2 + 16);
+    auto key_of = [](u32 brow, u32 bcol, u32 up) -> u64
+    { return ((u64)brow << 33) | ((u64)bcol << 1) | (u64)(up & 1u); };
+    for (size_t i = 0; i < narr; i++)
+    {
+        arrived[i].store(0, std::memory_order_relaxed);
+        index[key_of(L.arrivals[i].brow, L.arrivals[i].bcol, L.arrivals[i].is_upper)] = (u32)i;
+    }
+    double stall_limit_s = 120;
+    if (const char *e = getenv("PANGULU_AMD_STALL_S"))
+        stall_limit_s = atof(e);
+    std::vector<std::unique_ptr<Marker>> markers((size_t)L.nmarkers);
+    for (auto &m : markers)
+        m.reset(new Marker());
+
+    std::thread worker([&]()
+                       {
+                           size_t have = 0, send_at = 0;
+                           long long op = 0;
+                           for (const Solver::RankLog::Entry &e : L.entries)
+                           {
+                               double t_wait = 0;
+                               while (have < e.need)
+                               {
+                                   if (arrived[have].load(std::memory_order_acquire))
+                                   {
+                                       have++;
+                                       t_wait = 0;
+                                       continue;
+                                   }
+                                   const double now = wall_seconds();
+                                   if (t_wait == 0)
+                                       t_wait = now;
+                                   if (now - t_wait > stall_limit_s)
+                                       fatal("rank %d (replay): block (%u,%u) of the first run's arrival order has not come for %.0f s", S.rank,
+                                             L.arrivals[have].brow, L.arrivals[have].bcol, now - t_wait);
+                                   usleep(5);
+                               }
+                               if (e.op_end > op)
+                               {
+                                   if (plat.schedule_range(&S, op, e.op_end) != 0)
+                                       fatal("rank %d (replay): the recorded launch list is gone", S.rank);
+                                   op = e.op_end;
+                               }
+                               if (e.marker >= 0)
+                               {
+                                   Marker *m = markers[(size_t)e.marker].get();
+                                   m->ev.store(plat.marker_record_replay(), std::memory_order_release);
+                                   if (send_at < L.sends.size() && L.sends[send_at].marker == e.marker)
+                                   {
+                                       if (!comm->set_send_gate(m))
+                                           fatal("rank %d (replay): the transport no longer defers sends", S.rank);
+                                       while (send_at < L.sends.size() && L.sends[send_at].marker == e.marker)
+                                       {
+                                           const Solver::RankLog::Send &sd = L.sends[send_at++];
+                                           comm->isend_block(sd.slot, sd.h, sd.dst);
+                                       }
+                                   }
+                               }
+                           }
+                           if (send_at != L.sends.size())
+                               fatal("rank %d (replay): %zu recorded sends were never posted", S.rank, L.sends.size() - send_at);
+                           // (operations recorded behind the last logged call: the stream joins of the first run's final synchronise)
+                           const long long total = plat.schedule(6, &S);
+                           if (total > op)
+                               plat.schedule_range(&S, op, total);
+                       });
+    // receive thread: every announced block into the slot it had in the first run
+    {
+        std::vector<u32> begun;
+        size_t done = 0;
+        double t_last = 0;
+        auto finish = [&]()
+        {
+            if (begun.empty())
+                return;
+            comm->recv_blocks_finish();
+            for (u32 i : begun)
+                arrived[i].store(1, std::memory_order_release);
+            done += begun.size();
+            begun.clear();
+        };
+        while (done + begun.size() < narr)
+        {
+            BlockHeader h;
+            int src = -1;
+            if (!comm->probe_block(h, src))
+            {
+                if (!begun.empty())
+                    finish();
+                else
+                {
+                    const double now = wall_seconds();
+                    if (t_last == 0)
+                        t_last = now;
+                    if (now - t_last > stall_limit_s)
+                        fatal("rank %d (replay): no block arrived for %.0f s with %zu receives outstanding", S.rank, now - t_last, narr - done);
+                    usleep(10);
+                }
+                continue;
+            }
+            t_last = 0;
+            auto it = index.find(key_of(h.brow, h.bcol, h.is_upper));
+            if (it == index.end())
+                fatal("rank %d (replay): block (%u,%u) was not received in the recorded run", S.rank, h.brow, h.bcol);
+            slot_t *s = L.arrivals[it->second].slot;
+            bind_record(*s, S.nb, h.nnz, (char *)s->value - 32, (char *)s->d_value - 32, h.brow > h.bcol, h.brow == h.bcol && h.is_upper);
+            s->brow_pos = h.brow;
+            s->bcol_pos = h.bcol;
+            s->is_upper = (i32)h.is_upper;
+            comm->recv_block_begin(s, h, src);
+            begun.push_back(it->second);
+            if (begun.size() >= 128)
+                finish();
+        }
+        finish();
+    }
+    worker.join();
+    plat.schedule(8, &S);
+    plat.synchronize();
+    comm->flush_sends();
+    comm->set_send_gate(nullptr);
+    comm->barrier();
+    S.info.time_numeric = wall_seconds() - t0;
+    S.info.time_numeric_host_sched = S.info.time_numeric_platform = 0;
+    S.info.replayed = 1;
+    S.info.sent_bytes = comm->sent_bytes;
+    S.info.recv_bytes = comm->recv_bytes_total;
+    for (auto &sl : S.storage.owned)
+        sl.data_status = PANGULU_DATA_READY;
+    S.rank_remain_task = 0;
+    S.rank_remain_recv = 0;
+    S.factored = true;
+    S.host_values_current = false;
+    return true;
+}
+
 void numeric_factorize(Solver &S)
 {
     if (S.factored)
@@ -1149,9 +1377,13 @@ void numeric_factorize(Solver &S)
         const double t0 = wall_seconds();
         if (plat.schedule(3, &S) == 0)
         {
+            const double t_issued = wall_seconds() - t0; // (the host's share of a replay: issuing the recorded launches)
             plat.synchronize();
             S.info.time_numeric = wall_seconds() - t0;
-            S.info.time_numeric_host_sched = S.info.time_numeric_platform = 0;
+            S.info.time_numeric_host_sched = 0;
+            S.info.time_numeric_platform = t_issued;
+            if (getenv("PANGULU_AMD_TRACE"))
+                fprintf(stderr, "[pangulu_amd trace] replay: launches issued in %.2f ms, factorisation done after %.2f ms\n", 1e3 * t_issued, 1e3 * S.info.time_numeric);
             S.info.replayed = 1;
             for (auto &sl : S.storage.owned)
                 sl.data_status = PANGULU_DATA_READY;
@@ -1162,6 +1394,10 @@ void numeric_factorize(Solver &S)
         }
         S.schedule_recorded = false; // (other options than at recording time, or another handle recorded since: a normal run)
     }
+    const bool multi_replay = S.nproc > 1 && !plat.host_memory && multi_replay_enabled() && plat.schedule && plat.schedule_range && g_task_sample_stride <= 1 &&
+                              !S.eager_host_mirror;
+    if (multi_replay && S.rank_log.valid && replay_rank_log(S))
+        return;
     S.info.replayed = 0;
     Sched sch(S);
     S.info.sampled_flop = 0;
@@ -1169,6 +1405,11 @@ void numeric_factorize(Solver &S)
     if (plat.set_option)
         plat.set_option(PANGULU_HIP_OPT_RESET_BLOCK_STATE, 0);  // block values were (re)loaded behind the back-end's back
     const bool recording = can_schedule && plat.schedule(1, &S) == 0;
+    if (multi_replay && sch.use_markers && !S.rank_log.unusable)
+    {
+        S.rank_log = Solver::RankLog();
+        sch.rec_multi = plat.schedule(5, &S) == 0; // (drops an older recording of this back-end first)
+    }
     S.heap.clear();
     S.pending_total = 0;
     S.pending_dirty.clear();
@@ -1196,6 +1437,21 @@ void numeric_factorize(Solver &S)
         sch.poll_retired(); // (everything has completed: all of them go back)
         comm->flush_sends();
         comm->set_send_gate(nullptr);
+        if (sch.rec_multi)
+        {
+            Solver::RankLog &L = S.rank_log;
+            L.nmarkers = (int)sch.markers.size();
+            const bool listed = plat.schedule(2, &S) > 0;
+            L.valid = listed && sch.rec_gates_ok && !L.slot_reused && (i64)L.arrivals.size() == S.rank_remain_recv0;
+            L.unusable = !L.valid && listed; // (for a structural reason: the next factorisation would log the same thing)
+            if (!L.valid && listed)
+                plat.schedule(0, &S); // (drop the list: nobody will replay it)
+            S.schedule_recorded = L.valid; // (the back-end holds a list of this handle: dropped with the handle)
+            if (getenv("PANGULU_AMD_TRACE"))
+                fprintf(stderr, "[pangulu_amd trace] rank %d: log of this factorisation: %zu platform calls and markers, %zu sends, %zu arrivals -- %s\n", S.rank,
+                        L.entries.size(), L.sends.size(), L.arrivals.size(),
+                        L.valid ? "later factorisations replay it" : (L.slot_reused ? "a receive slot was used twice: not replayable" : "not replayable"));
+        }
     }
     else
     {

@@ -90,8 +90,8 @@ slot_t *Storage::allocate(size_t bytes)
         RecvBin &bin = bins[b];
         if (bin.slot_capacity >= bytes && !bin.free_list.empty())
         {
-            i32 idx = bin.free_list.back();
-            bin.free_list.pop_back();
+            i32 idx = bin.free_list.front();
+            bin.free_list.pop_front();
             slot_t *s = &bin.slots[idx];
             s->data_status = PANGULU_DATA_PREPARING;
             s->bin_id = (i32)b;
@@ -897,12 +897,19 @@ void preprocess(Solver &S, const CscMatrix &A)
                           full};
         for (int b = 1; b <= 6; b++)
             cls_nnz[b] = std::min(cls_nnz[b], full);
-        // how many remote blocks of each class will I receive in total?  slots = level * that, floored
+        // how many remote blocks of each class will I receive in total?  slots = level * that, floored.  A block is counted in the
+        // class Storage::allocate will take its slot from -- the first one whose slot holds the RECORD (an upper block or a
+        // diagonal half has no CSR part and may fit a class below the one its entry count suggests) --: with FIFO free lists a
+        // bin that is provisioned for its blocks then hands out every slot once per factorisation (multi-rank replay needs that).
         u64 need_cnt[7] = {0, 0, 0, 0, 0, 0, 0};
-        auto classify = [&](u64 nnz)
+        size_t cls_cap[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int b = 1; b <= 6; b++)
+            cls_cap[b] = (record_bytes(nb, cls_nnz[b], true) + 63) & ~(size_t)63;
+        auto classify = [&](u64 nnz, bool lower_offdiag)
         {
+            const size_t bytes = record_bytes(nb, nnz, lower_offdiag);
             for (int b = 1; b <= 6; b++)
-                if (nnz <= cls_nnz[b])
+                if (bytes <= cls_cap[b])
                     return b;
             return 6;
         };
@@ -915,11 +922,14 @@ void preprocess(Solver &S, const CscMatrix &A)
                 bool sent_to_me = consumer_rule ? ((S.consumers[t] >> me) & 1ull) != 0
                                                 : ((br > bc) ? (last_owned_col[br] > (i64)bc) : (last_owned_row[bc] > (i64)br));
                 if (sent_to_me)
-                    need_cnt[classify(P.nnz[t])]++;
+                    need_cnt[classify(P.nnz[t], br > bc)]++;
             }
         for (u32 k = 0; k < nbk; k++)
             if (S.owner(k, k) != me && S.remain_diag[k] > 0)
-                need_cnt[classify(P.diag_upper_nnz[k])] += 2;
+            {
+                need_cnt[classify(P.diag_lower_nnz[k], false)]++;
+                need_cnt[classify(P.diag_upper_nnz[k], false)]++;
+            }
         // The reference sizes bins as a fraction of block_length (init_options.mpi_recv_buffer_level) and aborts
         // when they run dry (src/pangulu_storage.c:109-132).  With 288 GB of HBM per GPU the safe choice is
         // affordable: provision one slot per block this rank will ever receive as long as that stays within
@@ -959,7 +969,7 @@ void preprocess(Solver &S, const CscMatrix &A)
                 s.d_value = (val_t *)(bin.dbuf + i * bin.slot_capacity + 32);
                 s.bin_id = b;
                 s.slot_idx = (i32)i;
-                bin.free_list.push_back((i32)(cnt - 1 - i));
+                bin.free_list.push_back((i32)i);
             }
         }
     }

@@ -143,6 +143,16 @@ struct Recorder
     };
     std::vector<Seg> segs;
     size_t descriptor_bytes = 0;
+    // Packed recording (multi-rank runs record thousands of small batches: a fresh 8 MB segment + twin per platform call would be tens
+    // of GB): a call gets the free TAIL of a recorded segment with at least 2 MB left and hands back what it did not use at commit.
+    // Calls nest (a launch function flushes mirror jobs while it holds its own segment), so a tail in use is out of the list.
+    bool pack = false;
+    struct Tail
+    {
+        int seg;
+        size_t used;
+    };
+    std::vector<Tail> tails;
     // what else the closures depend on: the block order and the generation of the back-end's shared resources when the list
     // was complete (B.generation)
     int nb = 0;
@@ -341,7 +351,9 @@ struct Segment
 {
     char *h, *d;
     size_t cap, used;
-    int index;
+    int index;       // ring segment, or -1: a recorded segment of its own, -2: the free tail of a recorded segment (packed recording)
+    int rec_idx = -1; // index -2: which recorded segment
+    size_t rec_off = 0; // ... and where this part starts
     template <typename T>
     T *alloc(size_t count, T **dev)
     {
@@ -408,6 +420,21 @@ Segment acquire_segment()
     if (REC.mode != 0)
     {
         // recording: the launches will be replayed, their descriptors have to stay -- a segment of its own, kept by the recorder
+        if (REC.pack && !REC.tails.empty())
+        {
+            const Recorder::Tail t = REC.tails.back();
+            REC.tails.pop_back();
+            const Recorder::Seg &sg = REC.segs[(size_t)t.seg];
+            Segment s;
+            s.h = sg.h + t.used;
+            s.d = sg.d + t.used;
+            s.cap = sg.cap - t.used;
+            s.used = 0;
+            s.index = -2;
+            s.rec_idx = t.seg;
+            s.rec_off = t.used;
+            return s;
+        }
         char *h = nullptr, *d = nullptr, *twin = nullptr;
         HIP_CHECK(hipHostMalloc((void **)&h, r.seg_bytes, hipHostMallocNonCoherent | hipHostMallocMapped));
         HIP_CHECK(hipHostGetDevicePointer((void **)&d, h, 0));
@@ -419,7 +446,9 @@ Segment acquire_segment()
         s.d = d;
         s.cap = r.seg_bytes;
         s.used = 0;
-        s.index = -1;
+        s.index = REC.pack ? -2 : -1;
+        s.rec_idx = (int)REC.segs.size() - 1;
+        s.rec_off = 0;
         return s;
     }
     int i = r.cur;
@@ -443,6 +472,13 @@ void commit_segment(Segment &s)
 {
     if (s.index >= 0)
         B.ring.pending.push_back(s.index);
+    else if (s.index == -2 && REC.mode != 0)
+    {
+        // packed recording: what the call did not use goes back, if it is worth a call
+        const size_t used = s.rec_off + ((s.used + 255) & ~(size_t)255);
+        if (used + ((size_t)2 << 20) <= REC.segs[(size_t)s.rec_idx].cap)
+            REC.tails.push_back(Recorder::Tail{s.rec_idx, used});
+    }
 }
 
 hipEvent_t take_event()

@@ -1694,11 +1694,13 @@ extern "C"
             return 0;
         case 1:
         case 4:
+        case 5: // (5: like 1, with the descriptor segments packed -- a multi-rank run's thousands of small batches)
             HIP_CHECK(hipDeviceSynchronize());
             drop_schedule();
             if (B.opt_profile || B.opt_host_mirror || !B.opt_assume_independent)
                 return -1;
             REC.mode = cmd == 4 ? 2 : 1;
+            REC.pack = cmd == 5;
             REC.owner = owner;
             REC.signature = options_signature();
             REC.stats_before = B.stats;
@@ -1759,6 +1761,25 @@ extern "C"
             REC.valid = true;
             return (long long)REC.ops.size();
         }
+        case 6: // operations recorded so far (while recording) / in the list
+            return (long long)REC.ops.size();
+        case 7: // a replay in RANGES begins (pangulu_platform_0201001_schedule_range): same validity rule as 3; the prologue goes out
+            if (!REC.valid || REC.owner != owner || REC.signature != options_signature() || REC.generation != B.generation)
+                return 1;
+            for (auto &op : REC.prologue)
+                op();
+            return 0;
+        case 8: // ... and ends: counters of one factorisation, streams as after a real run
+            if (!REC.valid || REC.owner != owner)
+                return 1;
+            HIP_CHECK(hipGetLastError());
+            host_counters_add(B.stats, REC.stats_delta);
+            B.front_workgroups += REC.wgs_delta[0];
+            B.general_workgroups += REC.wgs_delta[1];
+            B.chase_launches += REC.wgs_delta[2];
+            B.chase_solves += REC.wgs_delta[3];
+            B.rec_dirty.store(true, std::memory_order_release);
+            return 0;
         case 3:
             if (!REC.valid || REC.owner != owner || REC.signature != options_signature() || REC.generation != B.generation)
                 return 1;
@@ -1778,6 +1799,40 @@ extern "C"
         default:
             return -1;
         }
+    }
+
+    // Replay of the operations [first, last) of the owner's recorded list (between cmd 7 and cmd 8 of schedule): the multi-rank
+    // host replays its own log batch by batch, waiting for the blocks of other ranks in between.  Returns 0, or 1 when there is
+    // nothing valid to replay.
+    int pangulu_platform_0201001_schedule_range(const void *owner, long long first, long long last)
+    {
+        std::lock_guard<std::mutex> g(B.mutex);
+        if (!REC.valid || REC.owner != owner || first < 0 || last > (long long)REC.ops.size() || first > last)
+            return 1;
+        HIP_CHECK(hipSetDevice(B.device));
+        for (long long i = first; i < last; i++)
+            REC.ops[(size_t)i]();
+        return 0;
+    }
+
+    // A marker at the current point of the main stream and nothing else: in a ranged replay the joins a marker needs (records
+    // stream, background stream) are operations of the recorded list already -- marker_record appended them while recording.
+    void *pangulu_platform_0201001_marker_record_replay(void)
+    {
+        std::lock_guard<std::mutex> g(B.mutex);
+        HIP_CHECK(hipSetDevice(B.device));
+        static std::vector<hipEvent_t> ring;
+        static size_t next = 0;
+        if (ring.empty())
+        {
+            ring.resize(4096);
+            for (hipEvent_t &e : ring)
+                HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        hipEvent_t e = ring[next];
+        next = (next + 1) % ring.size();
+        HIP_CHECK(hipEventRecord(e, B.stream));
+        return (void *)e;
     }
 
     void *pangulu_platform_0201001_get_stream(void)

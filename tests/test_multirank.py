@@ -55,6 +55,9 @@ def run_ranks(world, spec, nb, out_path, vtype="r64", platform="oracle", transpo
                 q.kill()
             raise
         outs.append(o)
+    if os.environ.get("PANGULU_TEST_SHOW_OUTPUT"):
+        for r, o in enumerate(outs):
+            print("--- rank %d ---\n%s" % (r, o[-4000:]))
     failed = [r for r, p in enumerate(procs) if p.returncode != 0]
     assert not failed, "ranks %s failed:\n%s" % (failed, "\n".join("--- rank %d ---\n%s" % (r, outs[r][-3000:]) for r in range(world)))
 
@@ -293,6 +296,29 @@ def test_multirank_on_the_gpu_snapshot_reset_and_second_factorisation(tmp_path, 
     U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
     assert max_rel_diff(L, ref["L"]) < 1e-12 and max_rel_diff(U, ref["U"]) < 1e-12
     assert float(z["residual"]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,spec,nb,vtype,separators,distribute", [
+    (2, "fem27_9", 128, "r64", None, None), (2, "shell_40x40", 256, "r64", "cyclic", None), (4, "shell_40x40", 256, "r64", None, "0"),
+    (3, "fem27_9", 128, "r64", "cyclic", None), (8, "fem27_9", 128, "r64", None, "0"), (4, "kkt8", 64, "r64", None, "0"),
+    (2, "poisson12c", 128, "cr64", None, "0")])
+def test_multirank_replay_on_the_gpu(tmp_path, world, spec, nb, vtype, separators, distribute):
+    """PANGULU_AMD_MULTI_REPLAY=1: the first factorisation of every rank runs the scheduler and logs itself (operation ranges of its
+    platform calls, markers and the sends behind them, arrivals and their receive slots); the second and third REPLAY the log --
+    no task release, no descriptor building, waits for the first run's arrivals in their place -- and give the first one's
+    factors, which are the single-rank oracle's (1e-12).  Every rank reports the replays."""
+    from pangulu_amd import _lib
+
+    out = str(tmp_path / "out.npz")
+    env = {"PANGULU_AMD_MULTI_REPLAY": "1", "PANGULU_TEST_REPEATS": "2"}
+    if distribute is not None:
+        env["PANGULU_AMD_DISTRIBUTE_US"] = distribute
+    run_ranks(world, spec, nb, out, vtype=vtype, platform="hip", transport="ipc", repeat=True, separators=separators, extra_env=env)
+    z = check_against_single_rank(out, spec, nb, vtype, exchange=False)
+    assert int(z["transport"]) == _lib.TRANSPORT_IPC
+    flags = np.array(z["replayed"])
+    assert flags.shape == (world, 3) and (flags[:, 0] == 0).all() and (flags[:, 1:] == 1).all(), flags
 
 
 @pytest.mark.gpu
