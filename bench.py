@@ -72,6 +72,7 @@ def parse_args(argv=None):
                     "nested dissection (multilevel vertex separators) that a matrix file without coordinates gets")
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sched-steps", action="store_true", help="skip the three scheduler-in-the-loop steps behind the timed ones (profiling runs)")
     ap.add_argument("--multi-replay", action="store_true", help="N > 1: every rank logs its first factorisation (a warm-up step) and replays the log "
                     "afterwards (PANGULU_AMD_MULTI_REPLAY=1; needs --warmup >= 1 and a transport that defers sends: rccl or ipc)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run (the ldoor-class matrix of "
@@ -356,6 +357,8 @@ def passthrough_args(args):
         out.append("--no-secondary")
     if args.multi_replay:
         out.append("--multi-replay")
+    if args.no_sched_steps:
+        out.append("--no-sched-steps")
     if args.no_coords:
         out.append("--no-coords")
     return out
@@ -564,7 +567,7 @@ def gpu_worker_main(args):
     # dynamic).  So that a scaling curve compares like with like, a few un-timed-for-the-metric steps go through the scheduler
     # here as well, and the line carries both numbers.
     ms_scheduler_in_loop = None
-    if world == 1 and args.steps > 0 and info.get("replayed"):
+    if world == 1 and args.steps > 0 and info.get("replayed") and not args.no_sched_steps:
         before = lib.pangulu_amd_set_replay(0)
         ts = []
         for s in range(3):

@@ -11,7 +11,7 @@ TAG=${1:-run}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --gpu-worker --no-profile-pass --steps 2 --warmup 1 $*"
+B="python3 $R/bench.py --gpu-worker --no-profile-pass --no-secondary --no-sched-steps --steps 2 --warmup 1 $*"
 O=$R/gpurun_out/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o runc -- $B 2>&1 | grep metric | cut -c1-160
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d ${O}_fetch -o runc -- $B 2>&1 | grep metric | cut -c1-120
