@@ -492,6 +492,15 @@ void preprocess(Solver &S, const CscMatrix &A)
     int me = S.rank;
     u64 nblk = P.colptr[nbk];
 
+    const bool trace_pre = getenv("PANGULU_AMD_TRACE") != nullptr && S.rank == 0;
+    double t_mark = wall_seconds();
+    auto lap = [&](const char *what)
+    {
+        const double now = wall_seconds();
+        if (trace_pre)
+            fprintf(stderr, "[pangulu_amd trace] preprocess: %s %.2f s\n", what, now - t_mark);
+        t_mark = now;
+    };
     // ---- owned slots: off-diagonal blocks in block-CSC order, then diagonal halves ---------------------
     Storage &st = S.storage;
     st.nb = nb;
@@ -550,7 +559,14 @@ void preprocess(Solver &S, const CscMatrix &A)
         st.arena_bytes = 64; // no records: mapping, counters and models only (PANGULU_AMD_ANALYSIS_ONLY)
     if (posix_memalign((void **)&st.harena, 64, st.arena_bytes) != 0)
         fatal("host arena allocation of %zu bytes failed", st.arena_bytes);
-    memset(st.harena, 0, st.arena_bytes);
+    {
+        // zeroed by all threads (first touch included): one thread took 12 of the 60 s of pangulu_init on the default bench matrix's 87 GB
+        const size_t piece = (size_t)64 << 20;
+        const i64 npiece = (i64)((st.arena_bytes + piece - 1) / piece);
+#pragma omp parallel for schedule(static)
+        for (i64 k = 0; k < npiece; k++)
+            memset(st.harena + (size_t)k * piece, 0, std::min(piece, st.arena_bytes - (size_t)k * piece));
+    }
     if (plat.host_memory || analysis_only)
     {
         st.darena = st.harena;
@@ -600,6 +616,7 @@ void preprocess(Solver &S, const CscMatrix &A)
         S.diag_lower[k] = &lo;
         S.diag_upper[k] = &up;
     }
+    lap("mapping + slots + arena");
     // ---- patterns: one sweep per block column over the symbolic lower pattern ------------------------
     // lower block (br, bc), br > bc, is needed by its owner (CSC + CSR view) and by the owner of the upper
     // block (bc, br), whose CSC is the transpose.
@@ -711,6 +728,7 @@ void preprocess(Solver &S, const CscMatrix &A)
     if (!analysis_only)
         scatter_values(S, A);
 
+    lap("patterns + values into the records");
     // ---- dependency counters (src/pangulu_preprocessing.c:132-207, 443-556) ---------------------------
     S.remain.assign(nblk, 0);
     S.remain_diag.assign(nbk, 0);
@@ -881,6 +899,7 @@ void preprocess(Solver &S, const CscMatrix &A)
     S.heap.reserve((size_t)my_tasks + 1);
     S.pending.assign(st.owned.size(), {});
 
+    lap("dependency counters");
     // ---- receive bins (src/pangulu_preprocessing.c:319-366) -------------------------------------------
     st.bins.clear();
     st.bins.resize(7);
@@ -974,12 +993,14 @@ void preprocess(Solver &S, const CscMatrix &A)
         }
     }
 
+    lap("receive bins");
     // ---- upload -------------------------------------------------------------------------------------------
     if (!plat.host_memory && !analysis_only)
     {
         for (size_t c = 0; c < st.dchunks.size(); c++)
             plat.memcpy_(st.dchunks[c], st.harena + c * st.dchunk_bytes, st.chunk_len(c), 0);
         plat.synchronize();
+        lap("upload of the records");
         if (plat.prepare_diag)
             for (u32 k : owned_diag)
                 plat.prepare_diag((pangulu_inblock_idx)nb, S.diag_lower[k]);
@@ -990,6 +1011,7 @@ void preprocess(Solver &S, const CscMatrix &A)
                 offdiag[i] = &st.owned[i];
             plat.prepare_blocks((pangulu_inblock_idx)nb, offdiag.size(), offdiag.data());
         }
+        lap("back-end preparation (diagonal column views, pattern summaries)");
     }
     if (world()->size > 1 && !analysis_only)
         world()->register_arena(st.dchunks.data(), plat.host_memory ? 0 : st.dchunks.size(), st.dchunk_bytes, st.arena_bytes); // (collective)

@@ -26,13 +26,20 @@ def main(path, which=-1):
     # stall inside a factorisation for the boundary once)
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     groups, cur = [], []
+    last_end = None
     for r in rows:
         if "rocclr" in r["Kernel_Name"]:
             if cur:
                 groups.append(cur)
                 cur = []
             continue
+        # (round 4: with the records' snapshot in host memory the reset between two steps is an upload, no copy kernel shows up --
+        #  but the device then sits empty for hundreds of milliseconds: a gap of more than 150 ms separates factorisations too)
+        if cur and last_end is not None and int(r["Start_Timestamp"]) - last_end > 150_000_000:
+            groups.append(cur)
+            cur = []
         cur.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), cls(r["Kernel_Name"])))
+        last_end = max(last_end or 0, int(r["End_Timestamp"]))
     if cur:
         groups.append(cur)
     # factorisations only (the triangular solve at the end of a bench run is a group of its own)
