@@ -88,6 +88,12 @@ SYMB = [
     ("kkt5", lambda: M.kkt(5)),
     ("random400_unsym", lambda: M.random_pattern(400, 0.01, 3, symmetric_pattern=False)),
     ("poisson12", lambda: M.poisson3d(12)),
+    # (round 4: the symbolic phase keeps chain columns as views of their head's list -- patterns with long chains, with chains
+    #  broken by entries of the matrix itself, and with many small trees)
+    ("elastic3d_6", lambda: M.elastic3d(6)),
+    ("random300_dense_rows", lambda: M.random_pattern(300, 0.08, 11, symmetric_pattern=False)),
+    ("random900_sparse", lambda: M.random_pattern(900, 0.002, 5, symmetric_pattern=True)),
+    ("fem27_11x5x3", lambda: M.fem27(11, 5, 3)),
 ]
 
 
