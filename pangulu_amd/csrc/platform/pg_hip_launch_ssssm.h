@@ -30,9 +30,18 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
     HostTimer ht(0);
     hipStream_t const ms = background ? B.stream_bg : B.stream; // where the update kernels of this call run
     const bool dense_ok = dense_mode_available(nb);
+    // A call that does not fit one descriptor segment is cut into several launches.  On the background stream the mirror jobs
+    // of a later launch -- queued on the MAIN stream -- are not ordered behind the kernels of the earlier ones: a destination
+    // whose first updates went to its sparse record there and whose mirror is built here would be read before they have
+    // landed (found at the end of round 4: poisson3d(48) with a dense threshold of 100 per mille, factor check 4e-3).  The
+    // destinations of the earlier launches of this call are kept, and the main stream waits for them when a job touches one.
+    static std::unordered_set<const void *> bg_earlier;
+    bg_earlier.clear();
     size_t i = 0;
     while (i < n)
     {
+        bool bg_hazard = false;
+        const size_t chunk_begin = i;
         Segment seg = acquire_segment();
         // worst case per task: one group + one task descriptor in each class; fill until the segment is full
         // (per update: a task descriptor in each class -- PG_PLANES^2 real products on the MFMA side --, a group in each, four
@@ -88,6 +97,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
             // The destination works on its dense mirror when the mirror is already ahead of the sparse record, or
             // when at least one update of the group is heavy enough for the matrix cores.
             double *cm = nullptr;
+            const size_t jobs_before = MP.to_densify.size() + MP.to_sparsify.size() + MP.early.size();
             if (dense_ok)
             {
                 bool want = mirror_is_ahead(dst);
@@ -106,6 +116,9 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 require_sparse(dst, nb);
                 block_state(dst, nb).written = true; // (the sparse kernel updates the record: its first densify is no longer free to move)
             }
+            if (background && !bg_earlier.empty() && MP.to_densify.size() + MP.to_sparsify.size() + MP.early.size() != jobs_before &&
+                bg_earlier.count(block_key_any(dst)))
+                bg_hazard = true;
 #endif
             if (!G.cdense)
             {
@@ -273,6 +286,11 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
             i = j;
         }
 #if defined(PG_DENSE_UPDATES)
+        if (bg_hazard)
+        {
+            pg_event_record(B.ev_bg_done, ms);
+            pg_stream_wait(B.stream, B.ev_bg_done);
+        }
         // mirrors that have to be (re)built for this launch, and sparse records that must catch up first
         if (!MP.to_sparsify.empty())
             flush_mirror_jobs(nb, MP.to_sparsify, false);
@@ -478,6 +496,9 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
 #endif
         HIP_CHECK(hipGetLastError());
         release_pending_segments(ms);
+        if (background && i < n)
+            for (size_t t = chunk_begin; t < i; t++)
+                bg_earlier.insert(block_key_any(list[t]->opdst));
     }
     if (background)
     {

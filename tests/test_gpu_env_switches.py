@@ -21,6 +21,11 @@ SWITCHES = [
     {"PANGULU_HIP_OCCUPANCY_SUMMARIES": "0"},  # no host-side pattern summaries: maps read behind the mirrors, full work lists
     {"PANGULU_HIP_RESERVED_CUS": "8"},         # CU-masked bulk streams
     {"PANGULU_HIP_LAUNCH_CHUNK": "64"},        # launches cut into chunks of 64 tasks
+    # launches of 8 tasks: a destination's queue is cut between launches, and on the background stream the mirror jobs of the later
+    # launch must wait for the kernels of the earlier one (this case gave factors 2.8e-4 off until the end of round 4)
+    {"PANGULU_HIP_LAUNCH_CHUNK": "8", "_matrix": "fem27"},
+    {"PANGULU_HIP_LAUNCH_CHUNK": "8", "PG_TEST_HIP_OPTIONS": "2=100", "_matrix": "fem27"},  # ... with more updates on the sparse records
+    {"PANGULU_HIP_LAUNCH_CHUNK": "8", "PG_TEST_HIP_OPTIONS": "2=100"},
     {"PANGULU_AMD_ASYNC_LAUNCH": "0"},         # platform calls on the scheduler thread
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0"},  # lazy updates: queues accumulate until the destination's own panel task
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64"},

@@ -79,6 +79,16 @@ def test_midsize_nb256_without_coordinates(name, gen):
     assert gpu["hip_stats"]["ssssm_dense_mfma"]["launches"] > 0
 
 
+def test_largest_factor_comparison_nb256():
+    """The largest HIP-vs-oracle comparison of the suite: elastic3d(20) (24 000 unknowns of the default bench class, F = 2.0e10:
+    about a minute of the oracle's triple loops), every entry of L and U at 1e-12."""
+    mat = M.elastic3d(20)
+    gpu = factorize(mat, 256, "hip")
+    ref = factorize(mat, 256, oracle_library("r64"))
+    _check(mat, 256, gpu, ref, res_tol=2e-12)
+    assert gpu["hip_stats"]["ssssm_dense_mfma"]["launches"] > 0
+
+
 def test_large_getrf_batches_nb256():
     """shell(180,180): 792 diagonal blocks, leaf levels with more than 128 GETRFs per batch (panel-tile look-ahead)."""
     mat = M.shell(180, 180)
