@@ -277,6 +277,8 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                     z_allowed = lds_z;
                 }
                 PG_LAUNCH(zgetrf_planes_kernel, dim3((unsigned)ztasks.size()), dim3(ZG_THREADS), lds_z, ks, (const ZGetrfTaskD *)d_ztasks, nb);
+                if (ztrsm_direct_selected() && nb == 128) // the solves of this level multiply with the inverted diagonal tiles (left behind the planes)
+                    PG_LAUNCH(zdiag_tile_inverse_kernel, dim3((unsigned)(ztasks.size() * (size_t)(nb / 16))), dim3(64), 0, ks, (const ZGetrfTaskD *)d_ztasks, nb);
                 if (B.opt_count_flops)
                     PG_LAUNCH(getrf_flop_count_kernel, dim3((unsigned)ztasks.size()), dim3(256), 0, ks, (const GetrfTaskD *)d_zcount, nb, B.d_flops + 1);
                 B.zgetrf_tasks += ztasks.size();

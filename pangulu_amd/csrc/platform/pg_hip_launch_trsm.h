@@ -3,6 +3,13 @@
 #pragma once
 
 // ---- TSTRF / GESSM -----------------------------------------------------------------------------------------------
+// complex types: TSTRF / GESSM on the matrix cores (ztrsm_direct_kernel; PANGULU_HIP_ZTRSM_DIRECT=0: the vector-unit kernel)
+inline bool ztrsm_direct_selected()
+{
+    static const bool on = !(getenv("PANGULU_HIP_ZTRSM_DIRECT") && atoi(getenv("PANGULU_HIP_ZTRSM_DIRECT")) == 0);
+    return on;
+}
+
 void launch_trsm(int nb, task_t **list, size_t n)
 {
     HostTimer ht(1);
@@ -258,7 +265,12 @@ void launch_trsm(int nb, task_t **list, size_t n)
                     HIP_CHECK(hipFuncSetAttribute((const void *)ztrsm_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_z));
                     zt_allowed = lds_z;
                 }
-                PG_LAUNCH(ztrsm_planes_kernel, dim3((unsigned)zt.size()), dim3(ZT_THREADS), lds_z, B.stream, (const ZTrsmTaskD *)d_zt, nb);
+                // (nb = 256: sixteen solution tiles on two planes do not fit a wavefront's registers -- 1110 spilled -- and the complex
+                //  types' block order is 128, DESIGN.md 7: the vector-unit kernel stays there)
+                if (ztrsm_direct_selected() && nb == 128)
+                    PG_LAUNCH(ztrsm_direct_kernel<8>, dim3((unsigned)zt.size()), dim3(256), 0, B.stream, (const ZTrsmTaskD *)d_zt);
+                else
+                    PG_LAUNCH(ztrsm_planes_kernel, dim3((unsigned)zt.size()), dim3(ZT_THREADS), lds_z, B.stream, (const ZTrsmTaskD *)d_zt, nb);
             }
 #endif
 #if defined(PG_DENSE_PANELS)

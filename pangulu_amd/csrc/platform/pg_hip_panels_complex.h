@@ -480,3 +480,243 @@ __global__ __launch_bounds__(ZT_THREADS) void ztrsm_planes_kernel(const ZTrsmTas
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4 (end): TSTRF / GESSM of the complex types on the matrix cores.
+//
+// ztrsm_planes_kernel above is right-looking on the vector units: per panel every entry right of (below) it makes a round trip
+// to memory -- poisson3d(80) CR64, nb = 128: 95 ms of 288 per factorisation (profiles/r04y_cr64_poisson80_kernel_stats.csv),
+// 0.96 ms per launch.  Here the solve is the R64 one (pg_hip_trsm_dense.h, trsm_dense_direct_body) on two planes: one wavefront
+// per 16-row (TSTRF) / 16-column (GESSM) strip keeps ALL its solution tiles in registers, left-looking,
+//     X_p = (B_p - sum_{q<p} X_q U_qp) inv(U_pp)           X_p = inv(L_pp) (B_p - sum_{q<p} L_pq X_q)
+// every complex tile product as four real v_mfma_f64_16x16x4_f64 products on the planes (re -= Ar Xr, re += Ai Xi, im -= Ar Xi,
+// im -= Ai Xr: the NEG bit of the instruction does the signs), factor tiles straight from the L\U image (L2) into operand
+// registers one stage ahead, no LDS, no barriers.  The inverses of the image's 16 x 16 diagonal tiles come from
+// zdiag_tile_inverse_kernel, which runs behind zgetrf_planes_kernel and leaves them in the slack behind the planes (the
+// 16 * nb doubles a blocked R64 GETRF saves its diagonal tiles in; unused by the complex types): tile p at p * 256, column-major,
+// upper part inv(U_pp), strictly lower part inv(L_pp) without its unit diagonal -- the image itself stays L\U, the sparsify job
+// behind the factorisation reads it.  Inverting instead of substituting costs a few ulps on these tiles (pivots clamped like
+// the factorisation clamps them); parity: 1e-12 / 1e-5 of the oracle like the rest.
+// PANGULU_HIP_ZTRSM_DIRECT=0 selects ztrsm_planes_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void zdiag_tile_inverse_kernel(const ZGetrfTaskD *__restrict__ tasks, int nb)
+{
+    const int np = nb / 16;
+    const int p = (int)(blockIdx.x % (unsigned)np);
+    double *Dr = tasks[blockIdx.x / (unsigned)np].dense, *Di = Dr + mirror_plane_stride(nb);
+    __shared__ double Tr[16][17], Ti[16][17]; // T[row][col]
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)(16 * p) * nb + 16 * p;
+    for (int i = lane; i < 256; i += 64)
+    {
+        Tr[i & 15][i >> 4] = Dr[base + (size_t)(i >> 4) * nb + (i & 15)];
+        Ti[i & 15][i >> 4] = Di[base + (size_t)(i >> 4) * nb + (i & 15)];
+    }
+    __syncthreads();
+    if (lane >= 16)
+        return;
+    const int c = lane;
+    double xur[16], xui[16], xlr[16], xli[16];
+    // U x = e_c
+#pragma unroll
+    for (int r = 15; r >= 0; r--)
+    {
+        double sr = (r == c) ? 1.0 : 0.0, si = 0.0;
+#pragma unroll
+        for (int k = 15; k > r; k--)
+            z_submul(sr, si, Tr[r][k], Ti[r][k], xur[k], xui[k]);
+        double rr, ri;
+        z_pivot_rcp(Tr[r][r], Ti[r][r], rr, ri);
+        z_mul(sr, si, rr, ri);
+        xur[r] = (r > c) ? 0.0 : sr;
+        xui[r] = (r > c) ? 0.0 : si;
+    }
+    // L x = e_c  (unit lower)
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        double sr = (r == c) ? 1.0 : 0.0, si = 0.0;
+#pragma unroll
+        for (int k = 0; k < r; k++)
+            z_submul(sr, si, Tr[r][k], Ti[r][k], xlr[k], xli[k]);
+        xlr[r] = (r < c) ? 0.0 : sr;
+        xli[r] = (r < c) ? 0.0 : si;
+    }
+    double *outr = Dr + (size_t)nb * nb + MIRROR_MAP_BYTES / sizeof(double) + (size_t)p * 256, *outi = outr + mirror_plane_stride(nb);
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        outr[c * 16 + r] = (r <= c) ? xur[r] : xlr[r];
+        outi[c * 16 + r] = (r <= c) ? xui[r] : xli[r];
+    }
+}
+
+// grid = (block, 64-wide slab) items, 256 threads = four wavefronts, each solving its own 16-wide strip; NP = nb / 16.
+// Register layout as in trsm_dense_direct_body: TSTRF accumulates X^T tiles (register g of lane l = X(o0 + (l & 15), 16p + (l >> 4) + 4g)),
+// GESSM X tiles (register g = X(16p + (l >> 4) + 4g, o0 + (l & 15))): a finished tile is the B operand of the later panels as it stands.
+template <int NP>
+__global__ __launch_bounds__(256) void ztrsm_direct_kernel(const ZTrsmTaskD *__restrict__ tasks)
+{
+    constexpr int nb = NP * 16;
+    const ZTrsmTaskD T = tasks[blockIdx.x];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int o0 = (int)T.slab * 64 + wave * 16;
+    double *__restrict__ Bm = T.b;
+    const double *__restrict__ LU = T.lu;
+    const bool tstrf = T.is_tstrf != 0;
+    const size_t plane_bytes = mirror_plane_stride(nb) * sizeof(double);
+    unsigned my_lv = 0; // bit p: tile p of this strip holds pattern entries
+    {
+        const unsigned short *map = mirror_map(Bm, nb);
+        const int strip = o0 >> 4;
+        if (tstrf)
+        {
+            for (int c = 0; c < NP; c++)
+                my_lv |= (((unsigned)map[c] >> strip) & 1u) << c;
+        }
+        else
+            my_lv = map[strip];
+        my_lv = (unsigned)__builtin_amdgcn_readfirstlane((int)my_lv);
+    }
+    if (my_lv == 0)
+        return;
+    typedef const char __attribute__((address_space(1))) *gbytes;
+    typedef const double __attribute__((address_space(1))) *gdouble_c;
+    typedef double __attribute__((address_space(1))) *gdouble;
+    // factor tile (q, p), q < p:  TSTRF  A'[i = c][k] = U(16q + k, 16p + c);  GESSM  A[i = r][k] = L(16p + r, 16q + k)
+    const unsigned a_voff = (unsigned)(tstrf ? l15 * nb + l4 : l4 * nb + l15) * 8u;
+#define ZT_A_LOAD(dr_, di_, q_, p_)                                                                                                  \
+    {                                                                                                                                \
+        const gbytes ab_ = (gbytes)LU + (tstrf ? (size_t)(16 * (p_)) * nb + 16 * (q_) : (size_t)(16 * (q_)) * nb + 16 * (p_)) * 8;   \
+        _Pragma("unroll") for (int kq_ = 0; kq_ < 4; kq_++)                                                                          \
+        {                                                                                                                            \
+            const gbytes sb_ = ab_ + (tstrf ? (size_t)(4 * kq_) : (size_t)(4 * kq_) * nb) * 8;                                       \
+            (dr_)[kq_] = *(gdouble_c)(dg_scalar_base(sb_) + dg_lane_offset(a_voff));                                                 \
+            (di_)[kq_] = *(gdouble_c)(dg_scalar_base(sb_ + plane_bytes) + dg_lane_offset(a_voff));                                   \
+        }                                                                                                                            \
+    }
+    // inverted diagonal tile p (zdiag_tile_inverse_kernel's layout: [c * 16 + r]):
+    //   TSTRF  A''[i = c'][k = c] = invU(c, c') -> [i * 16 + k];   GESSM  A[i = r'][k = r] = invL(r', r) -> [k * 16 + i]
+    const unsigned d_voff = (unsigned)(tstrf ? l15 * 16 + l4 : l4 * 16 + l15) * 8u;
+#define ZT_D_LOAD(dr_, di_, p_)                                                                                                      \
+    {                                                                                                                                \
+        const gbytes db_ = (gbytes)LU + ((size_t)nb * nb + MIRROR_MAP_BYTES / sizeof(double) + (size_t)(p_) * 256) * 8;              \
+        _Pragma("unroll") for (int kq_ = 0; kq_ < 4; kq_++)                                                                          \
+        {                                                                                                                            \
+            const gbytes sb_ = db_ + (tstrf ? (size_t)(4 * kq_) : (size_t)(4 * kq_) * 16) * 8;                                       \
+            (dr_)[kq_] = *(gdouble_c)(dg_scalar_base(sb_) + dg_lane_offset(d_voff));                                                 \
+            (di_)[kq_] = *(gdouble_c)(dg_scalar_base(sb_ + plane_bytes) + dg_lane_offset(d_voff));                                   \
+        }                                                                                                                            \
+    }
+    const unsigned x_voff = (unsigned)(tstrf ? l4 * nb + l15 : l15 * nb + l4) * 8u;
+#define ZT_X(plane_, p_, g_)                                                                                                         \
+    (*(gdouble)(dg_scalar_base((gbytes)Bm + (tstrf ? (size_t)(16 * (p_) + 4 * (g_)) * nb + o0 : (size_t)o0 * nb + 16 * (p_) + 4 * (g_)) * 8 + \
+                               ((plane_) ? plane_bytes : 0)) + dg_lane_offset(x_voff)))
+    v4f64 xr[NP], xi[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            const bool lv = (my_lv >> p) & 1u;
+            xr[p][g] = lv ? ZT_X(0, p, g) : 0.0;
+            xi[p][g] = lv ? ZT_X(1, p, g) : 0.0;
+        }
+    // factor tiles in flight: two register sets used in turn (the loops unroll: the set index is static); the inverted diagonal
+    // tile and the first factor tile of a panel are requested at the end of the panel before, ahead of its diagonal multiply
+    double atr[2][4], ati[2][4], adr[2][4], adi[2][4];
+    bool fetched = false;
+    int set0 = 0;
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+    {
+        const int st = set0;
+        set0 = (set0 + p) & 1; // a panel has p stages
+        if (!((my_lv >> p) & 1u))
+        {
+            fetched = false;
+            continue; // (wavefront-uniform)
+        }
+        if (!fetched)
+        {
+            ZT_D_LOAD(adr[p & 1], adi[p & 1], p)
+            if (p > 0 && (my_lv & 1u))
+                ZT_A_LOAD(atr[st], ati[st], 0, p)
+        }
+        v4f64 pr[4], pi[4];
+        pr[0] = xr[p];
+        pi[0] = xi[p];
+        pr[1] = pr[2] = pr[3] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        pi[1] = pi[2] = pi[3] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < p; q++)
+        {
+            const int cur = (st + q) & 1, nxt = cur ^ 1;
+            __builtin_amdgcn_sched_barrier(0); // (fully unrolled, the scheduler otherwise hoists the loads of many stages: 1110 spilled registers at NP = 16)
+            if (q + 1 < p && ((my_lv >> (q + 1)) & 1u))
+                ZT_A_LOAD(atr[nxt], ati[nxt], q + 1, p)
+            if ((my_lv >> q) & 1u)
+            {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++)
+                {
+                    pr[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[cur][kq], xr[q][kq], pr[kq], 0, 0, 1); // re -= Ar Xr
+                    pi[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(atr[cur][kq], xi[q][kq], pi[kq], 0, 0, 1); // im -= Ar Xi
+                    pr[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(ati[cur][kq], xi[q][kq], pr[kq], 0, 0, 0); // re += Ai Xi
+                    pi[kq] = __builtin_amdgcn_mfma_f64_16x16x4f64(ati[cur][kq], xr[q][kq], pi[kq], 0, 0, 1); // im -= Ai Xr
+                }
+            }
+        }
+        fetched = false;
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 1 < NP && ((my_lv >> (p + 1)) & 1u))
+        {
+            ZT_D_LOAD(adr[(p + 1) & 1], adi[(p + 1) & 1], p + 1)
+            if (my_lv & 1u)
+                ZT_A_LOAD(atr[set0], ati[set0], 0, p + 1)
+            fetched = true;
+        }
+        const v4f64 ar = (pr[0] + pr[1]) + (pr[2] + pr[3]), ai = (pi[0] + pi[1]) + (pi[2] + pi[3]);
+        v4f64 yr = {0.0, 0.0, 0.0, 0.0}, yi = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++)
+        {
+            const int k = kq * 4 + l4;
+            double dr = adr[p & 1][kq], di = adi[p & 1][kq];
+            if (tstrf)
+            {
+                // invU(k, i) with i = l15: upper part of the tile
+                dr = (k <= l15) ? dr : 0.0;
+                di = (k <= l15) ? di : 0.0;
+            }
+            else
+            {
+                // invL(i, k) with i = l15: strictly lower part, unit diagonal
+                dr = (l15 > k) ? dr : ((l15 == k) ? 1.0 : 0.0);
+                di = (l15 > k) ? di : 0.0;
+            }
+            yr = __builtin_amdgcn_mfma_f64_16x16x4f64(dr, ar[kq], yr, 0, 0, 0); // re += Dr ar
+            yi = __builtin_amdgcn_mfma_f64_16x16x4f64(dr, ai[kq], yi, 0, 0, 0); // im += Dr ai
+            yr = __builtin_amdgcn_mfma_f64_16x16x4f64(di, ai[kq], yr, 0, 0, 1); // re -= Di ai
+            yi = __builtin_amdgcn_mfma_f64_16x16x4f64(di, ar[kq], yi, 0, 0, 0); // im += Di ar
+        }
+        xr[p] = yr;
+        xi[p] = yi;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+    {
+        if (!((my_lv >> p) & 1u))
+            continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            ZT_X(0, p, g) = xr[p][g];
+            ZT_X(1, p, g) = xi[p][g];
+        }
+    }
+#undef ZT_X
+#undef ZT_D_LOAD
+#undef ZT_A_LOAD
+}

@@ -1,7 +1,8 @@
 """poisson3d(N) CR64: residual of pangulu_gstrs and the device-side factor check side by side (which of the two phases is off?)
     python tools/cr64_diag.py N nb"""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pangulu_amd as pa
 from pangulu_amd import _lib, matrices as M
