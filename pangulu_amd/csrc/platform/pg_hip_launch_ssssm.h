@@ -449,17 +449,29 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 B.general_workgroups += nw - nfm;
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 unsigned long long *pc = B.opt_count_flops ? B.d_flops + 6 : nullptr;
+                // the two launches of a call on two streams (PANGULU_HIP_FRONT_FORK=0: one behind the other on one stream), so that workgroups of both are resident at once
+                // (one bound by the matrix pipes, the other by its per-step latencies) instead of one launch behind the other's tail.
+                const bool fork_front = nf && nw && B.opt_front_fork && !B.opt_profile;
+                hipStream_t fs = ds;
+                if (fork_front)
+                {
+                    fs = B.stream_front;
+                    pg_event_record(B.ev_front_fork, ds);
+                    pg_stream_wait(fs, B.ev_front_fork);
+                }
                 if (nf)
                 {
                     // the longest-running workgroups first: the front launch, then the general one fills in behind it
                     const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_front_unit);
                     if (B.opt_front_stages >= 4)
-                        PG_LAUNCH((ssssm_front_f64_kernel<4, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<4, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc, unit);
                     else if (B.opt_front_stages == 3)
-                        PG_LAUNCH((ssssm_front_f64_kernel<3, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<3, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc, unit);
                     else
-                        PG_LAUNCH((ssssm_front_f64_kernel<2, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<2, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc, unit);
                 }
+                if (fork_front)
+                    pg_event_record(B.ev_front_join, fs);
                 if (nw && B.opt_tiles_stages >= 2)
                 {
                     // round 3: LDS-DMA pipeline, strided piece ownership (pg_hip_front.h)
@@ -481,6 +493,8 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 else if (nw)
                     PG_LAUNCH(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb, pc,
                                        debug_ssssm ? B.d_flops + 8 : nullptr, d_work);
+                if (fork_front)
+                    pg_stream_wait(ds, B.ev_front_join);
             }
             if (B.opt_count_flops)
                 PG_LAUNCH(ssssm_flop_count_kernel, dim3((unsigned)nd), dim3(256), 0, ds, d_tasks_d, nb, B.d_flops + 5);

@@ -581,6 +581,28 @@ __global__ __launch_bounds__(256) void ztrsm_direct_kernel(const ZTrsmTaskD *__r
     }
     if (my_lv == 0)
         return;
+    // which factor tiles hold pattern entries: the map densify left behind the image's real plane is the diagonal block's SYMBOLIC
+    // pattern (fill included), so it describes L\U as well; a product with an empty factor tile is an exact no-op and is left out
+    // (leaf-level diagonal blocks are sparse at tile granularity)
+    unsigned fm[NP];
+    {
+        const unsigned short *fmap = mirror_map(LU, nb);
+#pragma unroll
+        for (int c = 0; c < NP; c++)
+            fm[c] = (unsigned)__builtin_amdgcn_readfirstlane((int)fmap[c]);
+    }
+#define ZT_LIVE_Q(out_, p_)                                                         \
+    {                                                                               \
+        unsigned fl_ = 0;                                                           \
+        if (tstrf)                                                                  \
+            fl_ = fm[p_]; /* tile column p of the image: bit q = rows 16q.. */      \
+        else                                                                        \
+        {                                                                           \
+            _Pragma("unroll") for (int q_ = 0; q_ < NP; q_++)                       \
+                fl_ |= ((fm[q_] >> (p_)) & 1u) << q_; /* tile row p: bit q = columns 16q.. */ \
+        }                                                                           \
+        (out_) = my_lv & fl_;                                                       \
+    }
     typedef const char __attribute__((address_space(1))) *gbytes;
     typedef const double __attribute__((address_space(1))) *gdouble_c;
     typedef double __attribute__((address_space(1))) *gdouble;
@@ -638,10 +660,12 @@ __global__ __launch_bounds__(256) void ztrsm_direct_kernel(const ZTrsmTaskD *__r
             fetched = false;
             continue; // (wavefront-uniform)
         }
+        unsigned lq;
+        ZT_LIVE_Q(lq, p)
         if (!fetched)
         {
             ZT_D_LOAD(adr[p & 1], adi[p & 1], p)
-            if (p > 0 && (my_lv & 1u))
+            if (p > 0 && (lq & 1u))
                 ZT_A_LOAD(atr[st], ati[st], 0, p)
         }
         v4f64 pr[4], pi[4];
@@ -654,9 +678,9 @@ __global__ __launch_bounds__(256) void ztrsm_direct_kernel(const ZTrsmTaskD *__r
         {
             const int cur = (st + q) & 1, nxt = cur ^ 1;
             __builtin_amdgcn_sched_barrier(0); // (fully unrolled, the scheduler otherwise hoists the loads of many stages: 1110 spilled registers at NP = 16)
-            if (q + 1 < p && ((my_lv >> (q + 1)) & 1u))
+            if (q + 1 < p && ((lq >> (q + 1)) & 1u))
                 ZT_A_LOAD(atr[nxt], ati[nxt], q + 1, p)
-            if ((my_lv >> q) & 1u)
+            if ((lq >> q) & 1u)
             {
 #pragma unroll
                 for (int kq = 0; kq < 4; kq++)
@@ -672,8 +696,10 @@ __global__ __launch_bounds__(256) void ztrsm_direct_kernel(const ZTrsmTaskD *__r
         __builtin_amdgcn_sched_barrier(0);
         if (p + 1 < NP && ((my_lv >> (p + 1)) & 1u))
         {
+            unsigned lqn;
+            ZT_LIVE_Q(lqn, p + 1)
             ZT_D_LOAD(adr[(p + 1) & 1], adi[(p + 1) & 1], p + 1)
-            if (my_lv & 1u)
+            if (lqn & 1u)
                 ZT_A_LOAD(atr[set0], ati[set0], 0, p + 1)
             fetched = true;
         }
@@ -717,6 +743,7 @@ __global__ __launch_bounds__(256) void ztrsm_direct_kernel(const ZTrsmTaskD *__r
         }
     }
 #undef ZT_X
+#undef ZT_LIVE_Q
 #undef ZT_D_LOAD
 #undef ZT_A_LOAD
 }

@@ -13,7 +13,7 @@ from tests.helpers import library_for, oracle_library
 lib = library_for(oracle_library("r64"))
 N = int(sys.argv[1]); nb = 256
 which = sys.argv[2] if len(sys.argv) > 2 else "fem27"
-mat = {"fem27": lambda: M.fem27(N), "shell": lambda: M.shell(N, N), "poisson3d": lambda: M.poisson3d(N)}[which]()
+mat = {"fem27": lambda: M.fem27(N), "shell": lambda: M.shell(N, N), "poisson3d": lambda: M.poisson3d(N), "elastic3d": lambda: M.elastic3d(N)}[which]()
 n, cp, ri, va, co = mat
 h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, ordering="nd", coords=co, lib=lib, nthread=8)
 blocks = {}
