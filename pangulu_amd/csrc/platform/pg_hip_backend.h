@@ -38,10 +38,13 @@ struct Backend
     hipStream_t stream2 = nullptr; // side stream: the MFMA update kernel runs beside the LDS update kernel
     hipStream_t stream3 = nullptr; // second side stream: GETRFs of a batch run beside its TSTRF/GESSM solves
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
-    // the dense-front launch of an update call on a stream of its own, beside the general launch (PANGULU_HIP_FRONT_FORK=0: one stream; see launch_ssssm)
+    // the dense-front launch of an update call on a stream of its own, beside the general launch (PANGULU_HIP_FRONT_FORK=1; see launch_ssssm)
     hipStream_t stream_front = nullptr;
     hipEvent_t ev_front_fork = nullptr, ev_front_join = nullptr;
-    long long opt_front_fork = 1; // (0.3-0.8 % on elastic3d(48) / fem27(80, 96), six A/B pairs on one box: profiles/r04aa_front_fork_ab.log)
+    // OFF by default: 0.3-0.8 % on elastic3d(48) / fem27(80, 96) (six A/B pairs on one box, profiles/r04aa_front_fork_ab.log), 1598.9 -> 1590.8 ms
+    // on the default bench matrix -- but the two launches then overlap in a kernel trace and rocprofv3's per-kernel durations no longer add
+    // up to the update class's launch time that bench.py's roofline is quoted on (profiles/r04ab_*): not worth half a per cent
+    long long opt_front_fork = 0;
     bool getrf_join_pending = false;
     // Records stream: the sparse record stays the authoritative form of every finished block, but the dense kernels
     // of the following steps read mirrors and LU images only.  The sparsify jobs behind the dense solves and behind

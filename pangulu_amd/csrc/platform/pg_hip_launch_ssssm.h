@@ -449,7 +449,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 B.general_workgroups += nw - nfm;
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 unsigned long long *pc = B.opt_count_flops ? B.d_flops + 6 : nullptr;
-                // the two launches of a call on two streams (PANGULU_HIP_FRONT_FORK=0: one behind the other on one stream), so that workgroups of both are resident at once
+                // PANGULU_HIP_FRONT_FORK=1 (off by default, see Backend::opt_front_fork): the two launches of a call on two streams, so that workgroups of both are resident at once
                 // (one bound by the matrix pipes, the other by its per-step latencies) instead of one launch behind the other's tail.
                 const bool fork_front = nf && nw && B.opt_front_fork && !B.opt_profile;
                 hipStream_t fs = ds;

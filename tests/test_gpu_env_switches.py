@@ -26,7 +26,7 @@ SWITCHES = [
     {"PANGULU_HIP_LAUNCH_CHUNK": "8", "_matrix": "fem27"},
     {"PANGULU_HIP_LAUNCH_CHUNK": "8", "PG_TEST_HIP_OPTIONS": "2=100", "_matrix": "fem27"},  # ... with more updates on the sparse records
     {"PANGULU_HIP_LAUNCH_CHUNK": "8", "PG_TEST_HIP_OPTIONS": "2=100"},
-    {"PANGULU_HIP_FRONT_FORK": "0", "_matrix": "fem27"},  # dense-front and general update launches on one stream (default: two)
+    {"PANGULU_HIP_FRONT_FORK": "1", "_matrix": "fem27"},  # dense-front and general update launches on two streams (default: one)
     {"PANGULU_AMD_ASYNC_LAUNCH": "0"},         # platform calls on the scheduler thread
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0"},  # lazy updates: queues accumulate until the destination's own panel task
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64"},
