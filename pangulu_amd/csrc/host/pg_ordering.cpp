@@ -217,6 +217,138 @@ void coarsen(const LGraph &g, LGraph &c, std::vector<u32> &cmap, u32 maxvw, Rng 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Indistinguishable vertices -- equal CLOSED neighbourhoods inside the region: the unknowns of one mesh node in a problem with
+// several degrees of freedom per node -- collapsed into one weighted vertex each (what METIS_NodeND does before it dissects,
+// `compress`).  Some minimum separator keeps such a group on one side, so nothing is lost; what is gained is that a refinement
+// move carries the whole node (moving one of three unknowns never has a positive gain: single-vertex FM is stuck in every
+// local minimum of such a graph) and a graph a third the size.  elastic3d(77) without coordinates, 3 unknowns per node:
+// root separator 20 493 -> see DESIGN.md 3.2.  Returns false (c untouched) when fewer than a fifth of the vertices would go.
+// ------------------------------------------------------------------------------------------------------------------
+bool compress_indistinguishable(const LGraph &g, LGraph &c, std::vector<u32> &cmap)
+{
+    const u32 n = g.n;
+    auto mix = [](u64 x)
+    {
+        x += 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    };
+    std::vector<u64> h(n);
+    for (u32 v = 0; v < n; v++)
+    {
+        u64 a = mix(v);
+        for (u32 p = g.xadj[v]; p < g.xadj[v + 1]; p++)
+            a += mix(g.adj[p]);
+        h[v] = a;
+    }
+    std::vector<u32> ord(n);
+    std::iota(ord.begin(), ord.end(), 0u);
+    auto deg = [&](u32 v)
+    { return g.xadj[v + 1] - g.xadj[v]; };
+    std::sort(ord.begin(), ord.end(), [&](u32 a, u32 b)
+              {
+                  if (h[a] != h[b])
+                      return h[a] < h[b];
+                  if (deg(a) != deg(b))
+                      return deg(a) < deg(b);
+                  return a < b; });
+    std::vector<u32> leader(n);
+    std::iota(leader.begin(), leader.end(), 0u);
+    std::vector<u32> la, lb, heads;
+    auto closed = [&](u32 v, std::vector<u32> &out)
+    {
+        out.assign(g.adj.begin() + g.xadj[v], g.adj.begin() + g.xadj[v + 1]);
+        out.push_back(v);
+        std::sort(out.begin(), out.end());
+    };
+    u32 merged = 0;
+    for (u32 b = 0; b < n;)
+    {
+        u32 e = b + 1;
+        while (e < n && h[ord[e]] == h[ord[b]] && deg(ord[e]) == deg(ord[b]))
+            e++;
+        if (e - b >= 2)
+        {
+            // (equal sums can collide: every member is compared with the heads of the classes found in the run so far)
+            heads.assign(1, ord[b]);
+            for (u32 k = b + 1; k < e; k++)
+            {
+                const u32 v = ord[k];
+                closed(v, la);
+                bool found = false;
+                for (u32 hd : heads)
+                {
+                    closed(hd, lb);
+                    if (la == lb)
+                    {
+                        leader[v] = hd; // (hd < v: the run is sorted by index)
+                        merged++;
+                        found = true;
+                        break;
+                    }
+                }
+                if (!found)
+                    heads.push_back(v);
+            }
+        }
+        b = e;
+    }
+    if ((u64)merged * 5 < (u64)n)
+        return false;
+    cmap.assign(n, NONE);
+    u32 cn = 0;
+    for (u32 v = 0; v < n; v++)
+        cmap[v] = leader[v] == v ? cn++ : cmap[leader[v]];
+    // members of every group, grouped (counting sort by group)
+    std::vector<u32> start((size_t)cn + 1, 0), members(n);
+    for (u32 v = 0; v < n; v++)
+        start[cmap[v] + 1]++;
+    for (u32 k = 0; k < cn; k++)
+        start[k + 1] += start[k];
+    {
+        std::vector<u32> cur(start.begin(), start.end() - 1);
+        for (u32 v = 0; v < n; v++)
+            members[cur[cmap[v]]++] = v;
+    }
+    c.n = cn;
+    c.vw.assign(cn, 0);
+    c.xadj.assign((size_t)cn + 1, 0);
+    c.adj.clear();
+    c.adjw.clear();
+    c.adj.reserve(g.adj.size() / 4 + 16);
+    c.adjw.reserve(g.adj.size() / 4 + 16);
+    c.total = g.total;
+    std::vector<u32> mark(cn, NONE);
+    for (u32 cu = 0; cu < cn; cu++)
+    {
+        const u32 row = (u32)c.adj.size();
+        for (u32 k = start[cu]; k < start[cu + 1]; k++)
+        {
+            const u32 w = members[k];
+            c.vw[cu] += g.vw[w];
+            for (u32 p = g.xadj[w]; p < g.xadj[w + 1]; p++)
+            {
+                const u32 cx = cmap[g.adj[p]];
+                if (cx == cu)
+                    continue;
+                const u32 m = mark[cx];
+                if (m != NONE && m >= row && m < c.adj.size())
+                    c.adjw[m] += g.adjw[p];
+                else
+                {
+                    mark[cx] = (u32)c.adj.size();
+                    c.adj.push_back(cx);
+                    c.adjw.push_back(g.adjw[p]);
+                }
+            }
+        }
+        c.xadj[cu + 1] = (u32)c.adj.size();
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Two-sided vertex-separator refinement (Fiduccia-Mattheyses on separators, as in multilevel nested dissection codes).
 // where[v]: 0 / 1 = the sides, 2 = separator; invariant: no edge joins side 0 and side 1.  Moving a separator vertex v to
 // side s pulls its neighbours on the other side into the separator: gain_s(v) = w(v) - sum of their weights.  A pass moves
@@ -799,8 +931,25 @@ void multilevel_separator(const LGraph &g0, std::vector<unsigned char> &where, u
             memcpy(best_pw, wpw, sizeof(best_pw));
         }
     };
-    for (int attempt = 0; attempt < std::max(1, attempts); attempt++)
+    // The attempts are independent: each coarsens anew from its own random stream (seeds drawn here, in order, so the result does
+    // not depend on which thread runs which attempt) and they run as OpenMP tasks -- at the root of the dissection, where they are
+    // asked for, nothing else is there to run beside them.  Their separators are compared afterwards, in attempt order.
+    struct Attempt
     {
+        std::vector<unsigned char> w_edge, w_node;
+        u64 pw_edge[3] = {0, 0, 0}, pw_node[3] = {0, 0, 0};
+        bool has_edge = false, has_node = false;
+    };
+    const int nattempts = std::max(1, attempts);
+    std::vector<Attempt> results((size_t)nattempts);
+    std::vector<u64> seeds((size_t)nattempts);
+    for (int a = 0; a < nattempts; a++)
+        seeds[a] = ((u64)rng.next() << 32) | rng.next();
+    auto run_attempt = [&](int attempt)
+    {
+        Rng rng(seeds[attempt]);
+        FmScratch S;
+        Attempt &out = results[attempt];
         // (every attempt coarsens anew: the random matchings are where the variance between attempts comes from)
         std::vector<std::unique_ptr<LGraph>> levels;
         std::vector<std::vector<u32>> cmaps;
@@ -869,7 +1018,9 @@ void multilevel_separator(const LGraph &g0, std::vector<unsigned char> &where, u
                 weights_of(g0, w, npw);
                 node_fm(g0, w, npw, maxpw_node, 6, S);
             }
-            offer(w, npw, "edge");
+            out.w_edge.swap(w);
+            memcpy(out.pw_edge, npw, sizeof(npw));
+            out.has_edge = true;
         }
         if (way_node)
         {
@@ -887,8 +1038,26 @@ void multilevel_separator(const LGraph &g0, std::vector<unsigned char> &where, u
                 weights_of(fine, w, npw);
                 node_fm(fine, w, npw, maxpw_node, 6, S);
             }
-            offer(w, npw, "node");
+            out.w_node.swap(w);
+            memcpy(out.pw_node, npw, sizeof(npw));
+            out.has_node = true;
         }
+    };
+    const bool parallel_attempts = nattempts > 1 && g0.n >= 20000;
+#pragma omp taskgroup
+    {
+        for (int attempt = 0; attempt < nattempts; attempt++)
+        {
+#pragma omp task default(shared) firstprivate(attempt) if (parallel_attempts)
+            run_attempt(attempt);
+        }
+    }
+    for (int attempt = 0; attempt < nattempts; attempt++)
+    {
+        if (results[attempt].has_edge)
+            offer(results[attempt].w_edge, results[attempt].pw_edge, "edge");
+        if (results[attempt].has_node)
+            offer(results[attempt].w_node, results[attempt].pw_node, "node");
     }
     if (way_level || best.empty())
     {
@@ -957,10 +1126,11 @@ struct Dissector
     }
 
     // The separators near the root carry the large fronts: a region of at least an eighth of the graph gets several attempts
-    // (other random matchings), the best separator is kept (PANGULU_AMD_ND_ATTEMPTS, default 3; 1 below that size).
+    // (other random matchings, run as concurrent tasks), the best separator is kept (PANGULU_AMD_ND_ATTEMPTS, default 8 -- 3 until the end of
+    // round 4: elastic3d(77) without coordinates F 7.98e13 -> 7.65e13 --; 1 below that size).
     int attempts_for(u32 m) const
     {
-        static const int top = getenv("PANGULU_AMD_ND_ATTEMPTS") ? atoi(getenv("PANGULU_AMD_ND_ATTEMPTS")) : 3;
+        static const int top = getenv("PANGULU_AMD_ND_ATTEMPTS") ? atoi(getenv("PANGULU_AMD_ND_ATTEMPTS")) : 8;
         return (u64)m * 8 >= (u64)G.n ? top : 1;
     }
     u32 new_region()
@@ -1230,7 +1400,20 @@ struct Dissector
             }
             if (!have && multilevel)
             {
-                multilevel_separator(g, where, pw, ub, rng, attempts_for(m));
+                static const bool compress_on = !(getenv("PANGULU_AMD_ND_COMPRESS") && atoi(getenv("PANGULU_AMD_ND_COMPRESS")) == 0);
+                LGraph gc;
+                std::vector<u32> cm;
+                if (compress_on && m >= 1024 && compress_indistinguishable(g, gc, cm))
+                {
+                    // the separator of the compressed graph, carried back: a node's unknowns stay together
+                    std::vector<unsigned char> wc;
+                    multilevel_separator(gc, wc, pw, ub, rng, attempts_for(m));
+                    where.resize(m);
+                    for (u32 i = 0; i < m; i++)
+                        where[i] = wc[cm[i]];
+                }
+                else
+                    multilevel_separator(g, where, pw, ub, rng, attempts_for(m));
                 have = pw[0] > 0 && pw[1] > 0 && pw[2] > 0;
             }
             if (!have && !multilevel && levelset_sides(g, where))

@@ -74,3 +74,15 @@ def test_elastic3d_has_serenas_row_length():
     # (values are not symmetric by construction; the pattern is)
     P = (A != 0).astype(np.int8)
     assert (P != P.T).nnz == 0
+
+
+def test_unknowns_of_one_node_are_dissected_together(tlib):
+    """Several unknowns per mesh node (elastic3d: 3, every unknown of a node coupled to the same neighbours): the graph-only dissection
+    collapses indistinguishable vertices before it looks for separators (METIS_NodeND's `compress`), so that a refinement move
+    carries a whole node; without it single-vertex FM is stuck, the more so the larger the graph.  F(graph) / F(coords) with / without
+    (`PANGULU_AMD_ND_COMPRESS=0`; tools/ordering_eval.py): elastic3d(32) 0.99 / 1.05, (48) 1.01 / 1.08, (77) -- the bench matrix -- 1.08 / 1.26;
+    shell(120), six unknowns per node: 1.03 / 1.14."""
+    mat = M.elastic3d(32)
+    f_c, _ = analysis(tlib, mat, True)
+    f_g, _ = analysis(tlib, mat, False)
+    assert f_g <= 1.02 * f_c, (f_g, f_c)
