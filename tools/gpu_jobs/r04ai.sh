@@ -5,21 +5,21 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
-( time timeout 2400 python -m pytest tests -m gpu -x -q ) > gpurun_out/r04ac_gputests.log 2>&1
-tail -4 gpurun_out/r04ac_gputests.log
-bash tools/profile_recipe.sh r04ac_elastic3d_77 > gpurun_out/r04ac_profile_recipe.log 2>&1
-tail -5 gpurun_out/r04ac_profile_recipe.log | cut -c1-200
+( time timeout 2400 python -m pytest tests -m gpu -x -q ) > gpurun_out/r04ai_gputests.log 2>&1
+tail -4 gpurun_out/r04ai_gputests.log
+bash tools/profile_recipe.sh r04ai_elastic3d_77 > gpurun_out/r04ai_profile_recipe.log 2>&1
+tail -5 gpurun_out/r04ai_profile_recipe.log | cut -c1-200
 cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json 2>/dev/null
-( time timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/r04ac_bench_default.log 2> gpurun_out/r04ac_bench_default.err
+( time timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/r04ai_bench_default.log 2> gpurun_out/r04ai_bench_default.err
 python - <<'PY'
 import json
-d = json.loads(open('gpurun_out/r04ac_bench_default.log').readline())
+d = json.loads(open('gpurun_out/r04ai_bench_default.log').readline())
 r = d['roofline']
 print(d['config']['workload'][:70], d['ms_per_step'], d['value'], d['residual'], d['factor_check'], d.get('ms_per_step_scheduler_in_loop'), d.get('gstrs_s'))
 print({k: r.get(k) for k in ('achieved', 'frac', 'traffic', 'traffic_over_algorithmic', 'traffic_note', 'mfma_executed_tflops', 'avg_launch_us')})
 print("cpu", d['cpu_baseline'] and (d['cpu_baseline']['value'], d['cpu_baseline']['sample'][-200:]))
 print([(s['workload'][:22], round(s['ms_per_step'],2), round(s['value']), s['residual']) for s in d.get('secondary') or []])
 PY
-head -12 gpurun_out/r04ac_elastic3d_77_table.md | cut -c1-220
+head -12 gpurun_out/r04ai_elastic3d_77_table.md | cut -c1-220
 # ... and the complex class on the same build
-for N in 48 64 80 96; do timeout 900 python tools/bench_cr64.py $N 128 2>&1 | grep "permille=2:" | tee -a gpurun_out/r04ac_cr64.log; done
+for N in 48 64 80 96; do timeout 900 python tools/bench_cr64.py $N 128 2>&1 | grep "permille=2:" | tee -a gpurun_out/r04ai_cr64.log; done
