@@ -1131,7 +1131,10 @@ struct Dissector
     int attempts_for(u32 m) const
     {
         static const int top = getenv("PANGULU_AMD_ND_ATTEMPTS") ? atoi(getenv("PANGULU_AMD_ND_ATTEMPTS")) : 8;
-        return (u64)m * 8 >= (u64)G.n ? top : 1;
+        // ... and a region of at least a sixty-fourth of it three (PANGULU_AMD_ND_ATTEMPTS_MID): elastic3d(77) without coordinates F 7.64e13 -> 7.49e13,
+        // fem27(112) 2.76e13 -> 2.69e13 (1.01x the geometric ordering's, both), no longer to compute: these regions are dissected by concurrent tasks anyway
+        static const int mid = getenv("PANGULU_AMD_ND_ATTEMPTS_MID") ? atoi(getenv("PANGULU_AMD_ND_ATTEMPTS_MID")) : 3;
+        return (u64)m * 8 >= (u64)G.n ? top : ((u64)m * 64 >= (u64)G.n ? mid : 1);
     }
     u32 new_region()
     {
