@@ -33,7 +33,7 @@ def analysis(lib, mat, coords):
 
 # (matrix, F(graph) / F(coords) at most, F(coords) / F(graph) at most, F(coords) at most: the values of the round this test was written in, +3 %)
 CASES = [("fem27_40", lambda: M.fem27(40), 1.3, 1.1, 5.4e10), ("shell_120", lambda: M.shell(120, 120), 1.3, 1.1, 1.37e10),
-         ("poisson3d_48", lambda: M.poisson3d(48), 1.3, 1.1, 5.6e10), ("kkt_16", lambda: M.kkt(16), 1.3, 1.1, 1.02e8)]
+         ("poisson3d_48", lambda: M.poisson3d(48), 1.3, 1.1, 5.6e10), ("kkt_16", lambda: M.kkt(16), 1.3, 1.1, 7.2e7)]
 
 
 @pytest.mark.parametrize("name,gen,graph_over_coords,coords_over_graph,f_coords_max", CASES, ids=[c[0] for c in CASES])
@@ -86,3 +86,16 @@ def test_unknowns_of_one_node_are_dissected_together(tlib):
     f_c, _ = analysis(tlib, mat, True)
     f_g, _ = analysis(tlib, mat, False)
     assert f_g <= 1.02 * f_c, (f_g, f_c)
+
+
+def test_constraint_rows_are_eliminated_ahead_of_their_unknowns(tlib):
+    """nlpkkt-class stand-in [[H, J^T], [J, -d I]]: a row of J couples two unknowns that H couples as well -- a simplicial vertex of degree two.
+    Such vertices are taken out before the dissection and ordered right ahead of their first neighbour, where they create no fill: the
+    factorisation then costs what H's own costs (kkt(24): F = 7.9e8, was 9.6e8 with the constraint rows inside the dissection; the graph-only
+    dissection 1.06x that, was 1.09-1.14x -- and 2.0x / 3.6x on the node / edge ways of the multilevel search alone)."""
+    f_h, _ = analysis(tlib, M.poisson3d(24, shift=2.0), True)
+    mat = M.kkt(24)
+    f_c, fill_c = analysis(tlib, mat, True)
+    f_g, fill_g = analysis(tlib, mat, False)
+    assert f_c <= 1.02 * f_h, (f_c, f_h)
+    assert f_g <= 1.1 * f_c, (f_g, f_c)
