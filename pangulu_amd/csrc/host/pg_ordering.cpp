@@ -1464,6 +1464,7 @@ struct Dissector
     // Vertices taken out before the dissection (order_nested_dissection: simplicial vertices of degree one or two) go out right
     // before the first of their neighbours: ahead of ALL their neighbours, where their elimination creates no fill.
     const std::vector<unsigned char> *hanging = nullptr;
+    double emitted_per_dissected = 1.0; // vertices of the matrix per vertex the dissection sees
     void emit_plain(const std::vector<u32> &vs)
     {
         for (u32 v : vs)
@@ -1633,7 +1634,9 @@ struct Dissector
         const size_t lbeg = out.size();
         emit(nd->left.get());
         const size_t lend = out.size();
-        maybe_align(nd->nleft, nd->nright);
+        // (sizes as emitted: vertices taken out before the dissection go out with their first neighbour -- the left half's count is
+        //  known, the right half's is scaled by the graph's ratio)
+        maybe_align(lend - lbeg, (size_t)((double)nd->nright * emitted_per_dissected));
         const size_t rbeg = out.size();
         emit(nd->right.get());
         const size_t rend = out.size();
@@ -1690,6 +1693,7 @@ void order_nested_dissection(const CscMatrix &A, const double *coords, int dim, 
                 else
                     D.region[v] = NONE; // (never a region's label: the dissection does not see the vertex)
             D.hanging = &hanging;
+            D.emitted_per_dissected = (double)A.n / (double)(A.n - taken);
         }
     }
     if (all.empty())
