@@ -99,3 +99,16 @@ def test_constraint_rows_are_eliminated_ahead_of_their_unknowns(tlib):
     f_g, fill_g = analysis(tlib, mat, False)
     assert f_c <= 1.02 * f_h, (f_c, f_h)
     assert f_g <= 1.1 * f_c, (f_g, f_c)
+
+
+@pytest.mark.parametrize("name,gen", [("elastic3d_20", lambda: M.elastic3d(20)), ("kkt_20", lambda: M.kkt(20))], ids=["elastic3d_20", "kkt_20"])
+def test_compressed_and_pre_eliminated_orderings_do_not_depend_on_the_thread_count(tlib, name, gen):
+    """The paths of the end of round 4 -- indistinguishable vertices collapsed, constraint rows taken out, the attempts near the root as
+    concurrent tasks from seeds drawn in order -- give the same permutation with one thread and with four."""
+    n, cp, ri, va, co = gen()
+    perms = []
+    for threads in (1, 4):
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=64, ordering="nd", coords=None, lib=tlib, nthread=threads)
+        perms.append(pa.permutation(h).tolist())
+        pa.pangulu_finalize(h)
+    assert perms[0] == perms[1]
