@@ -53,6 +53,9 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (v_mfma_f64_16x16x4: 64 cycles per 2048 flop per SIMD)
 XGMI_LINK_GBS = 153.0     # one xGMI link per GPU pair
+PARITY_TOL = 1e-10        # north star: ||Ax - b|| / ||b|| within 1e-10 of the CPU reference; the factor check is held to the same bound
+CHECK_VECTORS = 8         # factor check on the all-ones vector + 7 seeded random +-1 vectors (pangulu_amd_factor_check_vectors)
+RC_PARITY_FAILED = 4      # exit code of a run whose factors fail the gate: the line is printed with "value": null, "parity_failed": true
 CPU_GFLOPS_GUESS = 22.0   # one core of the oracle with OpenBLAS inside SSSSM (measured: 22-24 on the bench hosts), for sizing the sample only
 
 
@@ -342,6 +345,11 @@ DONE_MARK = "__PG_WORKER_DONE__"
 RC_TRANSPORT_UNAVAILABLE = 3
 
 
+def parity_ok(*values):
+    """True when every criterion is a number <= PARITY_TOL (a NaN or a missing value fails)."""
+    return all(v is not None and v <= PARITY_TOL for v in values)
+
+
 def passthrough_args(args):
     out = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--nb", str(args.nb),
            "--ordering", args.ordering, "--host-threads", str(args.host_threads)]
@@ -427,6 +435,9 @@ def supervisor(args):
         line["cpu_baseline"] = cpu
         line["config"]["worker_attempts"] = attempts
         print(json.dumps(line), flush=True)
+        if line.get("parity_failed"):
+            sys.stderr.write("[bench.py] the factors failed the parity gate (residual / factor_check > %g): no value is reported\n" % PARITY_TOL)
+            sys.exit(RC_PARITY_FAILED)
 
 
 def main():
@@ -517,11 +528,11 @@ def gpu_worker_main(args):
     info0 = h.info()
     flop = float(info0["flop"])
 
-    def one_step():
+    def one_step(handle=None):
         lib.pangulu_amd_comm_barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
-        pa.pangulu_gstrf(h)            # ends with a stream synchronise + barrier inside the library
+        pa.pangulu_gstrf(handle or h)  # ends with a stream synchronise + barrier inside the library
         torch.cuda.synchronize()
         lib.pangulu_amd_comm_barrier()
         return time.perf_counter() - t
@@ -548,7 +559,8 @@ def gpu_worker_main(args):
     mem = pa.hip_memory(lib)
 
     # the two correctness criteria of the reference on the factors the last timed step left on the device(s)
-    factor_check = pa.factor_check(h) if args.steps > 0 else None   # ||L(U 1) - A 1|| / ||A 1||  (src/pangulu_numeric.c:1082-1341)
+    # ||L(U x) - A x|| / ||A x||: x = 1 (src/pangulu_numeric.c:1082-1341) and CHECK_VECTORS - 1 random +-1 vectors, the worst of them
+    factor_check = pa.factor_check_vectors(h, CHECK_VECTORS) if args.steps > 0 else None
     residual = None
     if args.steps > 0:
         if rank == 0:
@@ -566,15 +578,18 @@ def gpu_worker_main(args):
     # One rank replays its recorded launch schedule; N > 1 ranks have to run the scheduler beside the device (arrival order is
     # dynamic).  So that a scaling curve compares like with like, a few un-timed-for-the-metric steps go through the scheduler
     # here as well, and the line carries both numbers.
-    ms_scheduler_in_loop = None
+    ms_scheduler_in_loop, sched_step_ms = None, None
     if world == 1 and args.steps > 0 and info.get("replayed") and not args.no_sched_steps:
         before = lib.pangulu_amd_set_replay(0)
         ts = []
-        for s in range(3):
+        for s in range(4):
             lib.pangulu_amd_reset_numeric(h.ref)
             ts.append(one_step())
         lib.pangulu_amd_set_replay(before)
-        ms_scheduler_in_loop = 1e3 * min(ts[1:])  # (the first one re-creates the launcher thread's buffers)
+        # the same statistic as ms_per_step (mean of the timed steps); the first step is this mode's warm-up (it re-creates the
+        # launcher thread's buffers)
+        sched_step_ms = [round(1e3 * t, 2) for t in ts[1:]]
+        ms_scheduler_in_loop = 1e3 * sum(ts[1:]) / len(ts[1:])
         pa.hip_stats(lib, reset=True)  # (the profile pass below counts its own launches only)
 
     # one extra, un-timed factorisation with per-launch hipEvents to attribute time to kernels: every launch on the ONE main
@@ -681,24 +696,23 @@ def gpu_worker_main(args):
             assert lib.pangulu_amd_snapshot(h2.ref) == 0
             ts2 = []
             for s2 in range(4):
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                pa.pangulu_gstrf(h2)
-                torch.cuda.synchronize()
-                ts2.append(time.perf_counter() - t)
+                ts2.append(one_step(h2))  # (the same bracket as the headline steps: barrier + synchronise on both sides)
                 if s2 < 3:
                     lib.pangulu_amd_reset_numeric(h2.ref)
             info2 = h2.info()
-            fc2 = pa.factor_check(h2)
+            fc2 = pa.factor_check_vectors(h2, CHECK_VECTORS)
             b2 = M.rhs_of_ones(n2, cp2, ri2, va2)
             t = time.perf_counter()
             x2 = pa.pangulu_gstrs(h2, b2)
             gstrs2 = time.perf_counter() - t
             ms2 = 1e3 * sum(ts2[1:]) / 3
+            res2 = M.relative_residual(n2, cp2, ri2, va2, x2, b2)
+            ok2 = parity_ok(res2, fc2)
             secondary.append({"workload": label, "n": int(info2["n"]), "nnz": int(info2["nnz"]), "nb": int(info2["nb"]),
                               "flop": int(info2["flop"]), "steps": 3, "warmup": 1, "ms_per_step": ms2, "step_ms": [round(1e3 * t_, 2) for t_ in ts2[1:]],
-                              "value": float(info2["flop"]) / (ms2 / 1e3) / 1e9, "unit": "GFLOP/s", "residual": M.relative_residual(n2, cp2, ri2, va2, x2, b2),
-                              "factor_check": fc2, "gstrs_s": gstrs2, "init_s": round(t_init2, 2), "static_schedule_replayed": bool(info2["replayed"])})
+                              "value": float(info2["flop"]) / (ms2 / 1e3) / 1e9 if ok2 else None, "unit": "GFLOP/s", "residual": res2,
+                              "factor_check": fc2, "parity_failed": not ok2, "gstrs_s": gstrs2, "init_s": round(t_init2, 2),
+                              "static_schedule_replayed": bool(info2["replayed"])})
             pa.pangulu_finalize(h2)
             del n2, cp2, ri2, va2, co2, b2, x2
     if world > 1:
@@ -706,12 +720,16 @@ def gpu_worker_main(args):
         lib.pangulu_amd_comm_finalize()
 
     if rank == 0:
-        value = flop / (ms_per_step / 1e3) / 1e9 if ms_per_step else 0.0
+        # THE GATE: a factorisation whose factors fail either criterion of the reference -- on the headline matrix or on a secondary
+        # one -- publishes no number (a silent wrong-result bug lived behind printed-but-unchecked residuals)
+        failed = args.steps > 0 and (not parity_ok(residual, factor_check) or any(w["parity_failed"] for w in (secondary or [])))
+        value = flop / (ms_per_step / 1e3) / 1e9 if ms_per_step and not failed else (None if failed else 0.0)
         sep_map = os.environ.get("PANGULU_AMD_SEPARATOR_MAP", "group")
         line = {
             "metric": "numeric factorisation GFLOP/s (pangulu_gstrf, R64)",
             "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "ms_per_step_scheduler_in_loop": ms_scheduler_in_loop, "gstrs_s": gstrs_s if args.steps > 0 else None,
+            "parity_failed": bool(failed), "parity_tol": PARITY_TOL,
+            "ms_per_step": ms_per_step, "ms_per_step_scheduler_in_loop": ms_scheduler_in_loop, "step_ms_scheduler_in_loop": sched_step_ms, "gstrs_s": gstrs_s if args.steps > 0 else None,
             "step_ms": [round(1e3 * t, 2) for t in times], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if not args.mtx else "file",
             "config": {
@@ -736,7 +754,9 @@ def gpu_worker_main(args):
                                 "ssssm": int(info["ntask_ssssm"])},
             },
             "residual": residual, "factor_check": factor_check,
-            "checked": "residual and factor_check are from the factors of the last timed step (timed configuration)",
+            "checked": "residual and factor_check are from the factors of the last timed step (timed configuration); factor_check = the worst of "
+                       "%d vectors (all ones + seeded random +-1); either above %g => value null, parity_failed, exit code %d" % (CHECK_VECTORS, PARITY_TOL, RC_PARITY_FAILED),
+            "factor_check_vectors": CHECK_VECTORS,
             "init_s": round(t_init, 2),
             "hbm_used_GB": round(used.value / 1e9, 2), "owned_records_GB": round(info["owned_bytes"] / 1e9, 2),
             # where the memory in use is: the records (authoritative form of every block), bench.py's own device-side snapshot of

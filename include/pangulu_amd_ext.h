@@ -161,6 +161,10 @@ extern "C"
      * they are: on the device-resident records (no download), any number of ranks (collective: every rank calls it, every
      * rank gets the value), all four value types.  Returns 0 on success, 1 if the handle has not been factorised. */
     int pangulu_amd_factor_check(void **pangulu_handle, double *relative_error);
+    /* The same criterion on `nvec` vectors -- the all-ones vector of the reference first, then nvec - 1 random +-1 vectors from a
+     * seeded generator (identical on every rank) -- and the LARGEST quotient of them.  One vector probes one direction; bench.py
+     * gates its line on nvec = 8 at full size.  Collective like pangulu_amd_factor_check; same return codes. */
+    int pangulu_amd_factor_check_vectors(void **pangulu_handle, int nvec, unsigned long long seed, double *worst_relative_error);
 
 #ifdef __cplusplus
 }

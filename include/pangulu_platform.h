@@ -268,8 +268,14 @@ extern "C"
      *     kernel -- operand slabs by LDS-DMA, strided piece ownership of the wavefronts.  2: two LDS stages, step records
      *     fetched a step ahead, the DMA instructions of the next slab issued behind the first products of the current one
      *     (ssssm_tilesv_f64_kernel); 1: two stages, DMA issue right behind the barrier; 3 or 4: that many stages
-     *     (ssssm_tiles_f64_kernel); 0: round 2's kernel (register staging, contiguous 64 x 32 sub-tiles). */
+     *     (ssssm_tiles_f64_kernel); 0: round 2's kernel (register staging, contiguous 64 x 32 sub-tiles); 5 (round 5): compacted,
+     *     piece-indexed staging -- a ring of 32 slots of one live 16 x 16 piece each, light slab steps of a queue share a batch = one
+     *     wait and one barrier (ssssm_tilesp_f64_kernel, pg_hip_pieces.h). */
 #define PANGULU_HIP_OPT_TILES_STAGES 16
+    /*   PANGULU_HIP_OPT_QUERY_FREE_MIB: a QUERY, nothing is set (value ignored): returns the free memory of the back-end's device in MiB
+     *     (hipMemGetInfo), so that a host decides placements (pangulu_amd_snapshot) by what THIS device or partition has, not by a
+     *     288 GB constant. */
+#define PANGULU_HIP_OPT_QUERY_FREE_MIB 17
     int pangulu_platform_0201001_set_option(int option, long long value);
     /* Optional: build, ahead of the numeric phase, the by-column view of a diagonal block's upper (CSR) half
      * that SSSSM updates INTO that block need (it is built lazily on first use otherwise, which costs an

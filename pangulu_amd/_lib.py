@@ -215,6 +215,8 @@ def load(vtype="r64", test_hooks=False):
     lib.pangulu_amd_apply_lu.restype = ctypes.c_int
     lib.pangulu_amd_factor_check.argtypes = [vpp, ctypes.POINTER(ctypes.c_double)]
     lib.pangulu_amd_factor_check.restype = ctypes.c_int
+    lib.pangulu_amd_factor_check_vectors.argtypes = [vpp, ctypes.c_int, ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_double)]
+    lib.pangulu_amd_factor_check_vectors.restype = ctypes.c_int
 
     lib.pangulu_platform_0201001_set_option.argtypes = [ctypes.c_int, ctypes.c_longlong]
     lib.pangulu_platform_0201001_set_option.restype = ctypes.c_int

@@ -6,6 +6,7 @@
 // L blocks, unit diagonal), the partial vectors are summed over the ranks, rank 0 prints the quotient.  Same here, but the
 // block products run on the DEVICE-resident records (pangulu_platform_0201001_block_spmv_add: one launch per sweep, no
 // download of the factors -- 46 GB for the Serena-class matrix), on the host copies for host-memory platforms.
+#include <algorithm>
 #include <cmath>
 
 #include "pg_host.h"
@@ -88,69 +89,110 @@ void sum_over_ranks(std::vector<val_t> &v)
 
 } // namespace
 
-double factor_check(Solver &S)
+namespace
 {
-    const u32 nb = S.nb, nbk = S.nbk, n = S.n;
-    const size_t len = (size_t)nbk * nb;
-    std::vector<slot_t *> slots;
-    std::vector<pangulu_exblock_idx> src, dst;
-    std::vector<int> csr;
-    auto add = [&](slot_t *s, u32 from, u32 to, int is_csr)
-    {
-        slots.push_back(s);
-        src.push_back(from);
-        dst.push_back(to);
-        csr.push_back(is_csr);
-    };
-    // t = U 1: this rank's upper blocks and upper diagonal halves
+
+// the block lists of the two sweeps (built once per call) and || L (U x) - A x ||_2 / || A x ||_2 for one vector x
+struct CheckLists
+{
+    std::vector<slot_t *> u_slots, l_slots;
+    std::vector<pangulu_exblock_idx> u_src, u_dst, l_src, l_dst;
+    std::vector<int> u_csr, l_csr;
+};
+
+CheckLists check_lists(Solver &S)
+{
+    CheckLists L;
     for (auto &s : S.storage.owned)
     {
-        if (s.brow_pos == s.bcol_pos)
+        // t = U x: this rank's upper blocks and upper diagonal halves (CSR); y = L t, L unit lower: y = t + (strictly lower part) t
+        const bool diag = s.brow_pos == s.bcol_pos;
+        if ((diag && s.is_upper) || (!diag && s.brow_pos < s.bcol_pos))
         {
-            if (s.is_upper)
-                add(&s, s.bcol_pos, s.brow_pos, 1);
+            L.u_slots.push_back(&s);
+            L.u_src.push_back(s.bcol_pos);
+            L.u_dst.push_back(s.brow_pos);
+            L.u_csr.push_back(diag ? 1 : 0);
         }
-        else if (s.brow_pos < s.bcol_pos)
-            add(&s, s.bcol_pos, s.brow_pos, 0);
+        else
+        {
+            L.l_slots.push_back(&s);
+            L.l_src.push_back(s.bcol_pos);
+            L.l_dst.push_back(s.brow_pos);
+            L.l_csr.push_back(0);
+        }
     }
-    std::vector<val_t> ones(len, czero()), t(len, czero());
-    for (u32 i = 0; i < n; i++)
-        ones[i] = cone();
-    apply_blocks(S, slots, src, dst, csr, ones, t);
+    return L;
+}
+
+double check_one_vector(Solver &S, const CheckLists &L, const std::vector<val_t> &x)
+{
+    const u32 n = S.n;
+    const size_t len = x.size();
+    std::vector<val_t> t(len, czero()), y(len, czero()), ax(len, czero());
+    apply_blocks(S, L.u_slots, L.u_src, L.u_dst, L.u_csr, x, t);
     sum_over_ranks(t);
-    // y = L t, L unit lower: y = t + (strictly lower part) t
-    slots.clear();
-    src.clear();
-    dst.clear();
-    csr.clear();
-    for (auto &s : S.storage.owned)
-    {
-        if (s.brow_pos == s.bcol_pos)
-        {
-            if (!s.is_upper)
-                add(&s, s.bcol_pos, s.brow_pos, 0);
-        }
-        else if (s.brow_pos > s.bcol_pos)
-            add(&s, s.bcol_pos, s.brow_pos, 0);
-    }
-    std::vector<val_t> y(len, czero());
-    apply_blocks(S, slots, src, dst, csr, t, y);
+    apply_blocks(S, L.l_slots, L.l_src, L.l_dst, L.l_csr, t, y);
     sum_over_ranks(y);
-    // A 1 from the reordered matrix every rank holds (row sums), the two norms
-    std::vector<val_t> a1(len, czero());
+    // A x from the reordered matrix every rank holds, the two norms
     const CscMatrix &A = S.Aperm;
     for (u32 j = 0; j < A.n; j++)
         for (u64 p = A.colptr[j]; p < A.colptr[j + 1]; p++)
-            cacc(a1[A.rowidx[p]], A.value[p]);
+            cacc(ax[A.rowidx[p]], cmul(A.value[p], x[j]));
     double num = 0, den = 0;
     for (u32 i = 0; i < n; i++)
     {
         val_t lu = y[i];
         cacc(lu, t[i]);
-        num += cabs2(csub(lu, a1[i]));
-        den += cabs2(a1[i]);
+        num += cabs2(csub(lu, ax[i]));
+        den += cabs2(ax[i]);
     }
     return den > 0 ? std::sqrt(num / den) : std::sqrt(num);
+}
+
+} // namespace
+
+double factor_check(Solver &S)
+{
+    const size_t len = (size_t)S.nbk * S.nb;
+    std::vector<val_t> ones(len, czero());
+    for (u32 i = 0; i < S.n; i++)
+        ones[i] = cone();
+    return check_one_vector(S, check_lists(S), ones);
+}
+
+// The same criterion on `nvec` vectors: the reference's all-ones vector first (src/pangulu_numeric.c:1082-1341 is the one-vector
+// form), then random +-1 vectors from a seeded generator (the same on every rank) -- the largest quotient.  One vector probes one
+// direction: an error confined to entries whose columns cancel under x = 1 does not show; eight independent sign patterns leave
+// 2^-7 of that room per entry pair.
+double factor_check_vectors(Solver &S, int nvec, unsigned long long seed)
+{
+    const size_t len = (size_t)S.nbk * S.nb;
+    const CheckLists L = check_lists(S);
+    std::vector<val_t> x(len, czero());
+    double worst = 0;
+    unsigned long long st = seed ? seed : 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < std::max(1, nvec); k++)
+    {
+        for (u32 i = 0; i < S.n; i++)
+        {
+            if (k == 0)
+            {
+                x[i] = cone();
+                continue;
+            }
+            st += 0x9E3779B97F4A7C15ull; // splitmix64
+            unsigned long long z = st;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            x[i] = (z >> 63) ? cone() : csub(czero(), cone());
+        }
+        const double q = check_one_vector(S, L, x);
+        if (!(q <= worst)) // (a NaN sticks)
+            worst = q;
+    }
+    return worst;
 }
 
 } // namespace pg

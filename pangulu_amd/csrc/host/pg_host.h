@@ -363,6 +363,7 @@ struct Solver
         {
             u32 brow, bcol, is_upper;
             slot_t *slot;
+            u64 nnz; // (of the record that landed there: the poisoning of pangulu_amd_reset_numeric's test mode needs the extent of its values)
         };
         std::vector<Entry> entries;
         std::vector<Send> sends;        // in posting order (grouped by marker)
@@ -420,6 +421,7 @@ void record_schedule(Solver &S);                          // pangulu_init, one r
 void download_factors(Solver &S);                         // device -> host mirror of owned values
 void triangular_solve(Solver &S, val_t *rhs_permuted);    // forward + backward block sweeps (host kernels)
 double factor_check(Solver &S);                           // ||L(U 1) - A 1|| / ||A 1|| on the factors where they are (pg_check.cpp; collective)
+double factor_check_vectors(Solver &S, int nvec, unsigned long long seed); // the same on the ones vector + nvec - 1 random +-1 vectors: the worst quotient
 void compute_task_model(Solver &S, double hbm_bytes_per_s, double fp_flops_per_s); // pg_model.cpp: T* of SURVEY.md §8d
 void build_structure_model(Solver &S);   // pg_model.cpp: column counts per lower block + per-column work (before the mapping)
 void compute_rank_model(Solver &S);      // pg_model.cpp: per-rank T*, flop shares, link term, critical path (after preprocess)

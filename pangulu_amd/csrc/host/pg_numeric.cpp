@@ -1002,7 +1002,7 @@ struct Sched
             ~Handled() { c.fetch_add(1, std::memory_order_release); }
         } handled{arrivals_handled};
         if (rec_multi)
-            S.rank_log.arrivals.push_back(Solver::RankLog::Arrival{h.brow, h.bcol, h.is_upper, s});
+            S.rank_log.arrivals.push_back(Solver::RankLog::Arrival{h.brow, h.bcol, h.is_upper, s, h.nnz});
         if (h.brow == h.bcol)
         {
             u32 level = h.brow;
@@ -1207,13 +1207,19 @@ static bool replay_rank_log(Solver &S)
     Solver::RankLog &L = S.rank_log;
     if (!L.valid || !plat.schedule || !plat.schedule_range || !plat.marker_record_replay)
         return false;
-    comm->barrier();
-    const double t0 = wall_seconds();
-    if (plat.schedule(7, &S) != 0)
+    // The decision to replay is taken BEFORE the start barrier: a rank that falls through to the scheduler makes that
+    // path's one start barrier, a rank that replays makes this one -- every rank exactly one, whatever the others decided.  (Checked
+    // behind the barrier, a rank whose list had gone stale made three barriers per factorisation against its peers' two and the
+    // run hung until the stall limit.)  cmd 9 is the validity rule of cmd 7 as a pure query.
+    if (plat.schedule(9, &S) != 0)
     {
         L.valid = false; // (options or back-end resources changed since the recording: schedule again, and record again)
         return false;
     }
+    comm->barrier();
+    const double t0 = wall_seconds();
+    if (plat.schedule(7, &S) != 0)
+        fatal("rank %d (replay): the recorded launch list went stale between the validity query and the start of the replay", S.rank);
     const size_t narr = L.arrivals.size();
     std::unique_ptr<std::atomic<unsigned char>[]> arrived(new std::atomic<unsigned char>[narr + 1]);
     std::unordered_map<u64, u32> index; // (brow, bcol, is_upper) -> position in the first run's arrival order

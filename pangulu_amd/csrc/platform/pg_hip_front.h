@@ -280,6 +280,11 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_front
 #define TL_PROBE_STEP
 #define TL_PROBE_FLUSH
 #endif
+#ifndef TL_ITEM
+#define TL_ITEM_DECL
+#define TL_ITEM(i)
+#define TL_ITEM_COUNT
+#endif
 template <int STAGES>
 __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb, const SsssmWorkD *__restrict__ work,
                                                                      unsigned long long *__restrict__ product_counter, unsigned unit)
@@ -737,6 +742,8 @@ __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const S
     const bool may_preload = !G.atomic && ntask <= TL_WINDOW;
 
     int stage_head = 0;
+    TL_ITEM_DECL
+    TL_ITEM_COUNT
     for (int win0 = 0; win0 < ntask; win0 += TL_WINDOW)
     {
         // ---- the window's step list (no DMA is in flight here: plain barriers) --------------------------------------
@@ -794,6 +801,7 @@ __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const S
 #endif
             }
             const unsigned long long bal = __ballot(v != 0);
+            TL_ITEM(0)
             if (lane == 0)
                 s_cnt[wave] = (u32)__builtin_popcountll(bal);
             __syncthreads();
@@ -813,6 +821,7 @@ __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const S
             }
             __syncthreads();
             T = __builtin_amdgcn_readfirstlane((int)all);
+            TL_ITEM(1)
         }
         if (T == 0)
             continue;
@@ -853,9 +862,11 @@ __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const S
         }
         // ---- the pipeline over the window's T live steps -------------------------------------------------------------
         // wC: word of the step being consumed; (wN, paN, pbN): record of the step whose slab is fetched during it
+        TL_ITEM(2)
         unsigned wC = (unsigned)__builtin_amdgcn_readfirstlane((int)s_step[0]), wN = 0;
         fr_gptr paN = uniform64(s_spa[0]), pbN = uniform64(s_spb[0]);
         issue(wC, paN, pbN, stage_head);
+        TL_ITEM(3)
         if (T > 1)
         {
             wN = (unsigned)__builtin_amdgcn_readfirstlane((int)s_step[1]);
@@ -947,6 +958,7 @@ __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const S
         }
         TL_PROBE_FLUSH
         stage_head = (stage_head + T) & 1;
+        TL_ITEM(4)
     }
     if (product_counter && lane == 0 && nprod)
         atomicAdd(product_counter, (unsigned long long)nprod);
@@ -1001,5 +1013,9 @@ __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const S
                 TL_C(ni, mi, r) = old[mi][r] + acc[ni][mi][r];
         }
     }
+#ifdef TL_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_ITEM(5)
+#endif
 #undef TL_C
 }

@@ -476,7 +476,10 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 {
                     // round 3: LDS-DMA pipeline, strided piece ownership (pg_hip_front.h)
                     const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_tiles_unit);
-                    if (B.opt_tiles_stages >= 4)
+                    if (B.opt_tiles_stages >= 5)
+                        // round 5: compacted, piece-indexed staging -- light slab steps of a queue share a batch (pg_hip_pieces.h)
+                        PG_LAUNCH(ssssm_tilesp_f64_kernel, dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                    else if (B.opt_tiles_stages >= 4)
                         PG_LAUNCH((ssssm_tiles_f64_kernel<4>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
                     else if (B.opt_tiles_stages == 3)
                         PG_LAUNCH((ssssm_tiles_f64_kernel<3>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);

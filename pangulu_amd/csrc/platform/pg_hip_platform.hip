@@ -516,6 +516,7 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 #include "pg_hip_dense.h"
 #include "pg_hip_front.h"
+#include "pg_hip_pieces.h"
 #endif
 #if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
 #include "pg_hip_trsm_dense.h"
@@ -1456,6 +1457,13 @@ extern "C"
         case PANGULU_HIP_OPT_TILES_STAGES:
             B.opt_tiles_stages = value;
             return 0;
+        case PANGULU_HIP_OPT_QUERY_FREE_MIB:
+        {
+            ensure_ready();
+            size_t free_b = 0, total_b = 0;
+            HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            return (int)(free_b >> 20);
+        }
         case PANGULU_HIP_OPT_RECORDS_STREAM:
         {
             ensure_ready();
@@ -1681,6 +1689,13 @@ extern "C"
     {
         ensure_ready();
         std::lock_guard<std::mutex> g(B.mutex);
+        // pure queries first: they launch nothing and must not flush a held GETRF (the scheduler's log asks for the
+        // operation count behind every platform call of a recording run -- with the flush in front, every such query ended the
+        // GETRF / solve chase of the recorded run and froze a chase-free launch list into every replay)
+        if (cmd == 6) // operations recorded so far (while recording) / in the list; a held GETRF's launches join the next entry's range
+            return (long long)REC.ops.size();
+        if (cmd == 9) // would cmd 7 / cmd 3 replay?  (validity rule only: owner, options signature, generation of the shared resources)
+            return (REC.valid && REC.owner == owner && REC.signature == options_signature() && REC.generation == B.generation) ? 0 : 1;
         flush_pending_getrf();
         HIP_CHECK(hipSetDevice(B.device));
         switch (cmd)
@@ -1761,8 +1776,6 @@ extern "C"
             REC.valid = true;
             return (long long)REC.ops.size();
         }
-        case 6: // operations recorded so far (while recording) / in the list
-            return (long long)REC.ops.size();
         case 7: // a replay in RANGES begins (pangulu_platform_0201001_schedule_range): same validity rule as 3; the prologue goes out
             if (!REC.valid || REC.owner != owner || REC.signature != options_signature() || REC.generation != B.generation)
                 return 1;

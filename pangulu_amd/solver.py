@@ -199,6 +199,15 @@ def factor_check(h):
     return float(out.value)
 
 
+def factor_check_vectors(h, nvec=8, seed=20251003):
+    """The factor check on the all-ones vector and nvec - 1 seeded random +-1 vectors: the largest quotient (collective)."""
+    out = ctypes.c_double(0.0)
+    rc = h.lib.pangulu_amd_factor_check_vectors(h.ref, int(nvec), int(seed), ctypes.byref(out))
+    if rc != 0:
+        raise RuntimeError("pangulu_amd_factor_check_vectors: the handle has not been factorised")
+    return float(out.value)
+
+
 def hip_memory(h_or_lib):
     """Device memory the back-end holds for itself (bytes): mirror pool, descriptor twins of a recorded schedule, GETRF scratch;
     and the number of blocks in dense mode."""

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Per-operator before/after vectors of the oracle's 0100000 operators on hand-built slots ("Next #1").
 
-    python tests/golden/make_operator_vectors.py      # rewrites tests/golden/operator_vectors.json
+    python tests/golden/make_operator_vectors.py                     # rewrites tests/golden/operator_vectors.json, KEEPING its permutation
+    python tests/golden/make_operator_vectors.py --new-permutation   # ... with the permutation today's nested dissection gives
+
+The fixture CARRIES its permutation (`case.perm`, perm[new] = old): the records are built with it as a user ordering, so a change
+of the ordering code no longer changes the vectors (they had to be regenerated two rounds running for that reason).
 
 The case is small on purpose (poisson3d(5), nb = 16, R64: 8 block rows): the whole factorisation is run one operator call per
 task in the reference's serial right-looking order (src/pangulu_kernel_interface.c:190-337); for the FIRST task of each kind
@@ -24,12 +28,23 @@ from pangulu_amd import matrices as M  # noqa: E402
 from tests import slots as S  # noqa: E402
 from tests.helpers import oracle_library  # noqa: E402
 
-CASE = {"generator": "poisson3d(5)", "nb": 16, "vtype": "r64", "ordering": "nd"}
+CASE = {"generator": "poisson3d(5)", "nb": 16, "vtype": "r64", "ordering": "frozen permutation (case.perm in the fixture)"}
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "operator_vectors.json")
 KIND = {S.GETRF: "getrf", S.TSTRF: "tstrf", S.GESSM: "gessm", S.SSSSM: "ssssm"}
 
 
 def case_matrix():
     return M.poisson3d(5)
+
+
+def frozen_perm():
+    """The permutation the committed fixture was made with."""
+    return np.array(json.load(open(FIXTURE))["perm"], dtype=np.uint32)
+
+
+def case_records(perm=None):
+    """The block records of the case under the fixture's permutation (or `perm`)."""
+    return S.exported_records(case_matrix(), CASE["nb"], CASE["vtype"], user_perm=frozen_perm() if perm is None else perm)
 
 
 def replay(call, bm, record_full=True):
@@ -68,12 +83,24 @@ def oracle_call(fo):
 
 
 def main():
-    recs = S.exported_records(case_matrix(), CASE["nb"], CASE["vtype"])
+    if "--new-permutation" in sys.argv or not os.path.exists(FIXTURE) or "perm" not in json.load(open(FIXTURE)):
+        import pangulu_amd as pa
+        from tests.helpers import library_for
+
+        n, cp, ri, va, coords = case_matrix()
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=CASE["nb"], vtype=CASE["vtype"], ordering="nd", coords=coords,
+                            lib=library_for(oracle_library(CASE["vtype"]), CASE["vtype"]))
+        perm = pa.permutation(h)
+        pa.pangulu_finalize(h)
+        assert len(perm) == n, "the case's dissection must not pad (user permutations have the matrix's order)"
+    else:
+        perm = frozen_perm()
+    recs = case_records(perm)
     bm = S.BlockMatrix(recs, CASE["nb"], np.float64, None)
     fo = S.declare_platform(ctypes.CDLL(oracle_library(CASE["vtype"])), "0100000")
     trace = replay(oracle_call(fo), bm)
-    out = {"case": CASE, "blocks": len(bm.blocks), "tasks": trace}
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "operator_vectors.json")
+    out = {"case": CASE, "perm": [int(x) for x in perm], "blocks": len(bm.blocks), "tasks": trace}
+    path = FIXTURE
     with open(path, "w") as f:
         json.dump(out, f)
     kinds = {}

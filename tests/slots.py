@@ -218,15 +218,20 @@ class BlockMatrix:
             b.free()
 
 
-def exported_records(mat, nb, vtype="r64", ordering="nd"):
-    """Block records (patterns closed under fill, values = A on its pattern, 0 on fill) as the host builds them."""
+def exported_records(mat, nb, vtype="r64", ordering="nd", user_perm=None):
+    """Block records (patterns closed under fill, values = A on its pattern, 0 on fill) as the host builds them.
+    `user_perm` (perm[new] = old): the permutation to use instead of computing an ordering -- a fixture that carries its
+    permutation pins the operators, not the ordering code."""
     import pangulu_amd as pa
 
     from .helpers import library_for, oracle_library
 
     n, cp, ri, va, coords = mat
     lib = library_for(oracle_library(vtype), vtype)
-    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=coords if ordering == "nd" else None, lib=lib)
+    if user_perm is not None:
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering="user", user_perm=user_perm, lib=lib)
+    else:
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=coords if ordering == "nd" else None, lib=lib)
     recs = list(pa.owned_blocks(h))
     pa.pangulu_finalize(h)
     return recs

@@ -77,3 +77,80 @@ def test_backend_switch_keeps_parity(env):
     assert r["dense_updates"] > 0 and r["dense_solves"] > 0 and r["getrf_launches"] > 0, r
     if env.get("PANGULU_HIP_CHASE") == "1":
         assert r["chase_launches"] > 0 and r["chase_solves"] > 0, r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A seeded random sweep next to the hand-kept list above (the list had 37 combinations and the bug of round 4 -- mirror
+# jobs of a cut background launch -- sat in a combination nobody had listed).  Every draw switches each option away from its default
+# with probability 1/4, on one of the two matrices, with launches cut into chunks of 8 / 64 tasks or not at all.  The seed is in the
+# test ids; PG_SWEEP_SEED / PG_SWEEP_DRAWS choose another sweep (e.g. a longer one before a release).
+# ---------------------------------------------------------------------------------------------------------------------
+SWEEP_SPACE = [
+    # (environment variable or back-end option number, non-default values)
+    ("PANGULU_HIP_LAUNCH_CHUNK", ["8", "64"]),
+    ("PANGULU_HIP_TRSM_DIRECT", ["0"]),
+    ("PANGULU_HIP_GETRF_TILED", ["0"]),
+    ("PANGULU_HIP_GETRF_LOOKAHEAD", ["0"]),
+    ("PANGULU_HIP_RECORDS_STREAM", ["0"]),
+    ("PANGULU_HIP_OCCUPANCY_SUMMARIES", ["0"]),
+    ("PANGULU_HIP_FRONT_FORK", ["1"]),
+    ("PANGULU_HIP_HEAVY_FIRST", ["0", "1"]),
+    ("PANGULU_HIP_EARLY_DENSIFY", ["1"]),
+    ("PANGULU_HIP_SOLVE_CHUNKED", ["0"]),
+    ("PANGULU_HIP_SMALL_LAUNCH_TASKS", ["0"]),
+    ("PANGULU_HIP_CHASE", ["1"]),
+    ("PANGULU_AMD_ASYNC_LAUNCH", ["0"]),
+    ("PANGULU_AMD_LOOKAHEAD_MAX_GETRF", ["0", "4"]),
+    ("PANGULU_AMD_PANEL_FIRST", ["0"]),
+    ("PANGULU_AMD_REPLAY", ["0"]),
+    ("PANGULU_AMD_RECORD_AT_INIT", ["0"]),
+    ("PANGULU_AMD_FORCE_MULTI_LOOP", ["1"]),
+    (2, ["10", "100"]),      # dense-update threshold (per mille): more updates on the sparse records
+    (8, ["1", "16"]),        # queue chunks
+    (9, ["50"]),             # dense-solve threshold
+    (10, ["0"]),             # MFMA kernel beside the LDS kernel on a side stream
+    (13, ["0"]),             # records stream
+    (14, ["0"]),             # background updates
+    (15, ["0", "3"]),        # dense-front kernel: off / three stages
+    (16, ["0", "1", "2", "3", "5"]),  # general update kernel: round 2's, the LDS-DMA ones, tilesv, the pieces kernel
+]
+
+
+def sweep_draws():
+    import random
+
+    seed = int(os.environ.get("PG_SWEEP_SEED", "20261003"))
+    ndraw = int(os.environ.get("PG_SWEEP_DRAWS", "40"))
+    rng = random.Random(seed)
+    draws = []
+    for k in range(ndraw):
+        env, opts = {"_matrix": rng.choice(["shell", "fem27"])}, []
+        for key, values in SWEEP_SPACE:
+            if rng.random() < 0.25:
+                val = rng.choice(values)
+                if isinstance(key, int):
+                    opts.append("%d=%s" % (key, val))
+                else:
+                    env[key] = val
+        if opts:
+            env["PG_TEST_HIP_OPTIONS"] = ",".join(opts)
+        draws.append(pytest.param(env, id="seed%d-draw%02d" % (seed, k)))
+    return draws
+
+
+@pytest.mark.parametrize("env", sweep_draws())
+def test_random_switch_sweep_keeps_parity(env, tmp_path_factory):
+    e = dict(os.environ)
+    env = dict(env)
+    which = env.pop("_matrix")
+    e.update(env)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    # (the oracle's factors once per matrix and session, not once per draw)
+    e["PG_TEST_REF_CACHE"] = os.path.join(str(tmp_path_factory.getbasetemp()), "sweep_ref_%s.npz" % which)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "env_switch_worker.py"), which], env=e, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, "%r\n%s" % (env, out.stderr[-2000:])
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["dL"] <= 1e-12 and r["dU"] <= 1e-12, (env, r)
+    assert r["residual"] <= 1e-12 and r["lu_check"] <= 1e-12 and r["factor_check_device"] <= 1e-12, (env, r)
+    assert r["getrf_launches"] > 0, (env, r)

@@ -238,7 +238,7 @@ def test_operators_reproduce_the_committed_vectors():
     spec.loader.exec_module(mk)
     gold = json.load(open(os.path.join(here, "operator_vectors.json")))
     hip, fh, _ = _platforms("r64")
-    recs = S.exported_records(mk.case_matrix(), mk.CASE["nb"], "r64")
+    recs = mk.case_records()  # (under the permutation the fixture carries)
     g = S.BlockMatrix(recs, mk.CASE["nb"], np.float64, hip)
     try:
         tasks = g.tasks()

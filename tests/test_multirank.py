@@ -311,7 +311,10 @@ def test_multirank_replay_on_the_gpu(tmp_path, world, spec, nb, vtype, separator
     from pangulu_amd import _lib
 
     out = str(tmp_path / "out.npz")
-    env = {"PANGULU_AMD_MULTI_REPLAY": "1", "PANGULU_TEST_REPEATS": "2"}
+    # PANGULU_AMD_POISON_RECV: every reset overwrites the values of the records other ranks sent in the logged run with NaNs -- a
+    # replayed launch that read its receive slot before the block had arrived AGAIN would otherwise find the previous
+    # factorisation's bit-identical record there and pass
+    env = {"PANGULU_AMD_MULTI_REPLAY": "1", "PANGULU_TEST_REPEATS": "2", "PANGULU_AMD_POISON_RECV": "1"}
     if distribute is not None:
         env["PANGULU_AMD_DISTRIBUTE_US"] = distribute
     run_ranks(world, spec, nb, out, vtype=vtype, platform="hip", transport="ipc", repeat=True, separators=separators, extra_env=env)

@@ -39,9 +39,16 @@ __device__ unsigned long long g_probe[8];
 #define TL_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); pr_sum[i] += n_ - pr_t; pr_t = n_; }
 #define TL_PROBE_FLUSH if (lane == 0 && (wave == 0 || wave == 5)) { for (int i_ = 0; i_ < 7; i_++) atomicAdd(&g_probe[i_], pr_sum[i_]); }
 #define TL_PROBE_STEP pr_sum[5]++;
+// ... and the life of a work item outside the step loop (wavefront 0 of every workgroup): TL_ITEM(i) adds the cycles since the previous
+// stamp to phase i; phase 15 counts the items
+__device__ unsigned long long g_item[16];
+#define TL_ITEM_DECL unsigned long long it_t = __builtin_readcyclecounter();
+#define TL_ITEM(i) { const unsigned long long n_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_item[i], n_ - it_t); it_t = n_; }
+#define TL_ITEM_COUNT if (threadIdx.x == 0) atomicAdd(&g_item[15], 1ull);
 #endif
 #include "../../pangulu_amd/csrc/platform/pg_hip_dense.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_front.h"
+#include "../../pangulu_amd/csrc/platform/pg_hip_pieces.h"
 #include "../experiments/front_k32.h"
 #include "../experiments/front_n64.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -158,6 +165,13 @@ void launch(int which, Problem &X)
         CK(hipGetLastError());
         return;
     }
+    if (which >= 50000)
+    {
+        // round 5: compacted, piece-indexed staging (pg_hip_pieces.h)
+        hipLaunchKernelGGL(ssssm_tilesp_f64_kernel, dim3(grid), dim3(FR_THREADS), 0, 0, X.dT, X.nb, X.dW, none, 4u * (unsigned)((which / 100) % 100));
+        CK(hipGetLastError());
+        return;
+    }
     if (which >= 40000)
     {
         // EXPERIMENT (tools/experiments/front_n64.h): 128 x 64 tiles, four wavefronts per workgroup, three workgroups per CU
@@ -214,6 +228,11 @@ const char *name_of(int which)
 {
     if (which == 0)
         return "round-2 kernel (pg_hip_dense.h)";
+    if (which >= 50000)
+    {
+        snprintf(name_buf, sizeof(name_buf), "pieces kernel (ring of 32 piece slots, batches), XCD unit %d dest.", (which / 100) % 100);
+        return name_buf;
+    }
     if (which >= 40000)
     {
         snprintf(name_buf, sizeof(name_buf), "front kernel 128 x 64 tiles, 4 wavefronts, 3 workgroups / CU, unit %d dest.", (which / 100) % 100);
@@ -270,7 +289,7 @@ int main(int argc, char **argv)
         build(X, 3, 2, true, cf);
         const int nb = X.nb;
         std::vector<double> ref((size_t)nb * nb), got((size_t)X.mb);
-        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102, 30100, 40100} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802};
+        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102, 30100, 40100, 50102} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802, 50102, 50802};
         for (int which : kinds)
         {
             for (int i = 0; i < X.P; i++)
@@ -299,15 +318,16 @@ int main(int argc, char **argv)
     const double flop = 8192.0 * X.products;
     printf("front %d x %d destinations of 256 x 256, %d update(s) queued on each, %d%% fill pattern: %zu workgroups, %.3f TFLOP of live 16x16x16 products per launch (%.1f%% of dense)\n", P, P, Q,
            fill, X.nwork, flop / 1e12, 100.0 * flop / (2.0 * 256 * 256 * 256 * (double)P * P * Q));
-    std::vector<int> kinds = fill >= 100 ? std::vector<int>{0, 112, 40100, 30100, 20102, 112, 40100, 40800} : std::vector<int>{0, 10102, 20102, 20802, 0, 10102, 20102, 20802};
+    std::vector<int> kinds = fill >= 100 ? std::vector<int>{112, 20102, 50102, 112, 20102, 50102} : std::vector<int>{20102, 50102, 20802, 50802, 20102, 50102, 20802, 50802};
 #ifdef TL_PROBE
-    kinds = {10102, 20102, 10102, 20102};
+    kinds = {20102, 50102, 20102, 50102};
 #endif
     for (int which : kinds)
     {
 #ifdef TL_PROBE
-        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zero, sizeof(zero)));
+        unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zero, 8 * sizeof(unsigned long long)));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_item), zero, sizeof(zero)));
 #endif
         float best = 1e30f, sum = 0;
         for (int rep = 0; rep < 5; rep++)
@@ -326,7 +346,19 @@ int main(int argc, char **argv)
         unsigned long long pr[8];
         CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr)));
         const double st = (double)pr[5];
-        if (which >= 20000)
+        {
+            unsigned long long it[16];
+            CK(hipMemcpyFromSymbol(it, HIP_SYMBOL(g_item), sizeof(it)));
+            const double ni = (double)it[15];
+            if (ni > 0)
+                printf("item   cycles per work item (%.0f items): work item + descriptors + candidates %.0f, scan / tables / barriers %.0f, batches + preload issue %.0f, first issue %.0f, "
+                       "step loop %.0f, epilogue %.0f: %.0f in all; %.1f live steps per item\n",
+                       ni, it[0] / ni, it[1] / ni, it[2] / ni, it[3] / ni, it[4] / ni, it[5] / ni, (it[0] + it[1] + it[2] + it[3] + it[4] + it[5]) / ni, st / 2.0 / ni);
+        }
+        if (which >= 50000)
+            printf("probe  cycles per slab step and wavefront (%.0f steps sampled): wait for the batch %.0f, barrier %.0f, record + fragments + first quarter %.0f, issue of following batches %.0f, other three quarters %.0f, between batches %.0f: %.0f in all\n",
+                   st, pr[0] / st, pr[1] / st, pr[2] / st, pr[3] / st, pr[4] / st, pr[6] / st, (pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[6]) / st);
+        else if (which >= 20000)
             printf("probe  cycles per slab step and wavefront (%.0f steps sampled): record reads + wait for the slab %.0f, barrier %.0f, fragments + first quarter %.0f, issue of the next slab %.0f, other three quarters %.0f, between steps %.0f: %.0f in all\n",
                    st, pr[0] / st, pr[1] / st, pr[2] / st, pr[3] / st, pr[4] / st, pr[6] / st, (pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[6]) / st);
         else
