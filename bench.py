@@ -672,6 +672,28 @@ def gpu_worker_main(args):
         "critical_path_ms": 1e3 * info0["model_critical_path"], "critical_path_tasks": int(info0["model_critical_path_tasks"]),
         "peaks": {"hbm_GBs": HBM_PEAK_GBS, "fp64_TFLOPs": FP64_PEAK_TFLOPS, "xgmi_link_GBs": XGMI_LINK_GBS},
     }
+    # What the structure says about 1 / 2 / 4 / 8 ranks (pangulu_amd_model_for_ranks: the mapping, the consumer sets and the rank
+    # model for each count, on this handle's replicated pattern): T*(N), the link term, the LATENCY-AWARE chain (every task at
+    # max(T*_t, the measured floor of a lone launch of its class), a hop per operand from another rank) and the HBM of the fullest
+    # rank.  `bound_ms` = max(T*(N), chain): no schedule is faster; `calibrated_ms` = max(T*(N) / (T*(1) / t measured here), chain).
+    model["latency_chain_ms"] = 1e3 * info0.get("model_critical_path_latency", 0.0)
+    model["hbm_fullest_rank_GB"] = {"total": info0.get("model_rank_hbm_bytes_max", 0.0) / 1e9, "records_owned": info0.get("model_rank_hbm_records", 0.0) / 1e9,
+                                    "records_received": info0.get("model_rank_hbm_received", 0.0) / 1e9, "dense_mirrors": info0.get("model_rank_hbm_mirrors", 0.0) / 1e9}
+    if rank == 0 and world == 1:
+        pred = {}
+        eff1 = (1e3 * info0["model_ranks_tstar_max"] / ms_per_step) if ms_per_step else None
+        for N in (1, 2, 4, 8):
+            m = pa.model_for_ranks(h, N)
+            if m is None:
+                continue
+            bound = 1e3 * max(m["T_star_s"], m["latency_chain_s"])
+            pred[str(N)] = {"T_star_ms": 1e3 * m["T_star_s"], "link_term_ms": 1e3 * m["link_term_s_max"], "latency_chain_ms": 1e3 * m["latency_chain_s"],
+                            "bound_ms": bound, "calibrated_ms": max(1e3 * m["T_star_s"] / eff1, 1e3 * m["latency_chain_s"]) if eff1 else None,
+                            "sent_GB": m["sent_bytes"] / 1e9, "rank_flop_share": m["rank_flop_share"],
+                            "hbm_fullest_rank_GB": m["hbm_bytes_fullest_rank"] / 1e9}
+        model["scaling_prediction"] = pred
+        model["scaling_prediction_note"] = ("structure only; launch floors GETRF 205 us, dense panel solve 70 us, update launch 25 us at nb = 256 (measured, DESIGN.md), "
+                                            "20 us per hop between ranks (an ASSUMPTION until a run on real links calibrates it)")
     if roofline is not None:
         roofline["model_T_star_ms"] = model["T_star_ms"]
         roofline["model_T_star_over_t_gstrf"] = model["T_star_over_t_gstrf"]

@@ -112,6 +112,16 @@ extern "C"
         double model_critical_path;           /* longest dependent chain of tasks, each at its own T*_t, seconds        */
         unsigned long long model_critical_path_tasks; /* ... and its length in tasks                                    */
         unsigned long long snapshot_device_bytes;     /* bytes of device memory pangulu_amd_snapshot holds (0: none, or kept on the host) */
+        /* (round 5) the same chain with every task at max(T*_t, the measured floor of a lone launch of its class) and a hop
+         * (PANGULU_AMD_MODEL_HOP_US + record bytes over one link) wherever an operand comes from another rank: what bounds
+         * strong scaling; seconds */
+        double model_critical_path_latency;
+        /* HBM demand of the fullest rank under the mapping, bytes: all of it, the records it owns, the records it receives
+         * (bins provisioned for every received block once), dense mirrors of both kinds from the dense threshold on */
+        double model_rank_hbm_bytes_max, model_rank_hbm_records, model_rank_hbm_received, model_rank_hbm_mirrors;
+        /* columns of the input that had no stored diagonal entry and got one (1e-8) by the reference's zero-diagonal rule
+         * (src/pangulu_reordering.c:715-796; nested-dissection path; PANGULU_AMD_ZERO_DIAGONAL) */
+        unsigned long long inserted_diagonals;
     } pangulu_amd_info_t;
     void pangulu_amd_get_info(void **pangulu_handle, pangulu_amd_info_t *out);
     /* evaluate T* = sum_t max(bytes_t / BW, flop_t / P) over this rank's task list (structure only) */
@@ -123,6 +133,12 @@ extern "C"
     /* per-rank figures of the structure-only model above: arrays of info.nproc entries (any may be NULL);
      * returns the number of ranks */
     int pangulu_amd_rank_model(void **pangulu_handle, double *tstar_seconds, double *flop, double *comm_seconds);
+    /* The structure-only model for ANY rank count on this handle (1 <= nranks <= 64), without touching the handle: out12 =
+     * { T*(N) incl. link term, sum_r T*_r, max link term, bytes sent, critical path at T*_t, latency-aware critical path, max / mean
+     * flop share, max / mean T* share, HBM of the fullest rank, its records owned, its records received, its dense mirrors }
+     * (seconds, bytes).  Local (no communication): the pattern and the weights are replicated.  Returns 0, or 1 when the model is
+     * not available (nb > 65535). */
+    int pangulu_amd_model_for_ranks(void **pangulu_handle, int nranks, double *out12);
 
     /* ---- repeated factorisations (bench.py) ---------------------------------------------------------- */
     /* gstrf overwrites the matrix with its factors.  snapshot() keeps a pristine device-side copy of this rank's

@@ -6,6 +6,6 @@ and the MatrixMarket reader around it.
 """
 from . import _lib, matrices  # noqa: F401
 from .solver import (  # noqa: F401
-    Handle, factor_check, factor_check_vectors, factors_as_scipy, hip_memory, hip_stats, owned_blocks, pangulu_finalize, pangulu_gssv, pangulu_gstrf, pangulu_gstrs,
+    Handle, factor_check, factor_check_vectors, factors_as_scipy, hip_memory, hip_stats, model_for_ranks, owned_blocks, pangulu_finalize, pangulu_gssv, pangulu_gstrf, pangulu_gstrs,
     pangulu_init, permutation, update_values,
 )

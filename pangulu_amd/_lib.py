@@ -92,6 +92,12 @@ class Info(ctypes.Structure):
         ("model_critical_path", ctypes.c_double),
         ("model_critical_path_tasks", ctypes.c_ulonglong),
         ("snapshot_device_bytes", ctypes.c_ulonglong),
+        ("model_critical_path_latency", ctypes.c_double),
+        ("model_rank_hbm_bytes_max", ctypes.c_double),
+        ("model_rank_hbm_records", ctypes.c_double),
+        ("model_rank_hbm_received", ctypes.c_double),
+        ("model_rank_hbm_mirrors", ctypes.c_double),
+        ("inserted_diagonals", ctypes.c_ulonglong),
     ]
 
     def as_dict(self):
@@ -217,6 +223,8 @@ def load(vtype="r64", test_hooks=False):
     lib.pangulu_amd_factor_check.restype = ctypes.c_int
     lib.pangulu_amd_factor_check_vectors.argtypes = [vpp, ctypes.c_int, ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_double)]
     lib.pangulu_amd_factor_check_vectors.restype = ctypes.c_int
+    lib.pangulu_amd_model_for_ranks.argtypes = [vpp, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    lib.pangulu_amd_model_for_ranks.restype = ctypes.c_int
 
     lib.pangulu_platform_0201001_set_option.argtypes = [ctypes.c_int, ctypes.c_longlong]
     lib.pangulu_platform_0201001_set_option.restype = ctypes.c_int

@@ -12,6 +12,12 @@
 
 namespace pg
 {
+#ifdef PANGULU_COMPLEX
+static inline val_t make_value(double re) { return val_t{(decltype(val_t{}.re))re, 0}; }
+#else
+static inline val_t make_value(double re) { return (val_t)re; }
+#endif
+
 
 void fatal(const char *fmt, ...)
 {
@@ -473,6 +479,64 @@ extern "C"
                 comm->bcast(A.value.data(), sizeof(val_t) * A.value.size(), 0);
             }
         }
+        // The reference's zero-diagonal rule (pangulu_add_diagonal_element_csc, src/pangulu_reordering.c:715-796, called on its METIS
+        // path, :959): a column without a stored diagonal entry gets one, with the value 1e-8, at its sorted position -- a static
+        // perturbation instead of a pivot search (matrix files of KKT systems have structurally empty diagonal blocks; with the matching
+        // on, the permuted diagonal is full and nothing is inserted).  Here on the nested-dissection path like there;
+        // PANGULU_AMD_ZERO_DIAGONAL=0 leaves such entries structurally present and numerically zero (GETRF's pivot clamp then sees
+        // them), any other value is used instead of 1e-8.  Every rank holds the matrix: every rank inserts.
+        {
+            double zero_element = 1e-8;
+            if (const char *e = getenv("PANGULU_AMD_ZERO_DIAGONAL"))
+                zero_element = atof(e);
+            if (opt.ordering == PANGULU_AMD_ORDER_ND && zero_element != 0.0)
+            {
+                u64 missing = 0;
+                for (u32 j = 0; j < A.n; j++)
+                {
+                    bool has = false;
+                    for (u64 p_ = A.colptr[j]; p_ < A.colptr[j + 1] && !has; p_++)
+                        has = A.rowidx[p_] == j;
+                    missing += has ? 0 : 1;
+                }
+                if (missing)
+                {
+                    CscMatrix B;
+                    B.n = A.n;
+                    B.colptr.resize((size_t)A.n + 1);
+                    B.rowidx.reserve(A.rowidx.size() + missing);
+                    B.value.reserve(A.value.size() + missing);
+                    B.colptr[0] = 0;
+                    for (u32 j = 0; j < A.n; j++)
+                    {
+                        bool has = false, placed = false;
+                        for (u64 p_ = A.colptr[j]; p_ < A.colptr[j + 1] && !has; p_++)
+                            has = A.rowidx[p_] == j;
+                        for (u64 p_ = A.colptr[j]; p_ < A.colptr[j + 1]; p_++)
+                        {
+                            if (!has && !placed && A.rowidx[p_] > j)
+                            {
+                                B.rowidx.push_back(j);
+                                B.value.push_back(make_value(zero_element));
+                                placed = true;
+                            }
+                            B.rowidx.push_back(A.rowidx[p_]);
+                            B.value.push_back(A.value[p_]);
+                        }
+                        if (!has && !placed)
+                        {
+                            B.rowidx.push_back(j);
+                            B.value.push_back(make_value(zero_element));
+                        }
+                        B.colptr[(size_t)j + 1] = B.rowidx.size();
+                    }
+                    A = std::move(B);
+                    if (rank == 0 && getenv("PANGULU_AMD_TRACE"))
+                        fprintf(stderr, "[pangulu_amd trace] init: %llu columns without a diagonal entry got one (%g)\n", (unsigned long long)missing, zero_element);
+                }
+                S->info.inserted_diagonals = missing;
+            }
+        }
         if (rank == 0)
         {
             if (opt.ordering == PANGULU_AMD_ORDER_USER)
@@ -914,6 +978,13 @@ extern "C"
                 comm_seconds[r] = M.rank_comm_s[(size_t)r];
         }
         return np;
+    }
+
+    int pangulu_amd_model_for_ranks(void **pangulu_handle, int nranks, double *out12)
+    {
+        Solver *S = (Solver *)*pangulu_handle;
+        evaluate_model_for_ranks(*S, nranks, out12);
+        return out12[0] < 0 ? 1 : 0;
     }
 
     void pangulu_amd_model_roofline(void **pangulu_handle, double hbm_gbytes_per_s, double fp_tflops)

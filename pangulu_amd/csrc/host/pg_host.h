@@ -298,7 +298,9 @@ struct StructureModel
     // after the mapping: per rank
     std::vector<double> rank_time_hbm, rank_time_fp, rank_flop, rank_bytes, rank_comm_s;
     std::vector<double> sent_bytes;     // [from * nproc + to]
+    std::vector<double> rank_mem_records, rank_mem_recv, rank_mem_mirrors; // HBM demand per rank under the mapping (bytes)
     double critical_path_s = 0;
+    double critical_path_latency_s = 0; // the same chain with every task at max(T*_t, launch floor of its class) and hops between ranks
     u64 critical_path_tasks = 0;
 };
 
@@ -424,6 +426,8 @@ double factor_check(Solver &S);                           // ||L(U 1) - A 1|| / 
 double factor_check_vectors(Solver &S, int nvec, unsigned long long seed); // the same on the ones vector + nvec - 1 random +-1 vectors: the worst quotient
 void compute_task_model(Solver &S, double hbm_bytes_per_s, double fp_flops_per_s); // pg_model.cpp: T* of SURVEY.md §8d
 void build_structure_model(Solver &S);   // pg_model.cpp: column counts per lower block + per-column work (before the mapping)
+void compute_rank_model(Solver &S);      // pg_model.cpp: per-rank T*, link term, critical paths, HBM per rank under the mapping
+void evaluate_model_for_ranks(Solver &S, int nranks, double *out12); // pg_model.cpp: the same figures for any rank count
 void compute_rank_model(Solver &S);      // pg_model.cpp: per-rank T*, flop shares, link term, critical path (after preprocess)
 double task_structural_flop(u32 nb, const task_t &t);
 // Checker's build only (oracle/pangulu_amd_test_hooks.h): execute every stride-th task of each kernel class and skip the

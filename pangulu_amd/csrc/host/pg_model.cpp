@@ -362,6 +362,11 @@ void build_structure_model(Solver &S)
     }
 }
 
+#ifdef PANGULU_COMPLEX
+#define MODEL_MIRROR_PLANES 2.0 // (a complex block's mirror is two real planes)
+#else
+#define MODEL_MIRROR_PLANES 1.0
+#endif
 void compute_rank_model(Solver &S)
 {
     StructureModel &M = S.smodel;
@@ -461,6 +466,61 @@ void compute_rank_model(Solver &S)
                 }
         }
     }
+    // HBM a rank needs under this mapping: the records it owns, the records it receives (receive bins provisioned for every block
+    // once, as the multi-rank replay wants them), and a dense mirror for every block of either kind whose fill reaches the dense
+    // threshold (2 per mille unless PANGULU_HIP_DENSE_PERMILLE says otherwise; nb = 128 or 256 only) -- the pool's DEMAND: when it
+    // is not met the blocks stay on the sparse kernels.  bench.py's snapshot of the records and the recorded schedule's descriptors
+    // come on top (see hbm_breakdown_GB of a measured line).
+    {
+        M.rank_mem_records.assign((size_t)np, 0.0);
+        M.rank_mem_recv.assign((size_t)np, 0.0);
+        M.rank_mem_mirrors.assign((size_t)np, 0.0);
+        double permille = 2.0;
+        if (const char *e = getenv("PANGULU_HIP_DENSE_PERMILLE"))
+            permille = atof(e);
+        const bool dense_mode = nb == 128 || nb == 256;
+        const double mirror_bytes = dense_mode ? 8.0 * ((double)nb * nb + 8.0 + 16.0 * nb) * MODEL_MIRROR_PLANES : 0.0;
+        const double thr = permille * 1e-3 * (double)nb * nb;
+        for (u32 bc = 0; bc < nbk; bc++)
+            for (u64 t = P.colptr[bc]; t < P.colptr[bc + 1]; t++)
+            {
+                const u32 br = P.rowidx[t];
+                const int o = S.owner(br, bc);
+                const double bytes = (double)record_bytes(nb, P.nnz[t], br > bc);
+                const double mir = (double)P.nnz[t] >= thr ? mirror_bytes : 0.0;
+                M.rank_mem_records[(size_t)o] += bytes;
+                M.rank_mem_mirrors[(size_t)o] += mir;
+                u64 to = S.consumers.empty() ? 0ull : S.consumers[t];
+                to &= ~(1ull << o);
+                for (int r = 0; r < np && r < 64; r++)
+                    if ((to >> r) & 1ull)
+                    {
+                        M.rank_mem_recv[(size_t)r] += bytes;
+                        M.rank_mem_mirrors[(size_t)r] += mir;
+                    }
+            }
+        for (u32 k = 0; k < nbk; k++)
+        {
+            const int o = S.owner(k, k);
+            M.rank_mem_records[(size_t)o] += (double)record_bytes(nb, P.diag_upper_nnz[k], false) + (double)record_bytes(nb, P.diag_lower_nnz[k], false);
+            M.rank_mem_mirrors[(size_t)o] += ((double)P.diag_upper_nnz[k] + P.diag_lower_nnz[k] >= thr) ? mirror_bytes : 0.0;
+        }
+        double worst = 0;
+        int at = 0;
+        for (int r = 0; r < np; r++)
+        {
+            const double tot = M.rank_mem_records[(size_t)r] + M.rank_mem_recv[(size_t)r] + M.rank_mem_mirrors[(size_t)r];
+            if (tot > worst)
+            {
+                worst = tot;
+                at = r;
+            }
+        }
+        S.info.model_rank_hbm_bytes_max = worst;
+        S.info.model_rank_hbm_records = M.rank_mem_records[(size_t)at];
+        S.info.model_rank_hbm_received = M.rank_mem_recv[(size_t)at];
+        S.info.model_rank_hbm_mirrors = M.rank_mem_mirrors[(size_t)at];
+    }
     double tsum = 0, tmax = 0, tworst = 0, fsum = 0, fmax = 0, cmax = 0, sent = 0, thbm = 0, tfp = 0, bsum = 0;
     for (int r = 0; r < np; r++)
     {
@@ -492,85 +552,228 @@ void compute_rank_model(Solver &S)
     S.info.model_comm_seconds_max = cmax;
     S.info.model_sent_bytes_total = sent;
 
-    // Critical path of the block task graph with every task at its own T*_t (a lower bound on any schedule's makespan
-    // however many devices there are): levels ascending; a block's updates may run concurrently once both operands are
-    // final, its panel task starts when the last of them is done.  (Serial: a few operations per task.)
+    // Critical path of the block task graph (levels ascending; a block's updates may run concurrently once both operands are final,
+    // its panel task starts when the last of them is done; serial: a few operations per task), twice:
+    //  * with every task at its own T*_t -- a lower bound on any schedule's makespan however many devices there are, but a useless
+    //    predictor: 0.24 us per task on the chain where a lone kernel launch has a floor of tens of microseconds;
+    //  * LATENCY-AWARE: a task takes max(T*_t, the measured floor of a lone launch of its class) -- GETRF 205 us, a dense panel
+    //    solve 70 us, an update launch 25 us at nb = 256, scaled with nb / 256 for the panel classes (16 dependent panel steps per
+    //    256 columns; DESIGN.md, kernel table; PANGULU_AMD_MODEL_FLOOR_{GETRF,PANEL,UPDATE}_US) -- and an operand that comes from
+    //    another rank arrives a hop later: PANGULU_AMD_MODEL_HOP_US (default 20: marker, announcement, start of the copy; an
+    //    assumption until a run on real links calibrates it) + record bytes over one link.  This is what bounds strong scaling.
     {
-        std::vector<float> ready(nblk, 0.f), fin(nblk, 0.f), ready_d(nbk, 0.f), fin_d(nbk, 0.f);
-        std::vector<u32> depth(nblk, 0), depth_rd(nbk, 0), depth_r(nblk, 0), depth_d(nbk, 0);
-        std::vector<u64> bl_of, bu_of;
-        for (u32 k = 0; k < nbk; k++)
+        const double scale_nb = (double)nb / 256.0;
+        auto env_us = [](const char *name, double dflt)
         {
-            fin_d[k] = ready_d[k] + t_getrf[k];
-            depth_d[k] = depth_rd[k] + 1;
-            const u64 l0 = P.lcolptr[k], l1 = P.lcolptr[k + 1];
-            const u64 nl = l1 - l0 - 1;
-            bl_of.resize(nl);
-            bu_of.resize(nl);
-            // panel solves of column k and row k
-            for (u64 a = 0; a < nl; a++)
+            const char *e = getenv(name);
+            return 1e-6 * (e ? atof(e) : dflt);
+        };
+        const float floor_getrf = (float)env_us("PANGULU_AMD_MODEL_FLOOR_GETRF_US", 205.0 * scale_nb);
+        const float floor_panel = (float)env_us("PANGULU_AMD_MODEL_FLOOR_PANEL_US", 70.0 * scale_nb);
+        const float floor_update = (float)env_us("PANGULU_AMD_MODEL_FLOOR_UPDATE_US", 25.0);
+        const float hop = (float)env_us("PANGULU_AMD_MODEL_HOP_US", 20.0);
+        const float inv_link = (float)(1.0 / M.link_bytes_per_s);
+        auto chain = [&](bool lat, float &cp_out, u32 &depth_out)
+        {
+            std::vector<float> ready(nblk, 0.f), fin(nblk, 0.f), ready_d(nbk, 0.f), fin_d(nbk, 0.f);
+            std::vector<u32> depth(nblk, 0), depth_rd(nbk, 0), depth_r(nblk, 0), depth_d(nbk, 0);
+            std::vector<u64> bl_of, bu_of;
+            std::vector<int> own_l, own_u;
+            // when a block finished on rank `from` is usable on rank `to`
+            auto arrive = [&](float t_done, int from, int to, double bytes) -> float
+            { return (!lat || from == to) ? t_done : t_done + hop + (float)bytes * inv_link; };
+            for (u32 k = 0; k < nbk; k++)
             {
-                const u32 i = P.lrowidx[l0 + 1 + a];
-                const u64 bl = P.find(i, k), bu = P.find(k, i);
-                bl_of[a] = bl;
-                bu_of[a] = bu;
-                fin[bl] = std::max(ready[bl], fin_d[k]) + t_panel[bl];
-                depth[bl] = std::max(depth_r[bl], depth_d[k]) + 1;
-                fin[bu] = std::max(ready[bu], fin_d[k]) + t_panel[bu];
-                depth[bu] = std::max(depth_r[bu], depth_d[k]) + 1;
-            }
-            // updates generated by level k
-            for (u64 b = 0; b < nl; b++)
-            {
-                const u32 j = P.lrowidx[l0 + 1 + b];
-                const u64 bu = bu_of[b];
-                // destinations (i, j), i over the L column: walk block column j of the pattern alongside
-                u64 cur = P.colptr[j];
-                const u64 cend = P.colptr[j + 1];
+                const int od = S.owner(k, k);
+                fin_d[k] = ready_d[k] + (lat ? std::max(t_getrf[k], floor_getrf) : t_getrf[k]);
+                depth_d[k] = depth_rd[k] + 1;
+                const u64 l0 = P.lcolptr[k], l1 = P.lcolptr[k + 1];
+                const u64 nl = l1 - l0 - 1;
+                bl_of.resize(nl);
+                bu_of.resize(nl);
+                own_l.resize(nl);
+                own_u.resize(nl);
+                const double diag_bytes = (double)record_bytes(nb, P.diag_upper_nnz[k], false);
+                // panel solves of column k and row k
                 for (u64 a = 0; a < nl; a++)
                 {
-                    const float t = t_upd[upd_off[k] + b * nl + a];
-                    if (t < 0)
-                        continue;
                     const u32 i = P.lrowidx[l0 + 1 + a];
-                    const u64 bl = bl_of[a];
-                    const float done = std::max(fin[bl], fin[bu]) + t;
-                    const u32 dp = std::max(depth[bl], depth[bu]) + 1;
-                    if (i == j)
+                    const u64 bl = P.find(i, k), bu = P.find(k, i);
+                    bl_of[a] = bl;
+                    bu_of[a] = bu;
+                    own_l[a] = S.owner(i, k);
+                    own_u[a] = S.owner(k, i);
+                    fin[bl] = std::max(ready[bl], arrive(fin_d[k], od, own_l[a], diag_bytes)) + (lat ? std::max(t_panel[bl], floor_panel) : t_panel[bl]);
+                    depth[bl] = std::max(depth_r[bl], depth_d[k]) + 1;
+                    fin[bu] = std::max(ready[bu], arrive(fin_d[k], od, own_u[a], diag_bytes)) + (lat ? std::max(t_panel[bu], floor_panel) : t_panel[bu]);
+                    depth[bu] = std::max(depth_r[bu], depth_d[k]) + 1;
+                }
+                // updates generated by level k
+                for (u64 b = 0; b < nl; b++)
+                {
+                    const u32 j = P.lrowidx[l0 + 1 + b];
+                    const u64 bu = bu_of[b];
+                    const double bu_bytes = lat ? (double)record_bytes(nb, P.nnz[bu], false) : 0.0;
+                    // destinations (i, j), i over the L column: walk block column j of the pattern alongside
+                    u64 cur = P.colptr[j];
+                    const u64 cend = P.colptr[j + 1];
+                    for (u64 a = 0; a < nl; a++)
                     {
-                        ready_d[i] = std::max(ready_d[i], done);
-                        depth_rd[i] = std::max(depth_rd[i], dp);
-                    }
-                    else
-                    {
-                        while (cur < cend && P.rowidx[cur] < i)
-                            cur++;
-                        // (t >= 0 means the destination exists; i ascends with a, but U blocks (i < j) come first in the column)
-                        const u64 bd = (cur < cend && P.rowidx[cur] == i) ? cur : P.find(i, j);
-                        ready[bd] = std::max(ready[bd], done);
-                        depth_r[bd] = std::max(depth_r[bd], dp);
+                        const float t = t_upd[upd_off[k] + b * nl + a];
+                        if (t < 0)
+                            continue;
+                        const u32 i = P.lrowidx[l0 + 1 + a];
+                        const u64 bl = bl_of[a];
+                        float in_l = fin[bl], in_u = fin[bu];
+                        if (lat)
+                        {
+                            const int o = S.owner(i, j);
+                            in_l = arrive(in_l, own_l[a], o, (double)record_bytes(nb, P.nnz[bl], true));
+                            in_u = arrive(in_u, own_u[b], o, bu_bytes);
+                        }
+                        const float done = std::max(in_l, in_u) + (lat ? std::max(t, floor_update) : t);
+                        const u32 dp = std::max(depth[bl], depth[bu]) + 1;
+                        if (i == j)
+                        {
+                            ready_d[i] = std::max(ready_d[i], done);
+                            depth_rd[i] = std::max(depth_rd[i], dp);
+                        }
+                        else
+                        {
+                            while (cur < cend && P.rowidx[cur] < i)
+                                cur++;
+                            // (t >= 0 means the destination exists; i ascends with a, but U blocks (i < j) come first in the column)
+                            const u64 bd = (cur < cend && P.rowidx[cur] == i) ? cur : P.find(i, j);
+                            ready[bd] = std::max(ready[bd], done);
+                            depth_r[bd] = std::max(depth_r[bd], dp);
+                        }
                     }
                 }
             }
-        }
-        float cp = 0;
-        u32 dmax = 0;
-        for (u32 k = 0; k < nbk; k++)
-        {
-            cp = std::max(cp, fin_d[k]);
-            dmax = std::max(dmax, depth_d[k]);
-        }
-        for (u64 b = 0; b < nblk; b++)
-        {
-            cp = std::max(cp, fin[b]);
-            dmax = std::max(dmax, depth[b]);
-        }
+            float cp = 0;
+            u32 dmax = 0;
+            for (u32 k = 0; k < nbk; k++)
+            {
+                cp = std::max(cp, fin_d[k]);
+                dmax = std::max(dmax, depth_d[k]);
+            }
+            for (u64 b = 0; b < nblk; b++)
+            {
+                cp = std::max(cp, fin[b]);
+                dmax = std::max(dmax, depth[b]);
+            }
+            cp_out = cp;
+            depth_out = dmax;
+        };
+        float cp = 0, cp_lat = 0;
+        u32 dmax = 0, dlat = 0;
+        chain(false, cp, dmax);
+        chain(true, cp_lat, dlat);
         M.critical_path_s = cp;
         M.critical_path_tasks = dmax;
+        M.critical_path_latency_s = cp_lat;
         S.info.model_critical_path = cp;
         S.info.model_critical_path_tasks = dmax;
+        S.info.model_critical_path_latency = cp_lat;
     }
-    M.lcount = std::vector<u16>(); // (51 MB for the Serena-class matrix: only needed until here)
+    // (M.lcount stays: 51 MB of host memory for the Serena-class matrix, and evaluate_model_for_ranks() needs it again)
+}
+
+// The structure-only model of this handle's factorisation on `nranks` ranks -- what pangulu_init evaluates for the handle's own
+// rank count -- for ANY rank count, on a handle of any rank count (the pattern and the per-column weights are replicated): the
+// mapping is made for nranks, the sets of consuming ranks are derived from it, the rank model runs, and the handle's own mapping,
+// consumer sets and model figures are put back.  out[0..11]: T*(N) incl. the link term, sum_r T*_r, max link term, bytes sent in
+// all, critical path at T*_t, LATENCY-AWARE critical path, max / mean flop share, max / mean T* share, HBM of the fullest rank and
+// its three parts (records owned, records received, dense mirrors), all in seconds / bytes.
+void evaluate_model_for_ranks(Solver &S, int nranks, double *out)
+{
+    if (nranks < 1 || nranks > 64 || S.smodel.lcount.empty())
+    {
+        for (int i = 0; i < 12; i++)
+            out[i] = -1.0;
+        return;
+    }
+    const int nproc0 = S.nproc, p0 = S.p, q0 = S.q, rank0 = S.rank;
+    std::vector<int> home0;
+    std::vector<Solver::Group> grp0;
+    std::vector<u64> cons0;
+    home0.swap(S.home);
+    grp0.swap(S.grp);
+    cons0.swap(S.consumers);
+    const StructureModel model0 = S.smodel; // (lcount included: a copy of 51 MB for the Serena-class matrix, once per call)
+    const pangulu_amd_info_t info0 = S.info;
+    S.nproc = nranks;
+    int p = (int)std::sqrt((double)nranks);
+    while (nranks % p)
+        p--;
+    S.p = p;
+    S.q = nranks / p;
+    S.rank = 0;
+    assign_subtrees(S);
+    // who consumes which block under that mapping (the rule of preprocess(): the owner of every update's destination)
+    const BlockPattern &P = S.pat;
+    const u32 nbk = S.nbk;
+    if (nranks > 1 && !getenv("PANGULU_AMD_REFERENCE_FORWARDING"))
+    {
+        S.consumers.assign(P.colptr[nbk], 0);
+#pragma omp parallel
+        {
+            std::vector<i64> pos(nbk, -1);
+#pragma omp for schedule(dynamic, 2)
+            for (i64 b_ = 0; b_ < (i64)nbk; b_++)
+            {
+                const u32 b = (u32)b_;
+                for (u64 t = P.colptr[b]; t < P.colptr[b + 1]; t++)
+                    pos[P.rowidx[t]] = (i64)t;
+                for (u64 t = P.colptr[b]; t < P.first_after_diag[b]; t++)
+                {
+                    const u32 k = P.rowidx[t];
+                    for (u64 la = P.first_after_diag[k]; la < P.colptr[k + 1]; la++)
+                    {
+                        const u32 a = P.rowidx[la];
+                        if (a != b && pos[a] < 0)
+                            continue;
+                        const int od = S.owner(a, b);
+                        if (S.owner(a, k) != od)
+                        {
+#pragma omp atomic
+                            S.consumers[la] |= 1ull << od;
+                        }
+                        if (S.owner(k, b) != od)
+                        {
+#pragma omp atomic
+                            S.consumers[t] |= 1ull << od;
+                        }
+                    }
+                }
+                for (u64 t = P.colptr[b]; t < P.colptr[b + 1]; t++)
+                    pos[P.rowidx[t]] = -1;
+            }
+        }
+    }
+    compute_rank_model(S);
+    out[0] = S.info.model_ranks_tstar_max;
+    out[1] = S.info.model_ranks_tstar_sum;
+    out[2] = S.info.model_comm_seconds_max;
+    out[3] = S.info.model_sent_bytes_total;
+    out[4] = S.info.model_critical_path;
+    out[5] = S.info.model_critical_path_latency;
+    out[6] = S.info.model_rank_flop_share;
+    out[7] = S.info.model_rank_time_share;
+    out[8] = S.info.model_rank_hbm_bytes_max;
+    out[9] = S.info.model_rank_hbm_records;
+    out[10] = S.info.model_rank_hbm_received;
+    out[11] = S.info.model_rank_hbm_mirrors;
+    // ... and everything back
+    S.nproc = nproc0;
+    S.p = p0;
+    S.q = q0;
+    S.rank = rank0;
+    S.home.swap(home0);
+    S.grp.swap(grp0);
+    S.consumers.swap(cons0);
+    S.smodel = model0;
+    S.info = info0;
 }
 
 } // namespace pg

@@ -108,14 +108,23 @@ def elastic3d(nx, ny=None, nz=None, dofs=3, dtype=np.float64):
     return _finish(A.astype(dtype), dtype, coords)
 
 
-def kkt(nx, dtype=np.float64, delta=1e-2):
-    """nlpkkt-class stand-in: [[H, J^T], [J, -delta I]] with H a 7-point operator on nx^3 and J a one-sided
-    difference.  Regularised so that no pivoting is needed."""
+def kkt(nx, dtype=np.float64, delta=1e-2, dominant=False):
+    """nlpkkt-class stand-in (BASELINE configs[3]): the 2 x 2 block KKT system [[H, J^T], [J, -delta I]] of SURVEY.md §8d with
+    delta = 1e-2 -- H a 7-point operator on nx^3 (symmetric positive definite), J a one-sided difference.  The matrix is symmetric
+    QUASI-DEFINITE: it has an L D L^T (hence L U) factorisation without pivoting under ANY symmetric permutation (Vanderbei 1995), with
+    pivots of both signs down to -delta and element growth of order |J|^2 / delta -- the class the reference treats with MC64 and
+    inserted 1e-8 diagonals (src/pangulu_reordering.c:149-681, 715-796).  `dominant=True` is rounds 1-4's matrix, whose (2,2) block was
+    -(delta + 4) I: diagonally dominant, an easy stand-in that is not the class (VERDICT r4 missing #3); `kkt_dominant(nx)` names it."""
     n1, cp, ri, va, coords = poisson3d(nx, dtype=dtype, shift=2.0)
     H = to_scipy(n1, cp, ri, va)
     J = (sp.identity(n1, format="csc") - _stencil(nx, nx, nx, [(1, 0, 0)])).astype(dtype) * 0.5
-    A = sp.bmat([[H, J.T], [J, -(delta + 4.0) * sp.identity(n1, dtype=dtype)]], format="csc")
+    A = sp.bmat([[H, J.T], [J, -(delta + (4.0 if dominant else 0.0)) * sp.identity(n1, dtype=dtype)]], format="csc")
     return _finish(A, dtype, np.concatenate([coords, coords + 0.25], axis=0))
+
+
+def kkt_dominant(nx, dtype=np.float64, delta=1e-2):
+    """Rounds 1-4's `kkt`: the same blocks with a diagonally dominant (2,2) block -(delta + 4) I."""
+    return kkt(nx, dtype=dtype, delta=delta, dominant=True)
 
 
 def trefethen(size=20, drop_first=True, dtype=np.float64):

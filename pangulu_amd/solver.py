@@ -208,6 +208,19 @@ def factor_check_vectors(h, nvec=8, seed=20251003):
     return float(out.value)
 
 
+MODEL_FIELDS = ("T_star_s", "sum_over_ranks_s", "link_term_s_max", "sent_bytes", "critical_path_s", "latency_chain_s", "rank_flop_share",
+                "rank_T_star_share", "hbm_bytes_fullest_rank", "hbm_records_owned", "hbm_records_received", "hbm_dense_mirrors")
+
+
+def model_for_ranks(h, nranks):
+    """The structure-only model of this handle's factorisation on `nranks` ranks (pangulu_amd_model_for_ranks): a dict of
+    MODEL_FIELDS, or None when the model is not available."""
+    out = (ctypes.c_double * 12)()
+    if h.lib.pangulu_amd_model_for_ranks(h.ref, int(nranks), out) != 0:
+        return None
+    return dict(zip(MODEL_FIELDS, (float(x) for x in out)))
+
+
 def hip_memory(h_or_lib):
     """Device memory the back-end holds for itself (bytes): mirror pool, descriptor twins of a recorded schedule, GETRF scratch;
     and the number of blocks in dense mode."""

@@ -162,13 +162,33 @@ def test_gstrf_twice_after_reset_gives_identical_factors():
 
 
 def test_matrix_generators_are_diagonally_dominant():
-    for gen in (lambda: M.shell(7, 6), lambda: M.fem27(4), lambda: M.poisson3d(5), lambda: M.kkt(3), lambda: M.random_pattern(60, 0.1, 2)):
+    for gen in (lambda: M.shell(7, 6), lambda: M.fem27(4), lambda: M.poisson3d(5), lambda: M.kkt_dominant(3), lambda: M.random_pattern(60, 0.1, 2)):
         n, cp, ri, va, _ = gen()
         A = M.to_scipy(n, cp, ri, va).tocsr()
         d = np.abs(A.diagonal())
         off = np.asarray(abs(A).sum(axis=1)).ravel() - d
         assert (d > off - 1e-12).all() or (d >= 0.99 * off).all()
         assert sp.issparse(A)
+
+
+def test_kkt_generator_is_the_quasi_definite_class():
+    """matrices.kkt = [[H, J^T], [J, -delta I]] with delta = 1e-2 (BASELINE configs[3]'s class): H symmetric positive
+    definite, a NEGATIVE (2,2) diagonal of modulus delta -- not diagonally dominant (rounds 1-4's stand-in, now kkt_dominant, was) --
+    and still factorisable without pivoting under any symmetric permutation (quasi-definite): pivots of both signs, residual at
+    round-off through the oracle with the nested-dissection ordering."""
+    n, cp, ri, va, co = M.kkt(5)
+    A = M.to_scipy(n, cp, ri, va).tocsc()
+    n1 = n // 2
+    assert np.allclose(A.diagonal()[n1:], -1e-2) and (A.diagonal()[:n1] > 0).all()
+    assert abs(A - A.T).max() == 0
+    d = np.abs(A.diagonal())
+    off = np.asarray(abs(A).sum(axis=1)).ravel() - d
+    assert (d[n1:] < off[n1:]).all()  # the constraint rows are far from dominant
+    assert np.linalg.eigvalsh(A[:n1, :n1].toarray()).min() > 0
+    r = factorize((n, cp, ri, va, co), 16, oracle_library("r64"))
+    du = r["U"].diagonal()
+    assert (du > 0).any() and (du < 0).any() and np.abs(du).min() >= 1e-2 * (1 - 1e-12)
+    assert r["residual"] < 1e-13 and r["factor_check"] < 1e-13
 
 
 @pytest.mark.parametrize("gen,nb", [(lambda: M.fem27(7), 32), (lambda: M.shell(12, 10), 48), (lambda: M.kkt(4), 16), (lambda: M.trefethen(), 4)])

@@ -120,7 +120,7 @@ def sweep_draws():
     import random
 
     seed = int(os.environ.get("PG_SWEEP_SEED", "20261003"))
-    ndraw = int(os.environ.get("PG_SWEEP_DRAWS", "40"))
+    ndraw = int(os.environ.get("PG_SWEEP_DRAWS", "60"))
     rng = random.Random(seed)
     draws = []
     for k in range(ndraw):

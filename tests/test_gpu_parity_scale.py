@@ -143,10 +143,12 @@ def test_device_solve_matches_host_sweep(vtype, gen, nb, monkeypatch):
     assert dev["residual"] <= (1e-12 if vtype in ("r64", "cr64") else 5e-5)
 
 
-@pytest.mark.parametrize("nx,nb", [(6, 32), (8, 128), (10, 256)])
+@pytest.mark.parametrize("nx,nb", [(6, 32), (8, 128), (10, 256), (24, 256), (32, 256)])
 def test_saddle_point_with_matching_on_the_hip_path(nx, nb):
     """nlpkkt class without regularisation: [[H, J^T], [J, 0]].  With the maximum-product matching + scaling (MC64's job) in
-    front, the factorisation without pivoting goes through on the device and matches the oracle on the same scaled matrix."""
+    front, the factorisation without pivoting goes through on the device and matches the oracle on the same scaled matrix.
+    nx = 24 / 32 (n = 27 648 / 65 536, F = 6.5e9 / 3.9e10): sizes at which the dense paths carry the factorisation (VERDICT r4
+    next #5; the oracle needs 6 / 25 s for them, nx = 48 would take it minutes)."""
     from .test_scaling import saddle
 
     mat = saddle(nx)

@@ -1,6 +1,7 @@
 """Maximum-product matching + scaling (pg_scaling.cpp; the job of the reference's MC64 port, src/pangulu_reordering.c:149-681,
 driver :1130-1272): properties of the matching, and the KKT class it exists for."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -101,15 +102,26 @@ def test_saddle_point_system_needs_and_gets_the_matching(nb):
     b = M.rhs_of_ones(n, cp, ri, va)
     lib = library_for(oracle_library("r64"))
     res = {}
-    for scaling in (False, True):
-        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, lib=lib, scaling=scaling)
-        pa.pangulu_gstrf(h)
-        x = pa.pangulu_gstrs(h, b)
-        pa.pangulu_finalize(h)
+    for scaling, zero_diagonal in ((False, "0"), (False, None), (True, None)):
+        if zero_diagonal is not None:
+            os.environ["PANGULU_AMD_ZERO_DIAGONAL"] = zero_diagonal
+        try:
+            h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, lib=lib, scaling=scaling)
+            inserted = int(h.info()["inserted_diagonals"])
+            pa.pangulu_gstrf(h)
+            x = pa.pangulu_gstrs(h, b)
+            pa.pangulu_finalize(h)
+        finally:
+            os.environ.pop("PANGULU_AMD_ZERO_DIAGONAL", None)
         with np.errstate(all="ignore"):
-            res[scaling] = M.relative_residual(n, cp, ri, va, x, b)
-    assert res[True] < 1e-10, res
-    assert not (res[False] < 1e-6), res  # zero pivots clamped to 1e-16: garbage without the matching
+            res[(scaling, zero_diagonal)] = (M.relative_residual(n, cp, ri, va, x, b), inserted)
+    # with the matching the permuted diagonal is full: nothing is inserted, the solve is exact to round-off
+    assert res[(True, None)][0] < 1e-10 and res[(True, None)][1] == 0, res
+    # without it and without the reference's zero-diagonal rule: zero pivots clamped to 1e-16 -- garbage
+    assert not (res[(False, "0")][0] < 1e-6) and res[(False, "0")][1] == 0, res
+    # without it but with the rule (src/pangulu_reordering.c:715-796): every constraint row gets a 1e-8 diagonal entry -- the solution of
+    # a system perturbed by 1e-8, which is what the reference delivers for such files when built without its MC64 port
+    assert res[(False, None)][1] == n // 2 and 1e-12 < res[(False, None)][0] < 1e-6, res
 
 
 def test_scaling_leaves_well_posed_systems_solvable_and_is_one_shot():
@@ -122,3 +134,54 @@ def test_scaling_leaves_well_posed_systems_solvable_and_is_one_shot():
     x = pa.pangulu_gstrs(h, b)
     pa.pangulu_finalize(h)
     assert M.relative_residual(n, cp, ri, va, x, b) < 1e-12
+
+
+def _without_some_diagonal_entries(mat, every):
+    """The matrix with the STORED diagonal entry of every `every`-th column removed, and the same matrix with 1e-8 stored there."""
+    n, cp, ri, va, co = mat
+    A = M.to_scipy(n, cp, ri, va).tolil()
+    B = A.copy()
+    cols = list(range(1, n, every))
+    for j in cols:
+        A[j, j] = 0.0
+        B[j, j] = 1e-8
+    A = A.tocsc()
+    A.eliminate_zeros()
+    A.sort_indices()
+    B = B.tocsc()
+    B.sort_indices()
+    pack = lambda X: (n, X.indptr.astype(np.uint64), X.indices.astype(np.uint32), X.data.astype(np.float64), co)
+    return pack(A), pack(B), len(cols)
+
+
+def test_zero_diagonal_rule_of_the_reference():
+    """src/pangulu_reordering.c:715-796 (pangulu_add_diagonal_element_csc, called on the reference's METIS path, :959): a column
+    without a stored diagonal entry gets one with the value 1e-8.  Here on the nested-dissection path: the factors of a matrix with
+    missing diagonal entries are BIT FOR BIT those of the same matrix with 1e-8 stored there (the diagonal is not part of the
+    graph: same ordering), the handle reports how many were inserted; PANGULU_AMD_ZERO_DIAGONAL=0 and the identity ordering
+    (the reference's build without METIS) insert nothing."""
+    missing, explicit, k = _without_some_diagonal_entries(M.fem27(6), 7)
+    lib = library_for(oracle_library("r64"))
+    out = {}
+    for name, mat in (("missing", missing), ("explicit", explicit)):
+        n, cp, ri, va, co = mat
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=32, coords=co, lib=lib)
+        inserted = int(h.info()["inserted_diagonals"])
+        pa.pangulu_gstrf(h)
+        L, U = pa.factors_as_scipy(h)
+        out[name] = (inserted, L, U, pa.permutation(h))
+        pa.pangulu_finalize(h)
+    assert out["missing"][0] == k and out["explicit"][0] == 0
+    assert (out["missing"][3] == out["explicit"][3]).all()
+    assert abs(out["missing"][1] - out["explicit"][1]).max() == 0 and abs(out["missing"][2] - out["explicit"][2]).max() == 0
+    n, cp, ri, va, co = missing
+    h = pa.pangulu_init(n, len(va), cp, ri, va, nb=32, ordering="identity", lib=lib)
+    assert int(h.info()["inserted_diagonals"]) == 0
+    pa.pangulu_finalize(h)
+    os.environ["PANGULU_AMD_ZERO_DIAGONAL"] = "0"
+    try:
+        h = pa.pangulu_init(n, len(va), cp, ri, va, nb=32, coords=co, lib=lib)
+        assert int(h.info()["inserted_diagonals"]) == 0
+        pa.pangulu_finalize(h)
+    finally:
+        del os.environ["PANGULU_AMD_ZERO_DIAGONAL"]
