@@ -76,8 +76,10 @@ def parse_args(argv=None):
     ap.add_argument("--host-threads", type=int, default=0, help="threads for the analysis phase (0: all cores / ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sched-steps", action="store_true", help="skip the three scheduler-in-the-loop steps behind the timed ones (profiling runs)")
-    ap.add_argument("--multi-replay", action="store_true", help="N > 1: every rank logs its first factorisation (a warm-up step) and replays the log "
-                    "afterwards (PANGULU_AMD_MULTI_REPLAY=1; needs --warmup >= 1 and a transport that defers sends: rccl or ipc)")
+    ap.add_argument("--multi-replay", action="store_true", help="(the default since round 5; kept for old command lines) N > 1: every rank logs its "
+                    "first factorisation (a warm-up step) and replays the log afterwards; needs --warmup >= 1 and a transport that defers sends "
+                    "(rccl or ipc) -- otherwise the ranks fall back to the scheduler by themselves")
+    ap.add_argument("--no-multi-replay", action="store_true", help="N > 1: the scheduler in the loop in every step (PANGULU_AMD_MULTI_REPLAY=0)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run (the ldoor-class matrix of "
                     "BASELINE configs[1] and round 3's headline matrix, 3 steps each): their lines ride in the JSON line as `secondary`")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -365,6 +367,8 @@ def passthrough_args(args):
         out.append("--no-secondary")
     if args.multi_replay:
         out.append("--multi-replay")
+    if args.no_multi_replay:
+        out.append("--no-multi-replay")
     if args.no_sched_steps:
         out.append("--no-sched-steps")
     if args.no_coords:
@@ -466,7 +470,9 @@ def gpu_worker_main(args):
     # 44.6 ms (44.0-48.0) on one box.  A user of the library sets it the same way.
     os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     os.environ["LOCAL_RANK"] = str(local_rank)
-    if args.multi_replay:
+    if args.no_multi_replay:
+        os.environ["PANGULU_AMD_MULTI_REPLAY"] = "0"
+    elif args.multi_replay:
         os.environ["PANGULU_AMD_MULTI_REPLAY"] = "1"
 
     import torch  # device selection + the synchronise the contract asks for; not on the compute path
@@ -572,7 +578,13 @@ def gpu_worker_main(args):
         x = pa.pangulu_gstrs(h, b)                                  # ||Ax - b|| / ||b||, b = A*1 (examples/example.c:252-264,304-364)
         gstrs_s = time.perf_counter() - t_solve0
         if rank == 0:
-            residual = M.relative_residual(n, cp, ri, va, x, b)
+            va_check = va
+            if os.environ.get("PANGULU_BENCH_TEST_BREAK_FACTORS"):
+                # (tests/test_gpu_smoke_bench.py: the gate itself under test -- the residual is taken against a matrix whose largest
+                #  entry was changed behind the factorisation's back, i.e. the factors are those of the wrong matrix)
+                va_check = np.array(va, copy=True)
+                va_check[int(np.argmax(np.abs(va_check)))] *= 1.5
+            residual = M.relative_residual(n, cp, ri, va_check, x, b)
     pa.hip_stats(lib, reset=True)
 
     # One rank replays its recorded launch schedule; N > 1 ranks have to run the scheduler beside the device (arrival order is

@@ -1181,7 +1181,7 @@ void record_schedule(Solver &S)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Multi-rank replay (round 4; PANGULU_AMD_MULTI_REPLAY=1).  A rank's FIRST factorisation runs the scheduler and records -- the
+// Multi-rank replay (round 4; the default since round 5, PANGULU_AMD_MULTI_REPLAY=0 turns it off).  A rank's FIRST factorisation runs the scheduler and records -- the
 // back-end its launches (schedule cmd 5: like a single-rank recording, descriptor segments packed), the scheduler this rank's log
 // (Solver::RankLog): the operation range of every platform call, the markers between them and the blocks announced behind each,
 // and the blocks of other ranks in the order they were handled, with the receive slot each one landed in and how many had been
@@ -1196,7 +1196,11 @@ void record_schedule(Solver &S)
 // ---------------------------------------------------------------------------------------------------------------------
 static bool multi_replay_enabled()
 {
-    static const bool on = getenv("PANGULU_AMD_MULTI_REPLAY") && atoi(getenv("PANGULU_AMD_MULTI_REPLAY")) != 0;
+    // ON by default since round 5 (PANGULU_AMD_MULTI_REPLAY=0 turns it off): N = 1 and N > 1 then run the same kind of loop -- the
+    // first factorisation of a handle schedules and records, later ones replay -- and a rank whose log cannot be replayed (a receive
+    // slot used twice, a transport that copies at post time, options changed since) falls back to the scheduler by itself, before
+    // its start barrier, whatever the other ranks do.
+    static const bool on = !getenv("PANGULU_AMD_MULTI_REPLAY") || atoi(getenv("PANGULU_AMD_MULTI_REPLAY")) != 0;
     return on && g_replay_enabled != 0;
 }
 

@@ -12,6 +12,13 @@ inline bool getrf_tiled_selected()
     return on;
 }
 
+// round 5's kernel (pg_hip_getrf_pipe.h) for blocks factorised in their mirrors; PANGULU_HIP_GETRF_PIPE=0 keeps the tiled kernel
+inline bool getrf_pipe_selected()
+{
+    static const bool on = !(getenv("PANGULU_HIP_GETRF_PIPE") && atoi(getenv("PANGULU_HIP_GETRF_PIPE")) == 0);
+    return on;
+}
+
 void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_join)
 {
     HostTimer ht(2);
@@ -236,6 +243,24 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         const unsigned ntake = (unsigned)take;
                         PEND.plain = [=]()
                         { PG_LAUNCH(getrf_tiled_f64_kernel, dim3(ntake), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, fc, (unsigned long long *)nullptr); };
+                    }
+                    else if (getrf_pipe_selected() && all_images && (nb == 128 || nb == 256))
+                    {
+                        // round 5: the trailing block resident in registers, panels finished on the matrix cores (pg_hip_getrf_pipe.h)
+                        const size_t lds_p = gp_lds_bytes(nb);
+                        static size_t p_allowed = 0;
+                        if (lds_p > p_allowed)
+                        {
+                            HIP_CHECK(hipFuncSetAttribute((const void *)getrf_pipe_f64_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gp_lds_bytes(256)));
+                            HIP_CHECK(hipFuncSetAttribute((const void *)getrf_pipe_f64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gp_lds_bytes(256)));
+                            p_allowed = gp_lds_bytes(256);
+                        }
+                        if (nb == 256)
+                            PG_LAUNCH(getrf_pipe_f64_kernel<16>, dim3((unsigned)take), dim3(GP_THREADS), lds_p, ks, d_tasks, nb, B.d_flops + 1,
+                                      debug_stamps ? B.d_flops + 8 : nullptr);
+                        else
+                            PG_LAUNCH(getrf_pipe_f64_kernel<8>, dim3((unsigned)take), dim3(GP_THREADS), lds_p, ks, d_tasks, nb, B.d_flops + 1,
+                                      debug_stamps ? B.d_flops + 8 : nullptr);
                     }
                     else
                         PG_LAUNCH(getrf_tiled_f64_kernel, dim3((unsigned)take), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, B.d_flops + 1,

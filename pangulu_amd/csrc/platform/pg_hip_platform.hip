@@ -727,6 +727,7 @@ __global__ __launch_bounds__(GETRF_THREADS) void getrf_kernel(const GetrfTaskD *
 
 #if defined(PG_DENSE_PANELS)
 #include "pg_hip_getrf_tiled.h"
+#include "pg_hip_getrf_pipe.h"
 
 // -----------------------------------------------------------------------------------------------------------------
 // GETRF of a level's diagonal blocks and the dense TSTRF/GESSM against them in ONE launch (the reference runs them as

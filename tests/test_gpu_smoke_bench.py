@@ -97,3 +97,50 @@ def test_bench_on_a_matrix_file_without_coordinates(tmp_path):
         assert line["data"] == ("file" if "--mtx" in extra else "synthetic")
         flops.append(line["config"]["flop"])
     assert flops[0] == flops[1] == flops[2]  # the same matrix three ways: the same ordering, the same structural flops
+
+
+def test_bench_eight_ranks_on_one_gpu_and_multi_replay():
+    """First-contact rehearsal of the driver's 8-GPU run on the one GPU of the box (VERDICT r4 next #3c): `bench.py --gpus 8`
+    self-launched -- eight supervisors, the transport order rccl -> ipc -> host walked by all of them together (RCCL refuses eight
+    ranks on one device), cpu_baseline R x 1 -- once with the scheduler in every step (--no-multi-replay) and once in the default mode (every rank
+    replays the log of its first factorisation).  Eight ranks share 288 GB here, so the matrix is small; what is checked is the contract, not a rate."""
+    for extra in (["--no-multi-replay"], []):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "fem27", "--size", "32", "--nb", "128",
+                              "--steps", "3", "--warmup", "2", "--cpu-sample-stride", "4"] + extra, capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+        line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{"metric"')][-1])
+        for key in CONTRACT_KEYS:
+            assert key in line, key
+        assert line["n_gpus"] == 8 and line["value"] > 0 and not line["parity_failed"]
+        assert line["residual"] < 1e-10 and line["factor_check"] < 1e-10
+        cfg = line["config"]
+        assert cfg["transport"] in ("ipc", "host") and cfg["transport_tried"], cfg  # (one device: no RCCL communicator over eight ranks)
+        assert any(a["transport"] == "rccl" for a in cfg["worker_attempts"]) and cfg["worker_attempts"][-1]["done"], cfg["worker_attempts"]
+        assert line["cpu_baseline"]["cores"] == 8 and line["cpu_baseline"]["one_rank_x_one_thread"]["cores"] == 1
+        m = line["model"]
+        assert m["sent_GB"] > 0 and m["latency_chain_ms"] > m["critical_path_ms"] and 1.0 <= m["rank_flop_share_max_over_mean"] < 3.0
+        assert m["hbm_fullest_rank_GB"]["total"] > 0
+        # (the default: every rank replays the log of its first factorisation; ipc defers sends, host staging cannot be replayed)
+        assert line["static_schedule_replayed"] is (not extra and cfg["transport"] == "ipc"), (extra, cfg["transport"], line["static_schedule_replayed"])
+
+
+def test_bench_scaling_prediction_and_parity_gate():
+    """One rank: the line carries the structure's forecast for 1 / 2 / 4 / 8 ranks (T*(N), link term, latency-aware chain, HBM of
+    the fullest rank).  And THE GATE: a factorisation whose factors fail the reference's criteria must not publish a rate -- forced
+    here with PANGULU_BENCH_TEST_BREAK_FACTORS (bench.py perturbs one value of the device records before the checks): value null,
+    parity_failed, exit code 4."""
+    line = run_bench("--no-cpu-baseline")
+    pred = line["model"]["scaling_prediction"]
+    assert set(pred) == {"1", "2", "4", "8"}
+    assert abs(pred["1"]["T_star_ms"] - line["model"]["T_star_ms"]) <= 1e-9 * line["model"]["T_star_ms"] and pred["1"]["sent_GB"] == 0
+    for N in ("2", "4", "8"):
+        assert pred[N]["sent_GB"] > 0 and pred[N]["latency_chain_ms"] >= pred["1"]["latency_chain_ms"] * (1 - 1e-12)
+        assert pred[N]["hbm_fullest_rank_GB"] <= pred["1"]["hbm_fullest_rank_GB"]
+        assert pred[N]["bound_ms"] >= pred[N]["latency_chain_ms"] * (1 - 1e-12)
+    assert line["parity_failed"] is False and line["factor_check_vectors"] == 8
+    env = dict(os.environ, PANGULU_BENCH_TEST_BREAK_FACTORS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "shell", "--size", "40", "40", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-profile-pass"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 4, (out.returncode, out.stdout[-500:], out.stderr[-2000:])
+    bad = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{"metric"')][-1])
+    assert bad["value"] is None and bad["parity_failed"] is True and (bad["factor_check"] > 1e-10 or bad["residual"] > 1e-10)

@@ -45,10 +45,11 @@ def matrix(workload, size):
 
 
 def analyse(workload, size, vtype, nb, threads):
-    mat, label = matrix(workload, size)
+    if vtype.startswith("c") and workload == "poisson":
+        mat, label = M.poisson3d(size, dtype=np.complex128, shift=0.5j), "poisson3d(%d), diagonal 6 + 0.5i" % size  # 
+    else:
+        mat, label = matrix(workload, size)
     n, cp, ri, va, co = mat
-    if vtype.startswith("c"):
-        va = np.asarray(va, dtype=np.complex128) + 0.5j * (np.asarray(ri) == np.repeat(np.arange(n), np.diff(cp)))  # complex-shifted diagonal
     lib = library_for(oracle_library(vtype), vtype)
     t0 = time.time()
     h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering="nd", coords=co, lib=lib, nthread=threads)
