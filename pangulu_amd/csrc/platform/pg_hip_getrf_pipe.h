@@ -15,20 +15,24 @@
 //     tiles of the last 12 tile rows and columns -- 144 of 256 at nb = 256, all 64 at nb = 128 -- IN REGISTERS from the prologue
 //     to the step that finishes them: 24 tiles = 192 registers per wavefront.  A step's update of a resident tile is four MFMAs on
 //     operands from the LDS images of the panel and the strip; nothing of the trailing block travels.
-//   * the band of the first tile rows / columns that does not fit (tiles with min(i, j) < 4 at nb = 256) is handled LEFT-LOOKING: a
-//     band tile stays in memory untouched until the step that finishes it, and then receives all its (at most three) updates at
-//     once from the finished factor tiles in memory (same CU: workgroup-scope visibility, a drained store counter and a barrier).
+//   * the band of the first tile rows / columns that does not fit (tiles with min(i, j) < 4 at nb = 256) takes the panels
+//     right-looking as well, but THROUGH MEMORY: in the trailing phase of step k its owner loads a band tile (three in flight),
+//     applies panel k - 1 from the same LDS images and stores it back -- except the tiles of step k's own panel and strip, which go
+//     to STAGING SLOTS in LDS (2 x 16 slots of [16][17] doubles) and are finished from there.  (The first version was left-looking:
+//     a band tile received all its updates at the step that finishes it, from factor tiles read back from memory -- up to three
+//     dependent trips to L2 per tile inside the one phase every wavefront waits for: 75 of 198 us.)
 //   * panel and strip tiles are finished by their OWNERS on the matrix cores with the inverses of the diagonal tile's factors
 //     (X = T U11^-1, Y = L11^-1 T; the accumulator layout of a tile is the operand layout of the second MFMA source, so a resident
 //     tile is an operand as it stands); those inverses are what the dense TSTRF/GESSM of the level want in the image anyway
 //     (pg_hip_trsm_dense.h), so nothing is computed twice, and the 16-step substitutions are gone.
-//   * ONE wavefront factorises the diagonal tile and inverts its two factors (a quarter wavefront each) while the others apply
-//     the previous panel to the trailing block; three workgroup barriers per step:
-//         A  diagonal tile k in LDS      | wavefront 0: LU + inverses        ||  trailing wavefronts: panel k-1 on their resident tiles
+//   * ONE wavefront factorises the diagonal tile (branch-free, the next pivot's reciprocal beside the current rank-1 update) and
+//     inverts its two factors BLOCKED BY 4 ON THE MATRIX CORES (W' = W - (W B) W per level, see there) while the others apply the
+//     previous panel to the trailing block; three workgroup barriers per step:
+//         A  diagonal tile k in LDS      | wavefront 0: LU + inverses        ||  trailing wavefronts: panel k-1 on their tiles
 //         B  inverses in LDS, images free| owners finish panel / strip tiles of step k into the images and the block's image in memory
 //         C  images of step k complete   | the owner of diagonal tile k+1 applies panel k to it and hands it over
-//   * 69 KB of LDS (one image pair: a step's tiles are finished behind barrier B, when nobody reads the previous ones any more):
-//     two factorisations, or one beside an update workgroup, share a CU.
+//   * LDS: 47 KB at nb = 128, 148 KB at nb = 256 (one image pair + the staging slots).  The 256 registers
+//     per wavefront allow one workgroup per CU whatever the LDS says.
 // Order of operations per entry: updates in ascending pivot order panel by panel, summed by the matrix cores inside a panel (as the
 // tiled kernel); the panel solves multiply by explicit 16 x 16 inverses instead of substituting (as the dense TSTRF/GESSM do).
 // Parity: within 1e-12 of the oracle (tests/test_gpu_parity*.py run every case on this kernel by default; PANGULU_HIP_GETRF_PIPE=0
@@ -38,12 +42,18 @@
 #define GP_THREADS 512
 #define GP_TWAVES 6
 
+#define GP_STAGE_SLOT (16 * 17 * 8) // bytes of one staged band tile ([16][17] doubles)
 __host__ __device__ inline size_t gp_lds_bytes(int nb)
 {
-    return sizeof(double) * (2 * 16 * (size_t)(nb + 2) + 16 * 17 /* Td */ + 2 * 16 * 17 /* inversion images */ + 2 * 16 * 17 /* IL, IU */ + 48 /* rdiag, row scalings of the inversion */) +
-           sizeof(unsigned) * (2 * (size_t)(nb + 1) + 16);
+    const size_t images = sizeof(double) * (2 * 16 * (size_t)(nb + 2) + 16 * 17 /* Td */ + 3 * 16 * 17 /* factorised tile, block-diagonal inverses of L and U */ + 2 * 16 * 17 /* IL, IU */ + 48 /* rdiag, row scalings of the inversion */) +
+                          sizeof(unsigned) * (2 * (size_t)(nb + 1) + 16);
+    // (nb = 256: the panel and strip tiles of a band step wait in LDS between their last update and their finish)
+    return ((images + 15) & ~(size_t)15) + (nb > 192 ? (size_t)2 * (nb / 16) * GP_STAGE_SLOT : 0);
 }
 
+#ifndef GP_BAND_CHUNK
+#define GP_BAND_CHUNK 3 // band tiles in flight per trailing wavefront
+#endif
 __device__ __forceinline__ void gp_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -60,7 +70,7 @@ __device__ __forceinline__ void gp_factor_wavefront(double *__restrict__ D, doub
 {
     constexpr int nb = NT * 16;
     constexpr unsigned colB = (unsigned)nb * 8u;
-    const int lane = threadIdx.x & 63, l15 = lane & 15;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     typedef double __attribute__((address_space(1))) *gp_gptr;
     // (arguments of a real call arrive in vector registers: the image's address back into scalar ones)
     const unsigned long long d_bits = (unsigned long long)D;
@@ -79,9 +89,8 @@ __device__ __forceinline__ void gp_factor_wavefront(double *__restrict__ D, doub
         dbg[slot] += now_ - ph_;                                          \
         ph_ = now_;                                                       \
     }
-    double *dsel = rdiag + 16; // [0][r]: reciprocal pivot 15 - r (U group), [1][r]: 1 (L group)
-    if (lane < 16)
-        dsel[16 + lane] = 1.0;
+    for (int i = lane; i < 2 * 272; i += 64)
+        Mi[272 + i] = 0.0; // (the two block-diagonal images: only their diagonal blocks are ever written)
     // ================= the factorisation wavefront: LU of diagonal tile k, then the inverses of its two factors =================
     for (int k = 0; k < NT; k++)
     {
@@ -127,80 +136,108 @@ __device__ __forceinline__ void gp_factor_wavefront(double *__restrict__ D, doub
         if (lane < 16)
         {
             rdiag[lane] = myrp;
-            dsel[15 - lane] = myrp; // (the U group's row scaling in the index-reversed inversion below)
         }
         if (lane < 16)
         {
 #pragma unroll
             for (int c = 0; c < 16; c++)
-            {
-                Mi[lane * 17 + c] = x[c];                        // plain image (the L factor is read from it)
-                Mi[272 + (15 - lane) * 17 + (15 - c)] = x[c];    // index-reversed image (U becomes lower triangular)
-            }
+                Mi[lane * 17 + c] = x[c];
         }
         wave_lds_fence();
         GP_PH(17)
-        // inverses: lanes 16..31 solve L y = e_c on the plain image, lanes 0..15 solve U x = e_c on the reversed one (a forward
-        // substitution as well); the whole column goes to LDS (zeros outside the triangle)
-        if (lane < 32)
+        // Inverses of the two factors, blocked by 4 on the matrix cores.  With W0 = the inverses of the four 4 x 4 diagonal blocks
+        // (block diagonal) and B the factor's blocks OFF that diagonal, one level doubles the block size:
+        //       W' = W - (W B') W ,  B' = the off-diagonal blocks that pair up neighbouring diagonal blocks of this level
+        // ([[A, 0], [B, C]]^-1 = [[A^-1, 0], [-C^-1 B A^-1, C^-1]] for L; the mirrored statement for U): two levels, each two
+        // dependent products of which only two k-quarters are non-zero (a quarter of the MFMA's k IS a 4-block).  The products
+        // chain in registers where the previous result is the left factor (the accumulator layout is the second source's);
+        // W goes through LDS once per level to become a right factor.  L and U run interleaved.  0.9 us per tile where the
+        // sixteen-step substitutions of the previous build took 3.0.
         {
-            const int grp = (lane >> 4) & 1, c = l15;
-            const double *M = Mi + (grp ? 0 : 1) * 272;
-            const double *dsl = dsel + grp * 16; // row scalings: 1 for L (unit diagonal), reciprocal pivots in reversed order for U
-            const int cc = grp ? c : 15 - c;
-            // Row by row with the NEXT row's entries of the factor in flight while the current one is summed (two row buffers; a
-            // compiler barrier between the rows keeps the loads where they are: left alone, the compiler hoists all 120 entries to
-            // the top, spills, and the inversion took 8 us per tile instead of the half microsecond its dependent chain needs).
-            double z[16], bufA[16], bufB[16];
-            z[0] = ((cc == 0) ? 1.0 : 0.0) * dsl[0];
-            bufA[0] = M[1 * 17 + 0];
+            const int grp = (lane >> 4) & 1, b4 = (l15 >> 2) * 4, cb = l15 & 3; // lanes 0..15: U (index-reversed), 16..31: L
+            double(*W0L)[17] = reinterpret_cast<double(*)[17]>(Mi + 272);
+            double(*W0U)[17] = reinterpret_cast<double(*)[17]>(Mi + 544);
+            // first-source form of the whole factorised tile: M(4 q + l4, l15)
+            double mq[4];
 #pragma unroll
-            for (int r = 1; r < 16; r++)
+            for (int q = 0; q < 4; q++)
+                mq[q] = Mi[(4 * q + l4) * 17 + l15];
+            if (lane < 32)
             {
-                asm volatile("" ::: "memory");
-                if (r + 1 < 16)
+                // column cb of the inverse of diagonal block b4 / 4: forward substitution (U through reversed indices)
+                const int base = grp ? (b4 * 17 + b4) : ((b4 + 3) * 17 + b4 + 3), sg = grp ? 1 : -1;
+                const double m10 = Mi[base + sg * 17], m20 = Mi[base + sg * 34], m21 = Mi[base + sg * 35];
+                const double m30 = Mi[base + sg * 51], m31 = Mi[base + sg * 52], m32 = Mi[base + sg * 53];
+                double d0 = 1.0, d1 = 1.0, d2 = 1.0, d3 = 1.0;
+                if (!grp)
                 {
-#pragma unroll
-                    for (int m = 0; m < 16; m++)
-                        if (m < r + 1)
-                        {
-                            if (r & 1)
-                                bufB[m] = M[(r + 1) * 17 + m];
-                            else
-                                bufA[m] = M[(r + 1) * 17 + m];
-                        }
+                    d0 = rdiag[b4 + 3];
+                    d1 = rdiag[b4 + 2];
+                    d2 = rdiag[b4 + 1];
+                    d3 = rdiag[b4];
                 }
-                const double dr = dsl[r];
-                double s0 = (r == cc) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-                for (int m = 0; m < r; m++)
-                {
-                    const double mv = (r & 1) ? bufA[m] : bufB[m];
-                    if (m & 1)
-                        s1 = __builtin_fma(-mv, z[m], s1);
-                    else
-                        s0 = __builtin_fma(-mv, z[m], s0);
-                }
-                z[r] = (s0 + s1) * dr;
-                asm volatile("" : "+v"(z[r])::"memory"); // (anchors this row's sums in front of the loads of the row after the next)
+                const int cc = grp ? cb : 3 - cb;
+                const double z0 = (cc == 0 ? 1.0 : 0.0) * d0;
+                const double z1 = __builtin_fma(-m10, z0, cc == 1 ? 1.0 : 0.0) * d1;
+                const double z2 = __builtin_fma(-m21, z1, __builtin_fma(-m20, z0, cc == 2 ? 1.0 : 0.0)) * d2;
+                const double z3 = __builtin_fma(-m32, z2, __builtin_fma(-m31, z1, __builtin_fma(-m30, z0, cc == 3 ? 1.0 : 0.0))) * d3;
+                double *W = grp ? &W0L[b4][b4 + cb] : &W0U[b4 + 3][b4 + cb];
+                W[0] = z0;
+                W[sg * 17] = z1;
+                W[sg * 34] = z2;
+                W[sg * 51] = z3;
             }
+            wave_lds_fence();
+            v4f64 wl, wu; // W in column form (= second source, k-quarter by register)
+            double fl[4], fu[4]; // W in first-source form
 #pragma unroll
-            for (int r = 0; r < 16; r++)
+            for (int q = 0; q < 4; q++)
             {
-                if (grp)
-                    IL[r][c] = z[r];
-                else
-                    IU[15 - r][c] = z[r];
+                wl[q] = W0L[l15][4 * q + l4];
+                wu[q] = W0U[l15][4 * q + l4];
+                fl[q] = W0L[4 * q + l4][l15];
+                fu[q] = W0U[4 * q + l4][l15];
             }
-            // ... and into the image in memory, over the diagonal tile (U11^-1 on and above the diagonal, L11^-1 below): scalar
-            // base + 32-bit lane offset (as 64-bit pointers these sixteen stores became sixteen induction variables in scratch)
-            const unsigned col_lane = (unsigned)c * colB;
+            const int cblk = l15 >> 2;
+            const v4f64 zero4 = {0.0, 0.0, 0.0, 0.0};
+            // level 1: blocks (1,0), (3,2) of L and (0,1), (2,3) of U
+            v4f64 tl = zero4, tu = zero4;
+            tl = __builtin_amdgcn_mfma_f64_16x16x4f64(cblk == 0 ? mq[1] : 0.0, wl[1], tl, 0, 0, 0);
+            tu = __builtin_amdgcn_mfma_f64_16x16x4f64(cblk == 1 ? mq[0] : 0.0, wu[0], tu, 0, 0, 0);
+            tl = __builtin_amdgcn_mfma_f64_16x16x4f64(cblk == 2 ? mq[3] : 0.0, wl[3], tl, 0, 0, 0);
+            tu = __builtin_amdgcn_mfma_f64_16x16x4f64(cblk == 3 ? mq[2] : 0.0, wu[2], tu, 0, 0, 0);
+            wl = __builtin_amdgcn_mfma_f64_16x16x4f64(fl[0], tl[0], wl, 0, 0, DG_NEG_A);
+            wu = __builtin_amdgcn_mfma_f64_16x16x4f64(fu[1], tu[1], wu, 0, 0, DG_NEG_A);
+            wl = __builtin_amdgcn_mfma_f64_16x16x4f64(fl[2], tl[2], wl, 0, 0, DG_NEG_A);
+            wu = __builtin_amdgcn_mfma_f64_16x16x4f64(fu[3], tu[3], wu, 0, 0, DG_NEG_A);
+            // level 2: block (1,0) of 8 x 8 blocks of L, (0,1) of U; W of level 1 through IL / IU to become a right factor
 #pragma unroll
-            for (int r = 0; r < 16; r++)
+            for (int g = 0; g < 4; g++)
             {
-                const int rowL = r, rowU = 15 - r;
-                if (grp ? (rowL > c) : (rowU <= c))
-                    gd(tile_off(k, k), col_lane + (unsigned)(grp ? rowL : rowU) * 8u) = z[r];
+                IL[l15][l4 + 4 * g] = wl[g];
+                IU[l15][l4 + 4 * g] = wu[g];
+            }
+            tl = zero4;
+            tu = zero4;
+            tl = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 < 8 ? mq[2] : 0.0, wl[2], tl, 0, 0, 0);
+            tu = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 >= 8 ? mq[0] : 0.0, wu[0], tu, 0, 0, 0);
+            tl = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 < 8 ? mq[3] : 0.0, wl[3], tl, 0, 0, 0);
+            tu = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 >= 8 ? mq[1] : 0.0, wu[1], tu, 0, 0, 0);
+            wave_lds_fence();
+            const double gl0 = IL[l4][l15], gl1 = IL[4 + l4][l15], gu2 = IU[8 + l4][l15], gu3 = IU[12 + l4][l15];
+            wl = __builtin_amdgcn_mfma_f64_16x16x4f64(gl0, tl[0], wl, 0, 0, DG_NEG_A);
+            wu = __builtin_amdgcn_mfma_f64_16x16x4f64(gu2, tu[2], wu, 0, 0, DG_NEG_A);
+            wl = __builtin_amdgcn_mfma_f64_16x16x4f64(gl1, tl[1], wl, 0, 0, DG_NEG_A);
+            wu = __builtin_amdgcn_mfma_f64_16x16x4f64(gu3, tu[3], wu, 0, 0, DG_NEG_A);
+            // the inverses: into LDS for the finishing wavefronts, and into the image in memory over the diagonal tile (U11^-1 on
+            // and above the diagonal, L11^-1 below)
+            const unsigned cfl = ((unsigned)l4 * (unsigned)nb + (unsigned)l15) * 8u;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                IL[l15][l4 + 4 * g] = wl[g];
+                IU[l15][l4 + 4 * g] = wu[g];
+                gd(tile_off(k, k) + (unsigned)g * 4u * colB, cfl) = (l15 > l4 + 4 * g) ? wl[g] : wu[g];
             }
         }
         if (lane < 16)
@@ -236,8 +273,8 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     double *Pm = reinterpret_cast<double *>(smem_raw); // Pm[c * ldp + r]: column c of the panel, row r (absolute)
     double *Sm = Pm + 16 * ldp;                        // Sm[k * ldp + c]: row k of the strip, column c (absolute)
     double(*Td)[17] = reinterpret_cast<double(*)[17]>(Sm + 16 * ldp); // diagonal tile: pre-LU, then L11 \ U11
-    double *Mi = reinterpret_cast<double *>(Td) + 16 * 17;              // inversion images: [plain, index-reversed][16][17]
-    double(*IL)[17] = reinterpret_cast<double(*)[17]>(Mi + 2 * 16 * 17); // L11^-1 [row][column]
+    double *Mi = reinterpret_cast<double *>(Td) + 16 * 17;              // inversion images [3][16][17]: L \\ U, blockdiag(L)^-1, blockdiag(U)^-1
+    double(*IL)[17] = reinterpret_cast<double(*)[17]>(Mi + 3 * 16 * 17); // L11^-1 [row][column]
     double(*IU)[17] = IL + 16;                                          // U11^-1 [row][column]
     double *rdiag = reinterpret_cast<double *>(IU + 16);                 // reciprocals of the (clamped) pivots of the tile
     u32 *sLcp = reinterpret_cast<u32 *>(rdiag + 48);
@@ -322,6 +359,10 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     constexpr unsigned SM_OFF = 16u * (unsigned)ldp * 8u; // Sm behind Pm
     const unsigned frag_lane = pm_base + ((unsigned)l4 * (unsigned)ldp + (unsigned)l15) * 8u; // + q * 4 ldp * 8 + tile * 128 (+ SM_OFF)
     const unsigned tstore_lane = pm_base + SM_OFF + ((unsigned)l15 * (unsigned)ldp + (unsigned)l4) * 8u; // strip image, transposed store: + tile * 128 + g * 32
+    // staging slots of a band step (nb = 256): slot i = panel tile (i, k) as [column][row], slot 16 + j = strip tile (k, j) as [row][column]
+    const unsigned stage_base = pm_base + (unsigned)((gp_lds_bytes(nb) - (nb > 192 ? (size_t)2 * NT * GP_STAGE_SLOT : 0)));
+    const unsigned stage_lane_cr = stage_base + ((unsigned)l4 * 17u + (unsigned)l15) * 8u; // + g * 4 * 17 * 8: element (l15, l4 + 4 g) of [c][r] / (l4 + 4 g, l15) of [r][c]
+    const unsigned stage_lane_rc = stage_base + ((unsigned)l15 * 17u + (unsigned)l4) * 8u; // + g * 32:         element (l15, l4 + 4 g) of [r][c]
     // (an address formed WHERE it is used -- lane constant + tile offset, one vector add -- instead of one register per (tile, quarter)
     //  of the wavefront kept for the whole kernel: the first build spilled 46 of them and reloaded them from scratch in every step)
     auto fresh = [](unsigned v) -> unsigned
@@ -382,36 +423,11 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int g = 0; g < 4; g++)
             gd(o + g * col4B, cf) = t[g];
     };
-    // ... row form: as the first MFMA source of a product (a finished U tile read back for a band tile's left-looking updates)
-    auto load_tile_rowform = [&](int ti, int tj) -> v4f64
-    {
-        v4f64 t;
-        const unsigned o = tile_off(ti, tj);
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            t[g] = gd(o + 32u * g, rf);
-        return t;
-    };
     // MFMA operand fragments of k-quarter q from the images: of the panel for tile row ti, of the strip for tile column tj
     auto panel_frag = [&](int q, int ti) -> double
     { return *(gp_lptr)(unsigned long long)(fresh(frag_lane) + (unsigned)(ti < 0 ? 0 : ti) * 128u + (unsigned)q * (4u * (unsigned)ldp * 8u)); };
     auto strip_frag = [&](int q, int tj) -> double
     { return *(gp_lptr)(unsigned long long)(fresh(frag_lane) + (unsigned)(tj < 0 ? 0 : tj) * 128u + (SM_OFF + (unsigned)q * (4u * (unsigned)ldp * 8u))); };
-    // band tile (min(ti, tj) < M0): everything the steps 0 .. upto-1 owe it, from the finished factor tiles in memory
-    auto band_catch_up = [&](v4f64 t, int ti, int tj, int upto) -> v4f64
-    {
-        for (int m = 0; m < upto; m++)
-        {
-            const unsigned cm = (unsigned)__builtin_amdgcn_readfirstlane((int)smap[m]);
-            if (!((cm >> ti) & 1u) || !((unsigned)__builtin_amdgcn_readfirstlane((int)smap[tj]) >> m & 1u))
-                continue;
-            const v4f64 a = load_tile(ti, m), b = load_tile_rowform(m, tj);
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                t = __builtin_amdgcn_mfma_f64_16x16x4f64(b[q], a[q], t, 0, 0, DG_NEG_A);
-        }
-        return t;
-    };
     // finish a panel tile: X = T U11^-1 (the tile is the second MFMA source as it stands), into the panel image and into memory
     auto finish_panel = [&](v4f64 t, int ti, int k) -> v4f64
     {
@@ -470,25 +486,102 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 R[ri][ci] = load_tile(i, j);
         }
 
+    // (a wait the COMPILER sees: with the resident loads still pending in its books it would drain the load counter in front of every
+    //  matrix instruction of the loop below -- and with it the band chunks in flight there)
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     for (int k = 0; k < NT; k++)
     {
         const unsigned colk = (unsigned)__builtin_amdgcn_readfirstlane((int)smap[k]); // bit i: tile (i, k) holds pattern entries
-        // ---- between A and B: panel k - 1 on the resident tiles (the diagonal tile k has had it already) -----------------
-        if (k > 0)
+        // ---- between A and B: panel k - 1 on this wavefront's tiles (the diagonal tile k has had it already) ------------------
+        // Resident tiles: four MFMAs each on operands from the images, nothing travels.
+        // Band tiles (min(i, j) < M0) take the panels right-looking as well, but through memory, GP_BAND_CHUNK tiles at a time:
+        // lane u proposes tile (row_of(u / AC), col_of(u % AC)) and the live ones are walked by the ballot.  (Issuing a chunk's
+        // loads in front of a k-quarter of the resident update and consuming them behind it was tried: with 250 registers live the
+        // compiler reuses the chunk's registers inside the quarter and drains the load counter there -- no gain, 156 against 152 us.)
+        // The tiles of THIS step's panel and strip (min(i, j) == k) go to the staging slots in LDS instead of back to memory:
+        // their owner finishes them from there behind barrier B (in step 0 they pass through here untouched).
         {
             const int kp = k - 1;
-            const unsigned colp = (unsigned)__builtin_amdgcn_readfirstlane((int)smap[kp]);
+            const unsigned colp = kp >= 0 ? (unsigned)__builtin_amdgcn_readfirstlane((int)smap[kp < 0 ? 0 : kp]) : 0u;
+            unsigned long long live = 0, updm = 0;
+            if (M0 > 0 && k < M0)
+            {
+                const int u_ri = lane / AC, u_ci = lane - u_ri * AC;
+                const int u_i = row_of(u_ri), u_j = col_of(u_ci);
+                const int u_m = u_i < u_j ? u_i : u_j;
+                const unsigned u_col = smap[u_j < 0 ? 0 : u_j];
+                const bool cand = lane < AR * AC && u_m >= k && u_m < M0 && !(u_i == k && u_j == k);
+                const bool upd = cand && kp >= 0 && ((colp >> (u_i & 31)) & 1u) && ((u_col >> (kp & 31)) & 1u);
+                const bool stg = cand && u_m == k && ((u_col >> (u_i & 31)) & 1u);
+                live = __builtin_amdgcn_ballot_w64(upd || stg);
+                updm = __builtin_amdgcn_ballot_w64(upd);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (this wavefront's stores of the previous step to the same tiles)
+            }
             // this wavefront's resident rows / columns beyond panel kp form a rectangle anchored at index 0
             unsigned rowlive = 0, collive = 0;
+            if (k > 0)
+            {
 #pragma unroll
-            for (int ri = 0; ri < RR; ri++)
-                if (row_of(ri) > kp && row_of(ri) >= M0 && ((colp >> row_of(ri)) & 1u))
-                    rowlive |= 1u << ri;
+                for (int ri = 0; ri < RR; ri++)
+                    if (row_of(ri) > kp && row_of(ri) >= M0 && ((colp >> row_of(ri)) & 1u))
+                        rowlive |= 1u << ri;
 #pragma unroll
-            for (int ci = 0; ci < RC; ci++)
-                if (col_of(ci) > kp && col_of(ci) >= M0 && ((colmap[ci] >> kp) & 1u))
-                    collive |= 1u << ci;
-            if (rowlive && collive)
+                for (int ci = 0; ci < RC; ci++)
+                    if (col_of(ci) > kp && col_of(ci) >= M0 && ((colmap[ci] >> kp) & 1u))
+                        collive |= 1u << ci;
+            }
+            const bool resident = rowlive && collive;
+#define GP_CHUNK_LOAD()                                           \
+    int ti[GP_BAND_CHUNK], tj[GP_BAND_CHUNK];                     \
+    bool tu[GP_BAND_CHUNK];                                       \
+    v4f64 t[GP_BAND_CHUNK];                                       \
+    _Pragma("unroll") for (int s = 0; s < GP_BAND_CHUNK; s++)     \
+    {                                                             \
+        ti[s] = -1;                                               \
+        tj[s] = 0;                                                \
+        tu[s] = false;                                            \
+        if (live)                                                 \
+        {                                                         \
+            const int u = __builtin_ctzll(live);                  \
+            live &= live - 1;                                     \
+            ti[s] = row_of(u / AC);                               \
+            tj[s] = col_of(u % AC);                               \
+            tu[s] = (updm >> u) & 1ull;                           \
+            t[s] = load_tile(ti[s], tj[s]);                       \
+        }                                                         \
+    }
+#define GP_CHUNK_PROCESS()                                                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < GP_BAND_CHUNK; s++) if (ti[s] >= 0)                                                                \
+    {                                                                                                                                        \
+        if (tu[s])                                                                                                                           \
+        {                                                                                                                                    \
+            _Pragma("unroll") for (int qq = 0; qq < 4; qq++)                                                                                 \
+                t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(strip_frag(qq, tj[s]), panel_frag(qq, ti[s]), t[s], 0, 0, DG_NEG_A);             \
+        }                                                                                                                                    \
+        if (tj[s] == k)                                                                                                                      \
+        {                                                                                                                                    \
+            /* panel tile: [column][row], as the finish reads it (second MFMA source = the accumulator layout) */                            \
+            const unsigned sa = fresh(stage_lane_cr) + (unsigned)ti[s] * GP_STAGE_SLOT;                                                      \
+            _Pragma("unroll") for (int g = 0; g < 4; g++) *(gp_lptr)(unsigned long long)(sa + (unsigned)g * (4u * 17u * 8u)) = t[s][g];       \
+        }                                                                                                                                    \
+        else if (ti[s] == k)                                                                                                                 \
+        {                                                                                                                                    \
+            /* strip tile: [row][column]; the finish reads it transposed in the lanes (first MFMA source) */                                 \
+            const unsigned sa = fresh(stage_lane_rc) + (unsigned)(16 + tj[s]) * GP_STAGE_SLOT;                                               \
+            _Pragma("unroll") for (int g = 0; g < 4; g++) *(gp_lptr)(unsigned long long)(sa + (unsigned)g * 32u) = t[s][g];                   \
+        }                                                                                                                                    \
+        else                                                                                                                                 \
+            store_tile(ti[s], tj[s], t[s]);                                                                                                  \
+    }
+            if (M0 > 0)
+            {
+                while (live)
+                {
+                    GP_CHUNK_LOAD()
+                    GP_CHUNK_PROCESS()
+                }
+            }
+            if (resident)
             {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -521,6 +614,8 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     }
                 }
             }
+#undef GP_CHUNK_LOAD
+#undef GP_CHUNK_PROCESS
         }
         if (wave == 1)
         {
@@ -532,59 +627,83 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             GP_PH(25)
         }
         // ---- between B and C: this wavefront's tiles of tile column k (panel) and tile row k (strip) are finished ---------
+        const int ck = NT - 1 - tc - k; // column index ci with col_of(ci) == k, times 3
+        const int rk = NT - 1 - tr - k; // row index ri with row_of(ri) == k, times 2
+        const bool own_col = ck >= 0 && ck % 3 == 0, own_row = rk >= 0 && rk % 2 == 0;
+        if (M0 > 0 && k < M0)
         {
-            const int ck = NT - 1 - tc - k; // column index ci with col_of(ci) == k, times 3
-            if (ck >= 0 && ck % 3 == 0)
+            // band step: this wavefront's tiles of the panel and the strip wait in their staging slots
+            {
+                const int u_i = row_of(lane & 15);
+                unsigned long long live = __builtin_amdgcn_ballot_w64(lane < AR && own_col && u_i > k && ((colk >> (u_i & 31)) & 1u));
+                while (live)
+                {
+                    const int i = row_of(__builtin_ctzll(live));
+                    live &= live - 1;
+                    const unsigned sa = fresh(stage_lane_cr) + (unsigned)i * GP_STAGE_SLOT;
+                    v4f64 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        x = __builtin_amdgcn_mfma_f64_16x16x4f64(IU[4 * q + l4][l15], *(gp_lptr)(unsigned long long)(sa + (unsigned)q * (4u * 17u * 8u)), x, 0, 0, 0);
+                    const unsigned pa = fresh(frag_lane) + (unsigned)i * 128u;
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        *(gp_lptr)(unsigned long long)(pa + (unsigned)g * (4u * (unsigned)ldp * 8u)) = x[g];
+                    store_tile(i, k, x);
+                }
+            }
+            {
+                const int u_j = col_of(lane & 7);
+                unsigned long long live = __builtin_amdgcn_ballot_w64(lane < AC && own_row && u_j > k && ((smap[u_j < 0 ? 0 : u_j] >> k) & 1u));
+                while (live)
+                {
+                    const int j = col_of(__builtin_ctzll(live));
+                    live &= live - 1;
+                    const unsigned sa = fresh(stage_lane_cr) + (unsigned)(16 + j) * GP_STAGE_SLOT; // ([row][column] read transposed)
+                    v4f64 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        y = __builtin_amdgcn_mfma_f64_16x16x4f64(*(gp_lptr)(unsigned long long)(sa + (unsigned)q * (4u * 17u * 8u)), IL[l15][4 * q + l4], y, 0, 0, 0);
+                    const unsigned ya = fresh(tstore_lane) + (unsigned)j * 128u;
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        *(gp_lptr)(unsigned long long)(ya + 32u * (unsigned)g) = y[g];
+                    store_tile(k, j, y);
+                }
+            }
+        }
+        {
+            if (own_col && k >= M0)
             {
                 const int cik = ck / 3;
 #pragma unroll
-                for (int ri = 0; ri < AR; ri++)
+                for (int ri = 0; ri < RR; ri++)
                 {
                     const int i = row_of(ri);
                     if (i <= k || !((colk >> i) & 1u))
                         continue;
-                    if (k >= M0)
-                    {
-                        // resident (ri < RR, cik < RC): static register indices by enumeration
-                        if (ri < RR)
-                        {
 #pragma unroll
-                            for (int ci = 0; ci < RC; ci++)
-                                if (ci == cik)
-                                    R[ri][ci] = finish_panel(R[ri][ci], i, k);
-                        }
-                    }
-                    else
-                        finish_panel(band_catch_up(load_tile(i, k), i, k, k), i, k);
+                    for (int ci = 0; ci < RC; ci++)
+                        if (ci == cik)
+                            R[ri][ci] = finish_panel(R[ri][ci], i, k);
                 }
             }
-            const int rk = NT - 1 - tr - k; // row index ri with row_of(ri) == k, times 2
-            if (rk >= 0 && rk % 2 == 0)
+            if (own_row && k >= M0)
             {
                 const int rik = rk / 2;
 #pragma unroll
-                for (int ci = 0; ci < AC; ci++)
+                for (int ci = 0; ci < RC; ci++)
                 {
                     const int j = col_of(ci);
                     if (j <= k || j < 0 || !((colmap[ci] >> k) & 1u))
                         continue;
-                    if (k >= M0)
-                    {
-                        if (ci < RC)
-                        {
 #pragma unroll
-                            for (int ri = 0; ri < RR; ri++)
-                                if (ri == rik)
-                                    R[ri][ci] = finish_strip(R[ri][ci], k, j);
-                        }
-                    }
-                    else
-                        finish_strip(band_catch_up(load_tile(k, j), k, j, k), k, j);
+                    for (int ri = 0; ri < RR; ri++)
+                        if (ri == rik)
+                            R[ri][ci] = finish_strip(R[ri][ci], k, j);
                 }
             }
         }
-        if (k + 1 < M0 + 1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (band steps: finished tiles are read back from memory by other wavefronts)
         if (wave == 1)
         {
             GP_PH(26)
@@ -621,7 +740,15 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     }
                 }
                 else
-                    t = band_catch_up(load_tile(kn, kn), kn, kn, kn); // (a band tile: all of steps 0 .. k at once, from memory)
+                {
+                    t = load_tile(kn, kn); // (a band tile: the panels before k are in its memory copy)
+                    if (reaches)
+                    {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            t = __builtin_amdgcn_mfma_f64_16x16x4f64(strip_frag(q, kn), panel_frag(q, kn), t, 0, 0, DG_NEG_A);
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; g++)
                     Td[l15][l4 + 4 * g] = t[g];
