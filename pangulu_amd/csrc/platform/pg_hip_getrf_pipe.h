@@ -21,6 +21,9 @@
 //     to STAGING SLOTS in LDS (2 x 16 slots of [16][17] doubles) and are finished from there.  (The first version was left-looking:
 //     a band tile received all its updates at the step that finishes it, from factor tiles read back from memory -- up to three
 //     dependent trips to L2 per tile inside the one phase every wavefront waits for: 75 of 198 us.)
+//     Also tried: the idle eighth wavefront doing ALL band updates with eight tiles in flight (profiles/r05y_*): 185 us against 153 --
+//     it shares its SIMD with a trailing wavefront whose f64 MFMAs hold up every vector instruction it issues, and 185 band-tile
+//     updates of 0.4 us each in one wavefront is longer than the 31 the six owners do each.
 //   * panel and strip tiles are finished by their OWNERS on the matrix cores with the inverses of the diagonal tile's factors
 //     (X = T U11^-1, Y = L11^-1 T; the accumulator layout of a tile is the operand layout of the second MFMA source, so a resident
 //     tile is an operand as it stands); those inverses are what the dense TSTRF/GESSM of the level want in the image anyway
@@ -41,6 +44,9 @@
 
 #define GP_THREADS 512
 #define GP_TWAVES 6
+#ifndef GP_IDLE_WAVE
+#define GP_IDLE_WAVE 4 // of the eight wavefronts: 0 factorises, six trail, this one leaves
+#endif
 
 #define GP_STAGE_SLOT (16 * 17 * 8) // bytes of one staged band tile ([16][17] doubles)
 __host__ __device__ inline size_t gp_lds_bytes(int nb)
@@ -337,8 +343,9 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     if (lane == 0 && ops)
         atomicAdd(flop_counter, ops);
     GETRF_STAMP(0)
-    if (wave == 1 + GP_TWAVES)
-        return; // (the eighth wavefront has no role: a finished wavefront does not count at the barriers below)
+    if (wave == GP_IDLE_WAVE)
+        return; // (no role: a finished wavefront does not count at the barriers below.  It is the one that would share the factorisation
+                //  wavefront's SIMD -- wavefront w runs on SIMD w % 4 -- and whose f64 MFMAs would hold up every instruction of that chain)
 
     // 32-bit byte offsets into the image (nb <= 256: below 512 KiB): one uniform base + one VGPR per access
     constexpr unsigned colB = (unsigned)nb * 8u, col4B = 4u * colB;
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 
     // ================= trailing wavefronts =================================================================================
-    const int tw = wave - 1, tr = tw & 1, tc = tw >> 1;
+    const int tw = wave < GP_IDLE_WAVE ? wave - 1 : wave - 2, tr = tw & 1, tc = tw >> 1;
     auto row_of = [&](int ri) -> int { return NT - 1 - tr - 2 * ri; };
     auto col_of = [&](int ci) -> int { return NT - 1 - tc - 3 * ci; };
     // occupancy of this wavefront's tile columns (bit i of colmap[ci]: tile (i, col_of(ci)) holds pattern entries)

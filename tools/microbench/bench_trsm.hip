@@ -25,6 +25,17 @@ __device__ inline unsigned logical_block_id(unsigned per_unit)
 #define MIRROR_MAP_BYTES 64
 __device__ inline const unsigned short *mirror_map(const double *mirror, int nb) { return reinterpret_cast<const unsigned short *>(mirror + (size_t)nb * nb); }
 __device__ inline int mirror_column_of(const u32 *sp, int ncols, u32 p) { int lo = 0, hi = ncols; while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sp[mid] <= p) lo = mid; else hi = mid; } return lo; }
+__device__ inline const char __attribute__((address_space(1))) *dg_scalar_base(const char __attribute__((address_space(1))) *p)
+{
+    unsigned long long v = (unsigned long long)p;
+    asm("" : "+s"(v));
+    return (const char __attribute__((address_space(1))) *)v;
+}
+__device__ inline unsigned dg_lane_offset(unsigned v)
+{
+    asm("" : "+v"(v));
+    return v;
+}
 #include "../../pangulu_amd/csrc/platform/pg_hip_trsm_dense.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 int main(int argc, char **argv)
@@ -40,7 +51,7 @@ int main(int argc, char **argv)
     for (int c = 0; c < 16; c++) reinterpret_cast<unsigned short *>(h.data() + (size_t)nb * nb)[c] = 0xFFFF;
     for (int i = 0; i < nmir; i++) CK(hipMemcpy(pool + (size_t)i * mb, h.data(), sizeof(double) * mb, hipMemcpyHostToDevice));
     std::vector<TrsmDenseTaskD> T(ntask);
-    for (int t = 0; t < ntask; t++) { T[t].b = pool + (size_t)t * mb; T[t].lu = pool + (size_t)(ntask + t % nlu) * mb; T[t].is_tstrf = tstrf; T[t].pad_ = 0; }
+    for (int t = 0; t < ntask; t++) { T[t].b = pool + (size_t)t * mb; T[t].lu = pool + (size_t)(ntask + t % nlu) * mb; T[t].is_tstrf = tstrf; T[t].lu_map = 0; T[t].progress = nullptr; }
     TrsmDenseTaskD *dT; CK(hipMalloc(&dT, sizeof(TrsmDenseTaskD) * ntask));
     CK(hipMemcpy(dT, T.data(), sizeof(TrsmDenseTaskD) * ntask, hipMemcpyHostToDevice));
     std::vector<u32> W((size_t)ntask * (nb / 64)); // work list: every (task, slab)
