@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
     {},  # defaults
     {"PANGULU_HIP_TRSM_DIRECT": "0"},          # LDS-staged dense solves
+    {"PANGULU_HIP_GETRF_PIPE": "0"},           # round 4's tiled GETRF (trailing tiles through L2) instead of the register-resident one
+    {"PANGULU_HIP_GETRF_PIPE": "0", "_matrix": "fem27"},
     {"PANGULU_HIP_GETRF_TILED": "0"},          # round-1 GETRF with look-ahead inside the block
     {"PANGULU_HIP_GETRF_TILED": "0", "PANGULU_HIP_GETRF_LOOKAHEAD": "0"},
     {"PANGULU_HIP_RECORDS_STREAM": "0"},       # sparsify jobs of finished blocks on the main stream
@@ -113,6 +115,7 @@ SWEEP_SPACE = [
     (14, ["0"]),             # background updates
     (15, ["0", "3"]),        # dense-front kernel: off / three stages
     (16, ["0", "1", "2", "3", "5"]),  # general update kernel: round 2's, the LDS-DMA ones, tilesv, the pieces kernel
+    ("PANGULU_HIP_GETRF_PIPE", ["0"]),  # (appended: the draws before this entry keep their settings for the options above)
 ]
 
 
