@@ -398,6 +398,8 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
     // ================= trailing wavefronts =================================================================================
     const int tw = wave < GP_IDLE_WAVE ? wave - 1 : wave - 2, tr = tw & 1, tc = tw >> 1;
+    const unsigned panel_base = frag_lane - (unsigned)tr * 128u;          // + tile row offsets of this wavefront: (NT - 1 - 2 ri) * 128
+    const unsigned strip_base = frag_lane + SM_OFF - (unsigned)tc * 128u; // + (NT - 1 - 3 ci) * 128
     auto row_of = [&](int ri) -> int { return NT - 1 - tr - 2 * ri; };
     auto col_of = [&](int ci) -> int { return NT - 1 - tc - 3 * ci; };
     // occupancy of this wavefront's tile columns (bit i of colmap[ci]: tile (i, col_of(ci)) holds pattern entries)
@@ -414,21 +416,25 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             R[ri][ci] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
     // a tile of the image in memory, column form
+    // (ONE lane-offset register per tile, four scalar bases: every vector instruction of a trailing wavefront is issued behind the
+    //  f64 MFMAs of the wavefront it shares its SIMD with, so address arithmetic in vector registers is paid in matrix-pipe time)
     auto load_tile = [&](int ti, int tj) -> v4f64
     {
         v4f64 t;
         const unsigned o = tile_off(ti, tj);
+        const unsigned lo = dg_lane_offset(cf);
 #pragma unroll
         for (int g = 0; g < 4; g++)
-            t[g] = gd(o + g * col4B, cf);
+            t[g] = *(gp_gptr)(dg_scalar_base(Dg + (o + g * col4B)) + lo);
         return t;
     };
     auto store_tile = [&](int ti, int tj, const v4f64 &t)
     {
         const unsigned o = tile_off(ti, tj);
+        const unsigned lo = dg_lane_offset(cf);
 #pragma unroll
         for (int g = 0; g < 4; g++)
-            gd(o + g * col4B, cf) = t[g];
+            *(gp_gptr)(dg_scalar_base(Dg + (o + g * col4B)) + lo) = t[g];
     };
     // MFMA operand fragments of k-quarter q from the images: of the panel for tile row ti, of the strip for tile column tj
     auto panel_frag = [&](int q, int ti) -> double
@@ -562,8 +568,16 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     {                                                                                                                                        \
         if (tu[s])                                                                                                                           \
         {                                                                                                                                    \
+            /* (one address per operand tile, the k-quarters by immediate offsets) */                                                        \
+            const unsigned pa_ = fresh(frag_lane) + (unsigned)ti[s] * 128u, sb_ = fresh(frag_lane) + (unsigned)tj[s] * 128u;                 \
+            double fa_[4], fb_[4];                                                                                                           \
             _Pragma("unroll") for (int qq = 0; qq < 4; qq++)                                                                                 \
-                t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(strip_frag(qq, tj[s]), panel_frag(qq, ti[s]), t[s], 0, 0, DG_NEG_A);             \
+            {                                                                                                                                \
+                fa_[qq] = *(gp_lptr)(unsigned long long)(pa_ + (unsigned)qq * (4u * (unsigned)ldp * 8u));                                    \
+                fb_[qq] = *(gp_lptr)(unsigned long long)(sb_ + (SM_OFF + (unsigned)qq * (4u * (unsigned)ldp * 8u)));                         \
+            }                                                                                                                                \
+            _Pragma("unroll") for (int qq = 0; qq < 4; qq++)                                                                                 \
+                t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb_[qq], fa_[qq], t[s], 0, 0, DG_NEG_A);                                         \
         }                                                                                                                                    \
         if (tj[s] == k)                                                                                                                      \
         {                                                                                                                                    \
@@ -595,17 +609,19 @@ __global__ __launch_bounds__(GP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 {
                     // (fragments: the strip's once per quarter, the panel's one tile row ahead of the matrix cores -- few registers
                     //  beside the 192 the resident tiles take)
+                    // (addresses: one register per image for the whole kernel + compile-time offsets -- the tile indices of a wavefront
+                    //  are constants minus its grid coordinates -- so these reads cost no vector instruction)
                     double b[RC];
 #pragma unroll
                     for (int ci = 0; ci < RC; ci++)
-                        b[ci] = strip_frag(q, col_of(ci));
-                    double a_cur = panel_frag(q, row_of(0));
+                        b[ci] = *(gp_lptr)(unsigned long long)(strip_base + (unsigned)((NT - 1 - 3 * ci) * 128 + q * (4 * ldp * 8)));
+                    double a_cur = *(gp_lptr)(unsigned long long)(panel_base + (unsigned)((NT - 1) * 128 + q * (4 * ldp * 8)));
 #pragma unroll
                     for (int ri = 0; ri < RR; ri++)
                     {
                         double a_nxt = a_cur;
                         if (ri + 1 < RR)
-                            a_nxt = panel_frag(q, row_of(ri + 1));
+                            a_nxt = *(gp_lptr)(unsigned long long)(panel_base + (unsigned)((NT - 1 - 2 * (ri + 1)) * 128 + q * (4 * ldp * 8)));
                         if ((rowlive >> ri) & 1u)
                         {
 #pragma unroll
