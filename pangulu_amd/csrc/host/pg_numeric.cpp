@@ -139,6 +139,15 @@ struct Sched
     std::vector<task_t> batch, ssssm_batch, combined;
     size_t lookahead_max_getrf = 32;  // PANGULU_AMD_LOOKAHEAD_MAX_GETRF (0 disables; 128 until round 3's sweep on replayed runs: fem27(112) 836.1 / 845.0 / 902.9 ms at 32 / 128 / 1024)
     bool panel_lookahead_on = true;   // PANGULU_AMD_PANEL_LOOKAHEAD (0 disables)
+    // Round 5: a look-ahead call used to take EVERY queued update.  A destination tile is read and written once per launch it is part of
+    // whatever the depth of its queue, and a work item's fixed cost is 20-48 % of its life: on elastic3d(77) the queues
+    // were two deep on average.  Now a destination waits until MIN_QUEUE updates are queued on it -- or until everything it will ever
+    // receive is (queue_is_complete) --, provided there is enough queued work for the device anyway (DEFER_FROM updates in all).
+    // elastic3d(77): 1 596 -> 1 543 ms, update class 1 545 -> 1 436 ms (profiles/r05a{h,i,j,k}_*: 2 / 3 / 4 / 5 / 6 / 8 / 16 = 1 564 / 1 543 /
+    // 1 548 / 1 552 / 1 555 / 1 564 / 1 572 ms; everything deferred to the destination's own panel task: 1 633).
+    size_t lookahead_min_queue = 3;     // PANGULU_AMD_LOOKAHEAD_MIN_QUEUE (1: round 4's behaviour)
+    size_t lookahead_defer_from = 8192; // PANGULU_AMD_LOOKAHEAD_DEFER_FROM
+    size_t lookahead_min_tasks = 0;     // PANGULU_AMD_LOOKAHEAD_MIN_TASKS: a floor on the size of a look-ahead call with deferral (measured: no gain)
     bool panel_first_on = true;       // PANGULU_AMD_PANEL_FIRST (0: panel-tile updates inside the look-ahead call, round 2's order)
     // multi-rank batching patience (PANGULU_AMD_GATHER_MIN_BATCH / _MAX_US / _QUIET_US)
     size_t gather_min_batch = 256;
@@ -215,6 +224,12 @@ struct Sched
             lookahead_max_getrf = (size_t)atol(e);
         if (const char *e = getenv("PANGULU_AMD_PANEL_LOOKAHEAD"))
             panel_lookahead_on = atoi(e) != 0;
+        if (const char *e = getenv("PANGULU_AMD_LOOKAHEAD_MIN_QUEUE"))
+            lookahead_min_queue = (size_t)std::max(1L, atol(e));
+        if (const char *e = getenv("PANGULU_AMD_LOOKAHEAD_DEFER_FROM"))
+            lookahead_defer_from = (size_t)std::max(0L, atol(e));
+        if (const char *e = getenv("PANGULU_AMD_LOOKAHEAD_MIN_TASKS"))
+            lookahead_min_tasks = (size_t)std::max(0L, atol(e));
         if (const char *e = getenv("PANGULU_AMD_PANEL_FIRST"))
             panel_first_on = atoi(e) != 0;
         if (const char *e = getenv("PANGULU_AMD_GATHER_MIN_BATCH"))
@@ -339,7 +354,15 @@ struct Sched
         u32 ti = tile_index(dst);
         auto &q = S.pending[ti];
         if (q.empty())
+        {
             S.pending_dirty.push_back(ti);
+            if (lookahead_min_queue > 1)
+            {
+                if (pending_bidx.size() < S.pending.size())
+                    pending_bidx.resize(S.pending.size(), ~0ull);
+                pending_bidx[ti] = dst_bidx;
+            }
+        }
         q.push_back(t);
         S.pending_total++;
 
@@ -691,6 +714,18 @@ struct Sched
         }
     }
 
+    // every update the destination will ever receive is in its queue (only its own panel task is left on its counter): waiting longer
+    // cannot make the queue any deeper
+    std::vector<u64> pending_bidx; // destination block of a tile's queue (~0: a diagonal block, counted per block row)
+    bool queue_is_complete(u32 tile) const
+    {
+        const auto &q = S.pending[tile];
+        if (q.empty() || tile >= pending_bidx.size())
+            return false;
+        const u64 b = pending_bidx[tile];
+        return b == ~0ull ? S.remain_diag[q.front().row] <= 1 : S.remain[b] <= 1;
+    }
+
     // move the queued updates of the given tiles into ssssm_batch (grouped by tile, queue order kept)
     void take_pending(u32 tile)
     {
@@ -814,9 +849,36 @@ struct Sched
                 std::lock_guard<std::mutex> g(S.info_mutex);
                 if (lookahead)
                 {
-                    for (u32 tile : S.pending_dirty)
-                        take_pending(tile);
-                    S.pending_dirty.clear();
+                    if (lookahead_min_queue <= 1 || S.pending_total < lookahead_defer_from)
+                    {
+                        for (u32 tile : S.pending_dirty)
+                            take_pending(tile);
+                        S.pending_dirty.clear();
+                    }
+                    else
+                    {
+                        // shallow queues wait: a destination tile is read and written once per launch it is part of, whatever the
+                        // number of updates in its queue (its own panel task takes whatever is left, flush (1) above)
+                        size_t w = 0;
+                        for (size_t i = 0; i < S.pending_dirty.size(); i++)
+                        {
+                            const u32 tile = S.pending_dirty[i];
+                            if (S.pending[tile].size() >= lookahead_min_queue || queue_is_complete(tile))
+                                take_pending(tile);
+                            else if (!S.pending[tile].empty())
+                                S.pending_dirty[w++] = tile;
+                        }
+                        S.pending_dirty.resize(w);
+                        // ... unless the call would then be too small to keep the device busy beside the factorisations and the
+                        // solves that follow them: shallow queues after all, oldest first, up to lookahead_min_tasks updates
+                        if (ssssm_batch.size() < lookahead_min_tasks)
+                        {
+                            size_t i = 0;
+                            for (; i < S.pending_dirty.size() && ssssm_batch.size() < lookahead_min_tasks; i++)
+                                take_pending(S.pending_dirty[i]);
+                            S.pending_dirty.erase(S.pending_dirty.begin(), S.pending_dirty.begin() + (long)i);
+                        }
+                    }
                 }
                 else
                     for_panel_tiles([&](u32 tile)
