@@ -34,6 +34,13 @@ SWITCHES = [
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64"},
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64", "_matrix": "fem27"},  # (long queues cut by launch chunks)
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_SMALL_LAUNCH_TASKS": "0", "_matrix": "fem27"},
+    # round 5: look-ahead calls leave shallow update queues alone -- by default only from 8 192 queued updates on, forced here
+    {"PANGULU_AMD_LOOKAHEAD_DEFER_FROM": "0"},
+    {"PANGULU_AMD_LOOKAHEAD_DEFER_FROM": "0", "_matrix": "fem27"},
+    {"PANGULU_AMD_LOOKAHEAD_DEFER_FROM": "0", "PANGULU_AMD_LOOKAHEAD_MIN_QUEUE": "8", "_matrix": "fem27"},
+    {"PANGULU_AMD_LOOKAHEAD_DEFER_FROM": "0", "PANGULU_AMD_LOOKAHEAD_MIN_QUEUE": "1000", "PANGULU_HIP_LAUNCH_CHUNK": "8"},
+    {"PANGULU_AMD_LOOKAHEAD_DEFER_FROM": "0", "PANGULU_AMD_LOOKAHEAD_MIN_TASKS": "512", "_matrix": "fem27"},
+    {"PANGULU_AMD_LOOKAHEAD_MIN_QUEUE": "1"},  # round 4's behaviour
     {"PANGULU_AMD_PANEL_FIRST": "0", "PG_TEST_HIP_OPTIONS": "14=0"},  # round 2's look-ahead: no background stream
     {"PANGULU_AMD_PANEL_FIRST": "0"},
     {"PANGULU_AMD_REPLAY": "0"},               # the scheduler in the loop (no static schedule)
@@ -116,6 +123,8 @@ SWEEP_SPACE = [
     (15, ["0", "3"]),        # dense-front kernel: off / three stages
     (16, ["0", "1", "2", "3", "5"]),  # general update kernel: round 2's, the LDS-DMA ones, tilesv, the pieces kernel
     ("PANGULU_HIP_GETRF_PIPE", ["0"]),  # (appended: the draws before this entry keep their settings for the options above)
+    ("PANGULU_AMD_LOOKAHEAD_DEFER_FROM", ["0"]),
+    ("PANGULU_AMD_LOOKAHEAD_MIN_QUEUE", ["1", "2", "8", "1000"]),
 ]
 
 

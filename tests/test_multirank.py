@@ -146,6 +146,19 @@ def test_multirank_matches_single_rank(tmp_path, world, spec, nb):
         assert float(z["residual"]) < 4e-16  # the reference printed 1.4e-16 at 2 and 4 ranks, nb=4
 
 
+@pytest.mark.parametrize("min_queue", ["3", "1000"])
+@pytest.mark.parametrize("world,spec,nb", [(2, "fem27_6", 32), (4, "shell_20x16", 24), (4, "fem27_9", 16), (3, "shell_8x7", 24)])
+def test_deferred_update_queues_at_several_ranks(tmp_path, world, spec, nb, min_queue):
+    """Round 5: a look-ahead call leaves destinations with fewer than MIN_QUEUE queued updates alone (pg_numeric.cpp).  The default
+    only does so from 8 192 queued updates on, which no test matrix reaches: forced here from the first update on, with the default
+    depth and with one no queue ever reaches (everything then waits for its destination's panel task, an idle rank, or a full
+    receive pool).  Operands received from other ranks live longer that way; the factors must not change."""
+    out = str(tmp_path / "out.npz")
+    run_ranks(world, spec, nb, out, extra_env={"PANGULU_AMD_LOOKAHEAD_DEFER_FROM": "0", "PANGULU_AMD_LOOKAHEAD_MIN_QUEUE": min_queue})
+    z = check_against_single_rank(out, spec, nb, "r64")
+    assert all(t > 0 for t in z["tasks"])
+
+
 @pytest.mark.parametrize("separators", ["path", "rank0"])
 @pytest.mark.parametrize("world,spec,nb", [(2, "shell_20x16", 24), (4, "shell_40x40", 32), (3, "fem27_9", 16), (4, "kkt6", 16)])
 def test_separator_maps(tmp_path, world, spec, nb, separators):
@@ -230,6 +243,21 @@ def test_two_by_four_block_cyclic_grid_on_the_gpu(tmp_path, world, spec, nb, vty
     run_ranks(world, spec, nb, out, vtype=vtype, platform="hip", transport=transport, separators=None,
               extra_env={"PANGULU_AMD_SUBTREE_MAP": "0"})
     check_against_single_rank(out, spec, nb, vtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,spec,nb,transport,min_queue,replay", [(4, "shell_40x40", 256, "ipc", "3", "0"), (2, "fem27_9", 128, "host", "1000", "0"),
+                                                                      (4, "shell_40x40", 256, "ipc", "1000", "1"), (8, "fem27_9", 128, "ipc", "3", "1")])
+def test_deferred_update_queues_at_several_ranks_on_the_gpu(tmp_path, world, spec, nb, transport, min_queue, replay):
+    """The deferral of shallow update queues (see test_deferred_update_queues_at_several_ranks) on the HIP back-end, ranks sharing the
+    GPU, with the scheduler in the loop and with every rank replaying its own log (second factorisation, receive slots poisoned)."""
+    out = str(tmp_path / "out.npz")
+    env = {"PANGULU_AMD_LOOKAHEAD_DEFER_FROM": "0", "PANGULU_AMD_LOOKAHEAD_MIN_QUEUE": min_queue, "PANGULU_AMD_MULTI_REPLAY": replay}
+    if replay == "1":
+        env.update({"PANGULU_TEST_REPEATS": "2", "PANGULU_AMD_POISON_RECV": "1"})
+    run_ranks(world, spec, nb, out, platform="hip", transport=transport, repeat=replay == "1", extra_env=env)
+    z = check_against_single_rank(out, spec, nb, "r64")
+    assert all(t > 0 for t in z["tasks"])
 
 
 @pytest.mark.gpu
