@@ -4,6 +4,13 @@
 
 // ---- TSTRF / GESSM -----------------------------------------------------------------------------------------------
 // complex types: TSTRF / GESSM on the matrix cores (ztrsm_direct_kernel; PANGULU_HIP_ZTRSM_DIRECT=0: the vector-unit kernel)
+// round 5's kernel (pg_hip_trsm_ring.h) for the TSTRF tasks of a dense-solve launch; PANGULU_HIP_TRSM_RING=0 keeps the direct kernel
+inline bool trsm_ring_selected()
+{
+    static const bool on = !(getenv("PANGULU_HIP_TRSM_RING") && atoi(getenv("PANGULU_HIP_TRSM_RING")) == 0);
+    return on;
+}
+
 inline bool ztrsm_direct_selected()
 {
     static const bool on = !(getenv("PANGULU_HIP_ZTRSM_DIRECT") && atoi(getenv("PANGULU_HIP_ZTRSM_DIRECT")) == 0);
@@ -318,6 +325,23 @@ void launch_trsm(int nb, task_t **list, size_t n)
                 }
                 else if (!nw)
                     ;
+                else if (direct && trsm_ring_selected())
+                {
+                    // round 5: TSTRF tasks with their factor tiles requested ahead through a ring in LDS, GESSM tasks on the direct
+                    // body (pg_hip_trsm_ring.h); PANGULU_HIP_TRSM_RING=0 goes back to the direct kernel for both
+                    static size_t r_allowed = 0;
+                    const size_t lds_r = tr_lds_bytes(256);
+                    if (r_allowed < lds_r)
+                    {
+                        HIP_CHECK(hipFuncSetAttribute((const void *)trsm_dense_ring_f64_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+                        HIP_CHECK(hipFuncSetAttribute((const void *)trsm_dense_ring_f64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+                        r_allowed = lds_r;
+                    }
+                    if (nb == 256)
+                        PG_LAUNCH(trsm_dense_ring_f64_kernel<16>, dim3((unsigned)nw), dim3(256), tr_lds_bytes(nb), ds, d_dtasks, d_dwork);
+                    else
+                        PG_LAUNCH(trsm_dense_ring_f64_kernel<8>, dim3((unsigned)nw), dim3(256), tr_lds_bytes(nb), ds, d_dtasks, d_dwork);
+                }
                 else if (direct && nb == 256)
                     PG_LAUNCH(trsm_dense_direct_f64_kernel<16>, dim3((unsigned)nw), dim3(256), 0, ds, d_dtasks, d_dwork);
                 else if (direct)

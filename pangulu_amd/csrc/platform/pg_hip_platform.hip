@@ -520,6 +520,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #endif
 #if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
 #include "pg_hip_trsm_dense.h"
+#include "pg_hip_trsm_ring.h"
 #endif
 #if defined(PG_COMPLEX_PANELS)
 #include "pg_hip_panels_complex.h"

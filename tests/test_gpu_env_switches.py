@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
     {},  # defaults
     {"PANGULU_HIP_TRSM_DIRECT": "0"},          # LDS-staged dense solves
+    {"PANGULU_HIP_TRSM_RING": "0"},            # round 4's barrier-free dense solves for TSTRF too (default: factor tiles requested ahead through LDS)
+    {"PANGULU_HIP_TRSM_RING": "0", "_matrix": "fem27"},
     {"PANGULU_HIP_GETRF_PIPE": "0"},           # round 4's tiled GETRF (trailing tiles through L2) instead of the register-resident one
     {"PANGULU_HIP_GETRF_PIPE": "0", "_matrix": "fem27"},
     {"PANGULU_HIP_GETRF_TILED": "0"},          # round-1 GETRF with look-ahead inside the block
@@ -125,6 +127,7 @@ SWEEP_SPACE = [
     ("PANGULU_HIP_GETRF_PIPE", ["0"]),  # (appended: the draws before this entry keep their settings for the options above)
     ("PANGULU_AMD_LOOKAHEAD_DEFER_FROM", ["0"]),
     ("PANGULU_AMD_LOOKAHEAD_MIN_QUEUE", ["1", "2", "8", "1000"]),
+    ("PANGULU_HIP_TRSM_RING", ["0"]),
 ]
 
 

@@ -1,14 +1,14 @@
 #!/bin/bash
-# round 5: lone dense panel solves against the depth of the factor-tile queue (tools/microbench/bench_trsm.hip, -DTRSM_SETS)
+# round 5: dense solves, ring kernel (factor tiles requested ahead through LDS) against the direct kernel (tools/microbench/bench_trsm.hip)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
-OUT=gpurun_out/${TAG:-r05q}_trsm_sets.log
+OUT=gpurun_out/${TAG:-r05q}_trsm_ring.log
 : > $OUT
-for s in 2 3 4 5; do
-  for args in "1 1 1" "1 0 1" "4 1 1" "64 1 4" "1024 1 64"; do
-    echo "== sets $s args $args" | tee -a $OUT
-    timeout 60 tools/microbench/bench_trsm_s$s.bin $args 2>&1 | tail -1 | tee -a $OUT
+for args in "1 1 1" "1 0 1" "4 1 1" "64 1 4" "64 0 4" "1024 1 64" "1024 0 64"; do
+  for mode in 1 2; do
+    echo "== kernel $mode (1 direct, 2 ring) args $args" | tee -a $OUT
+    timeout 60 tools/microbench/bench_trsm.bin $args $mode 2>&1 | grep -E "check|tasks" | sed -n '1p;$p' | tee -a $OUT
   done
 done

@@ -1,6 +1,8 @@
 // Stand-alone timing of trsm_dense_f64_kernel (pg_hip_trsm_dense.h)
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -37,6 +39,7 @@ __device__ inline unsigned dg_lane_offset(unsigned v)
     return v;
 }
 #include "../../pangulu_amd/csrc/platform/pg_hip_trsm_dense.h"
+#include "../../pangulu_amd/csrc/platform/pg_hip_trsm_ring.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 int main(int argc, char **argv)
 {
@@ -57,12 +60,31 @@ int main(int argc, char **argv)
     std::vector<u32> W((size_t)ntask * (nb / 64)); // work list: every (task, slab)
     for (size_t i = 0; i < W.size(); i++) W[i] = (u32)((i / (nb / 64)) << 2) | (u32)(i % (nb / 64));
     u32 *dW; CK(hipMalloc(&dW, sizeof(u32) * W.size())); CK(hipMemcpy(dW, W.data(), sizeof(u32) * W.size(), hipMemcpyHostToDevice));
-    int direct = argc > 4 ? atoi(argv[4]) : 1; // 1: barrier-free kernel, 0: LDS-staged
+    int direct = argc > 4 ? atoi(argv[4]) : 1; // 1: barrier-free kernel, 0: LDS-staged, 2: ring kernel (requests ahead through LDS)
+    CK(hipFuncSetAttribute((const void *)trsm_dense_ring_f64_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_lds_bytes(256)));
+    if (direct == 2)
+    {
+        // the ring kernel against the direct one on fresh copies of the same blocks
+        std::vector<double> r1((size_t)mb * ntask), r2((size_t)mb * ntask);
+        hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<16>, dim3(ntask * (nb / 64)), dim3(256), 0, 0, dT, dW);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r1.data(), pool, sizeof(double) * mb * ntask, hipMemcpyDeviceToHost));
+        for (int i = 0; i < ntask; i++) CK(hipMemcpy(pool + (size_t)i * mb, h.data(), sizeof(double) * mb, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(trsm_dense_ring_f64_kernel<16>, dim3(ntask * (nb / 64)), dim3(256), tr_lds_bytes(256), 0, dT, dW);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r2.data(), pool, sizeof(double) * mb * ntask, hipMemcpyDeviceToHost));
+        double worst = 0, big = 0;
+        for (size_t i = 0; i < r1.size(); i++) { worst = std::max(worst, std::fabs(r1[i] - r2[i])); big = std::max(big, std::fabs(r1[i])); }
+        printf("check  ring against direct (tstrf %d, %d tasks): max difference %.3e, largest entry %.3e  %s\n", tstrf, ntask, worst, big, worst <= 1e-14 * big ? "ok" : "WRONG");
+        for (int i = 0; i < ntask; i++) CK(hipMemcpy(pool + (size_t)i * mb, h.data(), sizeof(double) * mb, hipMemcpyHostToDevice));
+    }
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int rep = 0; rep < 3; rep++)
     {
         CK(hipEventRecord(a));
-        if (direct)
+        if (direct == 2)
+            hipLaunchKernelGGL(trsm_dense_ring_f64_kernel<16>, dim3(ntask * (nb / 64)), dim3(256), tr_lds_bytes(256), 0, dT, dW);
+        else if (direct)
             hipLaunchKernelGGL(trsm_dense_direct_f64_kernel<16>, dim3(ntask * (nb / 64)), dim3(256), 0, 0, dT, dW);
         else
             hipLaunchKernelGGL(trsm_dense_f64_kernel<16>, dim3(ntask * (nb / 64)), dim3(256), 0, 0, dT, nullptr, dW);
