@@ -10,6 +10,9 @@
 // wavefront-uniform branches -- live-tile tests, skipped panels -- and the compiler counts a request under a condition as not issued
 // when it places the waits; with 245 registers in use there is also no room for more than two tiles in flight.
 //
+// Measured (tools/microbench/bench_trsm.hip, results bit-identical to the direct kernel; profiles/r05a{s,t}_trsm_ring_*): TSTRF 1 / 64 /
+// 1 024 blocks of 256 x 256: 46.8 us / 0.90 / 0.63 us per block against 69.0 / 1.29 / 1.12; GESSM 56.0 / 1.00 / 0.69 against 55.0 / 1.28 / 0.74.
+//
 // Here the factor tiles of a strip travel HBM/L2 -> LDS by `global_load_lds_dwordx4` (no registers), up to TR_RING - 1 tiles ahead
 // of the matrix cores, in exactly the order the solve will use them (a scalar state machine walks the live tiles of the live
 // panels, diagonal tile last); the consumer waits with a COUNTED vmcnt for the oldest tile only.  Every wavefront has a ring of its
@@ -24,7 +27,7 @@
 
 #define TR_RING 8
 #ifndef TR_GESSM_THROUGH_RING
-#define TR_GESSM_THROUGH_RING 0 // 1: GESSM tasks through the ring as well (tools/microbench/bench_trsm.hip measures both)
+#define TR_GESSM_THROUGH_RING 1 // 0: GESSM tasks on the direct body (the first version of this kernel was slower than it on GESSM: 69 against 55 us alone)
 #endif
 #define TR_SLOT_DOUBLES 256
 
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
         return;
     if (!tstrf && !TR_GESSM_THROUGH_RING)
     {
-        // GESSM: the direct kernel's requests are contiguous along the rows of a factor tile already (64 bytes per lane quartet) and
-        // it is as fast as this one in a full launch (0.73 against 0.74 us per task of 1 024) and faster alone (55 against 69 us)
+        // (kept for measurements: with the requests of a GESSM tile laid along its columns and the operands of the next tile read
+        //  from LDS behind the current products the ring is the faster kernel for GESSM too: 0.69 against 0.74 us per task of 1 024)
         trsm_dense_direct_body<NP, false>(T, slab, wave, lane);
         return;
     }
@@ -185,16 +188,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
 
     // ---- the consumer ---------------------------------------------------------------------------------------------------------------
     const int rd_lane = tstrf ? 32 * (l4 >> 1) + 2 * l15 + (l4 & 1) : 16 * l4 + l15;
-    auto consume = [&](double(&a)[4])
+    // (the operands of the NEXT tile are read from its slot while the matrix cores work on the current one: a tile's fixed cost --
+    //  the wait, four LDS reads and their latency, the requester's scalar code -- is what bounds a lone solve, not the trip to L2)
+    double a_pf[4];
+    auto prefetch = [&]()
     {
-        tr_wait_tiles(head - tail - 1);
+        if (head == tail)
+            return; // (nothing left)
+        if (rp < NP)
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); // (steady state: TR_RING - 1 tiles requested, the oldest wanted)
+        else
+            tr_wait_tiles(head - tail - 1);
         const lptr slot = (lptr)ring + ((tail & (TR_RING - 1)) * TR_SLOT_DOUBLES + rd_lane);
 #pragma unroll
         for (int kq = 0; kq < 4; kq++)
-            a[kq] = slot[64 * kq];
+            a_pf[kq] = slot[64 * kq];
+    };
+    prefetch();
+    auto consume = [&](double(&a)[4])
+    {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the slot is free for the next request)
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++)
+            a[kq] = a_pf[kq];
         tail++;
         request_one();
+        prefetch();
     };
 #pragma unroll
     for (int p = 0; p < NP; p++)
