@@ -656,7 +656,7 @@ def gpu_worker_main(args):
             # (a launch of the MFMA update class is one launch of the general kernel plus, from 8192 dense-front workgroups on,
             #  one of the dense-front kernel: their bytes are added up per launch of the class)
             rocprof_names = {"ssssm_dense_mfma": ["ssssm_tilesv_f64_kernel", "ssssm_front_f64_kernel<2, true>"], "getrf": ["getrf_pipe_f64_kernel<16>"],
-                             "tstrf": ["trsm_dense_direct_f64_kernel<16>"], "gessm": ["trsm_dense_direct_f64_kernel<16>"],
+                             "tstrf": ["trsm_dense_ring_f64_kernel<16>"], "gessm": ["trsm_dense_ring_f64_kernel<16>"],
                              "ssssm_sparse": ["ssssm_sparse_kernel<false>"]}.get(dom)
             tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if world == 1 and rocprof_names and os.path.exists(tfile):
