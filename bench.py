@@ -803,6 +803,8 @@ def gpu_worker_main(args):
             # one rank: the first pangulu_gstrf of the handle (a warm-up step) recorded its launches, the timed steps replay the list
             "static_schedule_replayed": bool(info["replayed"]), "schedule_record_s": round(info["time_schedule_record"], 2),
             "batches_per_step": int(info["batches"]),
+            # destinations a background update call left alone because their queues were shallow (pg_numeric.cpp, round 5), in the run that scheduled
+            "deferred_queues_per_step": int(info.get("deferred_queues", 0)),
             "roofline": roofline,
             "model": model,
             "kernels": kernels,

@@ -122,6 +122,10 @@ extern "C"
         /* columns of the input that had no stored diagonal entry and got one (1e-8) by the reference's zero-diagonal rule
          * (src/pangulu_reordering.c:715-796; nested-dissection path; PANGULU_AMD_ZERO_DIAGONAL) */
         unsigned long long inserted_diagonals;
+        /* (round 5) times a look-ahead call left a destination's queued updates alone because the queue was shallower than
+         * PANGULU_AMD_LOOKAHEAD_MIN_QUEUE and not yet complete -- in the run that SCHEDULED: the last pangulu_gstrf, or the dry run
+         * at pangulu_init whose schedule it replayed */
+        unsigned long long deferred_queues;
     } pangulu_amd_info_t;
     void pangulu_amd_get_info(void **pangulu_handle, pangulu_amd_info_t *out);
     /* evaluate T* = sum_t max(bytes_t / BW, flop_t / P) over this rank's task list (structure only) */

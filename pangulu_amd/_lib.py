@@ -98,6 +98,7 @@ class Info(ctypes.Structure):
         ("model_rank_hbm_received", ctypes.c_double),
         ("model_rank_hbm_mirrors", ctypes.c_double),
         ("inserted_diagonals", ctypes.c_ulonglong),
+        ("deferred_queues", ctypes.c_ulonglong),
     ]
 
     def as_dict(self):

@@ -172,6 +172,7 @@ struct Sched
     std::deque<Retired> retired;
     double t_platform = 0, t_sched = 0;
     u64 batches = 0;
+    u64 deferred = 0; // queues a look-ahead call left alone (pangulu_amd_info_t::deferred_queues)
     bool multi;
     // Runs on a device: the platform calls (descriptor building and launches) cost about as much host time
     // as the scheduling itself, and nothing the scheduler does next depends on their return -- the back-end's streams
@@ -866,7 +867,10 @@ struct Sched
                             if (S.pending[tile].size() >= lookahead_min_queue || queue_is_complete(tile))
                                 take_pending(tile);
                             else if (!S.pending[tile].empty())
+                            {
                                 S.pending_dirty[w++] = tile;
+                                deferred++;
+                            }
                         }
                         S.pending_dirty.resize(w);
                         // ... unless the call would then be too small to keep the device busy beside the factorisations and the
@@ -1222,6 +1226,7 @@ void record_schedule(Solver &S)
         }
         sch.compute_loop();
         S.info.batches = sch.batches;
+        S.info.deferred_queues = sch.deferred;
     }
     S.schedule_recorded = plat.schedule(2, &S) > 0;
     // re-arm: nothing ran on the device, the block values are untouched
@@ -1539,6 +1544,7 @@ void numeric_factorize(Solver &S)
     // host time the scheduler itself needed: with the launcher thread, the time until the last batch was handed over
     S.info.time_numeric_host_sched = sch.async_launch ? sch.t_sched : S.info.time_numeric - sch.t_platform;
     S.info.batches = sch.batches;
+    S.info.deferred_queues = sch.deferred;
     S.info.time_numeric_platform = sch.t_platform;
     S.info.sent_bytes = comm->sent_bytes;
     S.info.recv_bytes = comm->recv_bytes_total;
