@@ -137,11 +137,13 @@ extern "C"
     /* per-rank figures of the structure-only model above: arrays of info.nproc entries (any may be NULL);
      * returns the number of ranks */
     int pangulu_amd_rank_model(void **pangulu_handle, double *tstar_seconds, double *flop, double *comm_seconds);
-    /* The structure-only model for ANY rank count on this handle (1 <= nranks <= 64), without touching the handle: out12 =
+    /* The structure-only model for ANY rank count on this handle (1 <= nranks <= 64): out12 =
      * { T*(N) incl. link term, sum_r T*_r, max link term, bytes sent, critical path at T*_t, latency-aware critical path, max / mean
      * flop share, max / mean T* share, HBM of the fullest rank, its records owned, its records received, its dense mirrors }
      * (seconds, bytes).  Local (no communication): the pattern and the weights are replicated.  Returns 0, or 1 when the model is
-     * not available (nb > 65535). */
+     * not available (nb > 65535).  The handle's state is the same after the call as before it, but DURING the call its mapping,
+     * consumer sets and model figures are those of `nranks`: not thread-safe, exclusive with every other use of the handle
+     * (pangulu_gstrf, pangulu_amd_get_info, pangulu_amd_rank_model). */
     int pangulu_amd_model_for_ranks(void **pangulu_handle, int nranks, double *out12);
 
     /* ---- repeated factorisations (bench.py) ---------------------------------------------------------- */

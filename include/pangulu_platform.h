@@ -350,7 +350,9 @@ extern "C"
      *   flops     : structural flops the kernels executed (counted on the device for the sparse kernels,
      *               2*nb^3 per task for the dense kernel)
      *   elapsed_ms: sum of launch durations from hipEvents on the back-end stream; only collected while
-     *               PANGULU_HIP_OPT_PROFILE is 1 (it adds two event records per launch)                  */
+     *               PANGULU_HIP_OPT_PROFILE is 1 (it adds two event records per launch).  One solve launch serves TSTRF and GESSM
+     *               tasks together: it counts as a launch of each class it carries tasks of, and its duration is split between
+     *               classes 2 and 3 in proportion to their algorithmic bytes (round 6; it used to go to the larger class whole) */
 #define PANGULU_HIP_STAT_CLASSES 9
     typedef struct pangulu_hip_stats_t
     {
@@ -366,6 +368,11 @@ extern "C"
         unsigned long long ssssm_front_workgroups, ssssm_general_workgroups;
         /* GETRF -> dense-solve chase: launches that carried a level's factorisations AND its dense solves, and the solves in them */
         unsigned long long chase_launches, chase_solves;
+        /* class 5 by kernel (round 6; appended, older callers' layout is a prefix): the two MFMA update kernels of a class-5 launch
+         * timed on their own while PANGULU_HIP_OPT_PROFILE is 1 ([0] dense-front kernel, [1] general kernel), and the flops the
+         * dense-front kernel's products executed (the general kernel's = mfma_flops_executed - this), counted under COUNT_FLOPS */
+        double ssssm_kernel_ms[2];
+        double ssssm_front_flops_executed;
     } pangulu_hip_stats_t;
     void pangulu_platform_0201001_get_stats(pangulu_hip_stats_t *out, int reset);
     /* Device memory the BACK-END holds for itself, in bytes (the host's records, receive bins and snapshots are the host's

@@ -121,6 +121,8 @@ class HipStats(ctypes.Structure):
         ("ssssm_general_workgroups", ctypes.c_ulonglong),
         ("chase_launches", ctypes.c_ulonglong),
         ("chase_solves", ctypes.c_ulonglong),
+        ("ssssm_kernel_ms", ctypes.c_double * 2),
+        ("ssssm_front_flops_executed", ctypes.c_double),
     ]
 
 

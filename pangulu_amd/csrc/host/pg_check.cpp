@@ -189,7 +189,7 @@ double factor_check_vectors(Solver &S, int nvec, unsigned long long seed)
             x[i] = (z >> 63) ? cone() : csub(czero(), cone());
         }
         const double q = check_one_vector(S, L, x);
-        if (!(q <= worst)) // (a NaN sticks)
+        if (std::isnan(q) || (!std::isnan(worst) && q > worst)) // a NaN on ANY vector sticks (`!(q <= worst)` let the next finite q overwrite it)
             worst = q;
     }
     return worst;

@@ -110,10 +110,17 @@ struct SocketComm : Comm
         inet_pton(AF_INET, addr, &sa.sin_addr);
         if (::bind(ls, (sockaddr *)&sa, sizeof(sa)) != 0)
             fatal("rank %d: bind to %s:%d failed: %s", rank, addr, base_port + rank, strerror(errno));
-        ::listen(ls, size);
+        ::listen(ls, 4 * size + 16);
         // connect to every lower rank, accept from every higher rank.  Both sides check a magic word: base_port + rank may
         // lie in the ephemeral range, where some other socket of the job (the launcher's rendezvous, gloo pairs) can hold
         // the number -- a connection that reached the wrong listener is dropped and retried instead of waited on forever.
+        // The handshake has THREE legs (round 6): hello ->, <- ack, confirm ->.  A rank accepts only after it has reached all of ITS lower
+        // ranks, so a peer that starts seconds later than the others (eight processes importing torch on a cold box; bench.py has no
+        // rendezvous in front of this constructor) makes everybody above it wait.  With two legs and a 3 s wait for the ack, the
+        // waiting rank gave up, closed and retried -- and left a connection in the backlog whose hello was still readable: the
+        // acceptor registered that dead socket, dropped the live retry as a duplicate, and the job ended minutes later in "peer closed
+        // the connection" / "cannot reach rank".  Now the acceptor registers a connection only when the confirm arrives (on an
+        // abandoned one it does not), and the connector waits 30 s per attempt.
         const unsigned magic = 0x50474c55u; // "PGLU"
         auto set_timeout = [](int s, int seconds)
         {
@@ -135,6 +142,7 @@ struct SocketComm : Comm
             }
             return true;
         };
+        const double t_begin = wall_seconds();
         for (int peer = 0; peer < rank; peer++)
         {
             int s = -1;
@@ -146,15 +154,17 @@ struct SocketComm : Comm
                 if (::connect(s, (sockaddr *)&pa, sizeof(pa)) == 0)
                 {
                     unsigned hello[2] = {magic, (unsigned)rank}, ack = 0;
-                    set_timeout(s, 3);
-                    if (::send(s, hello, sizeof(hello), MSG_NOSIGNAL) == (ssize_t)sizeof(hello) && read_some(s, &ack, sizeof(ack)) && ack == (magic ^ (unsigned)peer))
+                    const unsigned confirm = ~magic ^ (unsigned)rank;
+                    set_timeout(s, 30);
+                    if (::send(s, hello, sizeof(hello), MSG_NOSIGNAL) == (ssize_t)sizeof(hello) && read_some(s, &ack, sizeof(ack)) && ack == (magic ^ (unsigned)peer) &&
+                        ::send(s, &confirm, sizeof(confirm), MSG_NOSIGNAL) == (ssize_t)sizeof(confirm))
                     {
                         set_timeout(s, 0);
                         break;
                     }
                 }
                 ::close(s);
-                if (attempt > 6000)
+                if (attempt > 6000 || wall_seconds() - t_begin > 900.0)
                     fatal("rank %d: cannot reach rank %d at %s:%d", rank, peer, addr, base_port + peer);
                 usleep(10000);
             }
@@ -174,9 +184,11 @@ struct SocketComm : Comm
                 continue;
             }
             const unsigned ack = magic ^ (unsigned)rank;
-            if (::send(s, &ack, sizeof(ack), MSG_NOSIGNAL) != (ssize_t)sizeof(ack))
+            unsigned confirm = 0;
+            if (::send(s, &ack, sizeof(ack), MSG_NOSIGNAL) != (ssize_t)sizeof(ack) || !read_some(s, &confirm, sizeof(confirm)) ||
+                confirm != (~magic ^ hello[1]))
             {
-                ::close(s);
+                ::close(s); // (abandoned by its connector, which has retried or will)
                 continue;
             }
             set_timeout(s, 0);

@@ -426,7 +426,6 @@ double factor_check(Solver &S);                           // ||L(U 1) - A 1|| / 
 double factor_check_vectors(Solver &S, int nvec, unsigned long long seed); // the same on the ones vector + nvec - 1 random +-1 vectors: the worst quotient
 void compute_task_model(Solver &S, double hbm_bytes_per_s, double fp_flops_per_s); // pg_model.cpp: T* of SURVEY.md §8d
 void build_structure_model(Solver &S);   // pg_model.cpp: column counts per lower block + per-column work (before the mapping)
-void compute_rank_model(Solver &S);      // pg_model.cpp: per-rank T*, link term, critical paths, HBM per rank under the mapping
 void evaluate_model_for_ranks(Solver &S, int nranks, double *out12); // pg_model.cpp: the same figures for any rank count
 void compute_rank_model(Solver &S);      // pg_model.cpp: per-rank T*, flop shares, link term, critical path (after preprocess)
 double task_structural_flop(u32 nb, const task_t &t);

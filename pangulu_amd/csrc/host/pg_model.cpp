@@ -556,8 +556,8 @@ void compute_rank_model(Solver &S)
     // its panel task starts when the last of them is done; serial: a few operations per task), twice:
     //  * with every task at its own T*_t -- a lower bound on any schedule's makespan however many devices there are, but a useless
     //    predictor: 0.24 us per task on the chain where a lone kernel launch has a floor of tens of microseconds;
-    //  * LATENCY-AWARE: a task takes max(T*_t, the measured floor of a lone launch of its class) -- GETRF 205 us, a dense panel
-    //    solve 70 us, an update launch 25 us at nb = 256, scaled with nb / 256 for the panel classes (16 dependent panel steps per
+    //  * LATENCY-AWARE: a task takes max(T*_t, the measured floor of a lone launch of its class) -- GETRF 138 us, a dense panel
+    //    solve 47 us (round 5's kernels: getrf_pipe, trsm_dense_ring), an update launch 25 us at nb = 256, scaled with nb / 256 for the panel classes (16 dependent panel steps per
     //    256 columns; DESIGN.md, kernel table; PANGULU_AMD_MODEL_FLOOR_{GETRF,PANEL,UPDATE}_US) -- and an operand that comes from
     //    another rank arrives a hop later: PANGULU_AMD_MODEL_HOP_US (default 20: marker, announcement, start of the copy; an
     //    assumption until a run on real links calibrates it) + record bytes over one link.  This is what bounds strong scaling.
@@ -568,8 +568,8 @@ void compute_rank_model(Solver &S)
             const char *e = getenv(name);
             return 1e-6 * (e ? atof(e) : dflt);
         };
-        const float floor_getrf = (float)env_us("PANGULU_AMD_MODEL_FLOOR_GETRF_US", 205.0 * scale_nb);
-        const float floor_panel = (float)env_us("PANGULU_AMD_MODEL_FLOOR_PANEL_US", 70.0 * scale_nb);
+        const float floor_getrf = (float)env_us("PANGULU_AMD_MODEL_FLOOR_GETRF_US", 138.0 * scale_nb);
+        const float floor_panel = (float)env_us("PANGULU_AMD_MODEL_FLOOR_PANEL_US", 47.0 * scale_nb);
         const float floor_update = (float)env_us("PANGULU_AMD_MODEL_FLOOR_UPDATE_US", 25.0);
         const float hop = (float)env_us("PANGULU_AMD_MODEL_HOP_US", 20.0);
         const float inv_link = (float)(1.0 / M.link_bytes_per_s);
@@ -700,7 +700,11 @@ void evaluate_model_for_ranks(Solver &S, int nranks, double *out)
     home0.swap(S.home);
     grp0.swap(S.grp);
     cons0.swap(S.consumers);
-    const StructureModel model0 = S.smodel; // (lcount included: a copy of 51 MB for the Serena-class matrix, once per call)
+    // (the figures only: lcount -- 51 MB for the Serena-class matrix, read-only in compute_rank_model -- is parked beside the copy)
+    std::vector<u16> lcount_parked;
+    lcount_parked.swap(S.smodel.lcount);
+    const StructureModel model0 = S.smodel;
+    S.smodel.lcount.swap(lcount_parked);
     const pangulu_amd_info_t info0 = S.info;
     S.nproc = nranks;
     int p = (int)std::sqrt((double)nranks);
@@ -772,7 +776,9 @@ void evaluate_model_for_ranks(Solver &S, int nranks, double *out)
     S.home.swap(home0);
     S.grp.swap(grp0);
     S.consumers.swap(cons0);
+    lcount_parked.swap(S.smodel.lcount);
     S.smodel = model0;
+    S.smodel.lcount.swap(lcount_parked);
     S.info = info0;
 }
 

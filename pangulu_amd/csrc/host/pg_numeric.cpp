@@ -356,7 +356,15 @@ struct Sched
         auto &q = S.pending[ti];
         if (q.empty())
         {
-            S.pending_dirty.push_back(ti);
+            // one entry per tile (a deferred tile whose queue flush (1) or panel-first had emptied was pushed a second time,
+            // both entries were kept and counted while shallow, and the list grew)
+            if (in_dirty.size() < S.pending.size())
+                in_dirty.resize(S.pending.size(), 0);
+            if (!in_dirty[ti])
+            {
+                in_dirty[ti] = 1;
+                S.pending_dirty.push_back(ti);
+            }
             if (lookahead_min_queue > 1)
             {
                 if (pending_bidx.size() < S.pending.size())
@@ -717,6 +725,14 @@ struct Sched
 
     // every update the destination will ever receive is in its queue (only its own panel task is left on its counter): waiting longer
     // cannot make the queue any deeper
+    std::vector<unsigned char> in_dirty; // tile has an entry in S.pending_dirty
+    void clear_dirty_list()
+    {
+        for (u32 tile : S.pending_dirty)
+            if (tile < in_dirty.size())
+                in_dirty[tile] = 0;
+        S.pending_dirty.clear();
+    }
     std::vector<u64> pending_bidx; // destination block of a tile's queue (~0: a diagonal block, counted per block row)
     bool queue_is_complete(u32 tile) const
     {
@@ -784,6 +800,8 @@ struct Sched
         for (size_t i = 0; i < S.pending_dirty.size(); i++)
             if (!S.pending[S.pending_dirty[i]].empty())
                 S.pending_dirty[w++] = S.pending_dirty[i];
+            else
+                in_dirty[S.pending_dirty[i]] = 0;
         S.pending_dirty.resize(w);
     }
 
@@ -854,7 +872,7 @@ struct Sched
                     {
                         for (u32 tile : S.pending_dirty)
                             take_pending(tile);
-                        S.pending_dirty.clear();
+                        clear_dirty_list();
                     }
                     else
                     {
@@ -870,7 +888,9 @@ struct Sched
                             {
                                 S.pending_dirty[w++] = tile;
                                 deferred++;
+                                continue;
                             }
+                            in_dirty[tile] = 0;
                         }
                         S.pending_dirty.resize(w);
                         // ... unless the call would then be too small to keep the device busy beside the factorisations and the
@@ -879,7 +899,10 @@ struct Sched
                         {
                             size_t i = 0;
                             for (; i < S.pending_dirty.size() && ssssm_batch.size() < lookahead_min_tasks; i++)
+                            {
                                 take_pending(S.pending_dirty[i]);
+                                in_dirty[S.pending_dirty[i]] = 0;
+                            }
                             S.pending_dirty.erase(S.pending_dirty.begin(), S.pending_dirty.begin() + (long)i);
                         }
                     }
@@ -949,7 +972,7 @@ struct Sched
                 return false;
             for (u32 tile : S.pending_dirty)
                 take_pending(tile);
-            S.pending_dirty.clear();
+            clear_dirty_list();
         }
         run_updates_and_release_operands();
         return true;

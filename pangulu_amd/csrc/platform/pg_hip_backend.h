@@ -25,9 +25,13 @@ struct Ring // descriptor staging in pinned host memory that the kernels read in
 struct EventPair
 {
     hipEvent_t a, b;
-    int cls;
+    int cls;          // 100 + k: kernel k of a class-5 launch (Backend stats ssssm_kernel_ms[k]), not a class of its own
+    int split_cls;    // > 0: `split_frac` of the duration goes to this class instead (a solve launch with TSTRF and GESSM tasks)
+    double split_frac;
     unsigned long long tag[3]; // per-launch log (PANGULU_HIP_LAUNCH_LOG): workgroups, tasks, live 128 x 128 x 16 slab steps
 };
+
+#define PG_FLOP_WORDS 48 // device words behind Backend::d_flops: counters, debug stamps, the pipe GETRF's phase stamps
 
 struct Backend
 {
@@ -107,7 +111,7 @@ struct Backend
     size_t progress_next = 0;
     unsigned long long chase_launches = 0, chase_solves = 0;
     unsigned long long zgetrf_tasks = 0; // complex types: diagonal blocks factorised in their mirrors
-    unsigned long long *d_flops = nullptr; // [6]
+    unsigned long long *d_flops = nullptr; // [PG_FLOP_WORDS]
     val_t *getrf_scratch = nullptr;
     int getrf_scratch_slots = 0;
     std::unordered_map<const void *, DiagAux> diag_aux;
@@ -352,8 +356,10 @@ void ensure_ready()
         HIP_CHECK(hipEventCreateWithFlags(&B.ring.ev[i], hipEventDisableTiming));
         B.ring.used[i] = false;
     }
-    HIP_CHECK(hipMalloc((void **)&B.d_flops, sizeof(unsigned long long) * 16)); // [0..7] flop counters, [8..15] debug stamps
-    HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(unsigned long long) * 16));
+    // [0..7] flop counters, [8..15] debug stamps, [16..47] the phase stamps of getrf_pipe_f64_kernel (its slots 16..20 and 24..29 count from
+    // d_flops + 8: ADVICE r5 found them 22 words past a 16-word allocation)
+    HIP_CHECK(hipMalloc((void **)&B.d_flops, sizeof(unsigned long long) * PG_FLOP_WORDS));
+    HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(unsigned long long) * PG_FLOP_WORDS));
     memset(&B.stats, 0, sizeof(B.stats));
     B.ready = true;
 }
@@ -512,6 +518,8 @@ struct LaunchTimer
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
     unsigned long long tag[3] = {0, 0, 0};
+    int split_cls = 0;
+    double split_frac = 0.0;
     explicit LaunchTimer(int c, hipStream_t stream = nullptr) : cls(c), st(stream ? stream : B.stream)
     {
         if (B.opt_profile)
@@ -526,7 +534,7 @@ struct LaunchTimer
         if (B.opt_profile)
         {
             HIP_CHECK(hipEventRecord(b, st));
-            B.pending_events.push_back(EventPair{a, b, cls, {tag[0], tag[1], tag[2]}});
+            B.pending_events.push_back(EventPair{a, b, cls, split_cls, split_frac, {tag[0], tag[1], tag[2]}});
         }
     }
 };
@@ -541,7 +549,21 @@ void harvest_events()
         HIP_CHECK(hipEventSynchronize(p.b));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
-        B.stats.elapsed_ms[p.cls] += ms;
+        if (p.cls >= 100)
+        {
+            if (p.cls - 100 < 2)
+                B.stats.ssssm_kernel_ms[p.cls - 100] += ms;
+            B.event_pool.push_back(p.a);
+            B.event_pool.push_back(p.b);
+            continue;
+        }
+        if (p.split_cls > 0)
+        {
+            B.stats.elapsed_ms[p.split_cls] += ms * p.split_frac;
+            B.stats.elapsed_ms[p.cls] += ms * (1.0 - p.split_frac);
+        }
+        else
+            B.stats.elapsed_ms[p.cls] += ms;
         if (launch_log)
             fprintf(launch_log, "%d %.2f %llu %llu %llu\n", p.cls, 1e3 * ms, p.tag[0], p.tag[1], p.tag[2]);
         B.event_pool.push_back(p.a);

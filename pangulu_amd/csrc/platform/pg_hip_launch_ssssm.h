@@ -449,6 +449,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 B.general_workgroups += nw - nfm;
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 unsigned long long *pc = B.opt_count_flops ? B.d_flops + 6 : nullptr;
+                unsigned long long *pc_front = B.opt_count_flops ? B.d_flops + 7 : nullptr; // (the dense-front kernel's products on their own)
                 // PANGULU_HIP_FRONT_FORK=1 (off by default, see Backend::opt_front_fork): the two launches of a call on two streams, so that workgroups of both are resident at once
                 // (one bound by the matrix pipes, the other by its per-step latencies) instead of one launch behind the other's tail.
                 const bool fork_front = nf && nw && B.opt_front_fork && !B.opt_profile;
@@ -462,16 +463,18 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 if (nf)
                 {
                     // the longest-running workgroups first: the front launch, then the general one fills in behind it
+                    LaunchTimer lk(100, fs);
                     const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_front_unit);
                     if (B.opt_front_stages >= 4)
-                        PG_LAUNCH((ssssm_front_f64_kernel<4, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<4, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc_front, unit);
                     else if (B.opt_front_stages == 3)
-                        PG_LAUNCH((ssssm_front_f64_kernel<3, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<3, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc_front, unit);
                     else
-                        PG_LAUNCH((ssssm_front_f64_kernel<2, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc, unit);
+                        PG_LAUNCH((ssssm_front_f64_kernel<2, true>), dim3((unsigned)nf), dim3(FR_THREADS), 0, fs, d_tasks_d, nb, d_work_f, pc_front, unit);
                 }
                 if (fork_front)
                     pg_event_record(B.ev_front_join, fs);
+                LaunchTimer lk_general(nw ? 101 : 102, ds); // (102: no general launch in this call -- an empty pair, dropped at harvest)
                 if (nw && B.opt_tiles_stages >= 2)
                 {
                     // round 3: LDS-DMA pipeline, strided piece ownership (pg_hip_front.h)

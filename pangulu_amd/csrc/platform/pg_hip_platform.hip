@@ -1884,7 +1884,7 @@ extern "C"
         join_background(B.stream);
         HIP_CHECK(hipStreamSynchronize(B.stream));
         harvest_events();
-        unsigned long long f[16];
+        unsigned long long f[PG_FLOP_WORDS];
         HIP_CHECK(hipMemcpy(f, B.d_flops, sizeof(f), hipMemcpyDeviceToHost));
         if (getenv("PANGULU_HIP_DEBUG_SSSSM"))
             fprintf(stderr, "[ssssm_dense stamps, every 64th workgroup, shader clocks] bookkeeping+first step %llu | barrier A %llu | LDS stage (waits for the slab) %llu | barrier B %llu | next step + loads issued %llu | mfma %llu | C update %llu | slab steps %llu, empty workgroups %llu\n",
@@ -1895,9 +1895,13 @@ extern "C"
         if (getenv("PANGULU_HIP_DEBUG_GETRF"))
             fprintf(stderr, "[getrf stamps, block 0, shader clocks; tiled kernel: 1 = diag+priority tiles, 2 = trailing passes, 3 = wait for LU, 4 = substitution (wavefront 0), lu = tile LU (wavefront 7)] prologue %llu | 1 %llu | 2 %llu | 3 %llu | 4 %llu | loop %llu | gather %llu | lu %llu\n",
                     f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15]);
+        if (getenv("PANGULU_HIP_DEBUG_GETRF"))
+            fprintf(stderr, "[getrf_pipe stamps, block 0, shader clocks; factorisation wavefront: wait A %llu | tile LU %llu | inverses %llu | wait B %llu | wait C %llu; trailing wavefront 1: update %llu | wait B %llu | panel+strip %llu | wait C %llu | hand-over %llu | wait A %llu]\n",
+                    f[8 + 16], f[8 + 17], f[8 + 18], f[8 + 19], f[8 + 20], f[8 + 24], f[8 + 25], f[8 + 26], f[8 + 27], f[8 + 28], f[8 + 29]);
         for (int c = 1; c <= 5; c++)
             B.stats.flops[c] = (double)f[c];
-        B.stats.mfma_flops_executed = 8192.0 * (double)f[6]; // 16 x 16 x 16 products counted by the MFMA update kernels
+        B.stats.mfma_flops_executed = 8192.0 * (double)(f[6] + f[7]); // 16 x 16 x 16 products counted by the MFMA update kernels
+        B.stats.ssssm_front_flops_executed = 8192.0 * (double)f[7];    // ... the dense-front kernel's share
         B.stats.ssssm_front_workgroups = B.front_workgroups;
         B.stats.ssssm_general_workgroups = B.general_workgroups;
         B.stats.chase_launches = B.chase_launches;

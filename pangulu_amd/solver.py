@@ -242,6 +242,10 @@ def hip_stats(h_or_lib, reset=False):
     out["tstrf"]["dense_path_tasks"] = int(st.trsm_dense_tasks)  # TSTRF + GESSM tasks solved on the matrix cores
     out["ssssm_dense_mfma"]["front_workgroups"] = int(st.ssssm_front_workgroups)      # dense-front kernel (pg_hip_front.h)
     out["ssssm_dense_mfma"]["general_workgroups"] = int(st.ssssm_general_workgroups)  # general MFMA kernel (pg_hip_dense.h)
+    # class 5 by kernel: time of each kernel's launches (PROFILE on) and the flops its 16 x 16 x 16 products executed (COUNT_FLOPS on)
+    out["ssssm_dense_mfma"]["front_kernel_ms"] = float(st.ssssm_kernel_ms[0])
+    out["ssssm_dense_mfma"]["general_kernel_ms"] = float(st.ssssm_kernel_ms[1])
+    out["ssssm_dense_mfma"]["front_flops_executed"] = float(st.ssssm_front_flops_executed)
     out["getrf"]["chase_launches"] = int(st.chase_launches)  # launches that carried a level's factorisations and its dense solves
     out["tstrf"]["chase_solves"] = int(st.chase_solves)
     return out

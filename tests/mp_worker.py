@@ -4,8 +4,12 @@ Rendezvous and result gathering use torch.distributed with the gloo backend; the
 (pangulu_amd_comm_init: TCP control plane + host-staged block records) is what is under test.  The numeric kernels
 are the oracle's CPU platform -- this checks the distributed scheduler, not the GPU.
 """
+import faulthandler
 import os
 import sys
+import time
+
+faulthandler.enable()  # a rank that dies on a signal says where (round 5 lost a rank of an 8-process case without a line of output)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,8 +23,18 @@ from pangulu_amd import matrices as M  # noqa: E402
 from tests.helpers import oracle_library  # noqa: E402
 
 
+_T0 = time.time()
+
+
+def stage(what):
+    """One line per stage on stderr (shown by the harness only when a rank fails): the last one printed is where the rank was."""
+    sys.stderr.write("[mp_worker rank %s pid %d +%.2fs] %s\n" % (os.environ.get("RANK"), os.getpid(), time.time() - _T0, what))
+    sys.stderr.flush()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    stage("imports done")
     spec, nb, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     vtype = sys.argv[4] if len(sys.argv) > 4 else "r64"
     platform = sys.argv[5] if len(sys.argv) > 5 else "oracle"
@@ -34,7 +48,9 @@ def main():
     # gloo's pair sockets live (a number taken by one of those would be dialled by mistake)
     base_port = 20000 + (int(os.environ["MASTER_PORT"]) * 7) % 8000
     transport = {"host": _lib.TRANSPORT_HOST, "ipc": _lib.TRANSPORT_IPC, "rccl": _lib.TRANSPORT_RCCL}[os.environ.get("PANGULU_TEST_TRANSPORT", "host")]
+    stage("library loaded, gloo up")
     assert lib.pangulu_amd_comm_init(rank, world, b"127.0.0.1", base_port, transport, None) == 0
+    stage("comm_init done")
     dtype = _lib.VALUE_TYPES[vtype][0]
     gen = {"fem27_6": lambda: M.fem27(6, dtype=dtype), "poisson8": lambda: M.poisson3d(8, dtype=dtype),
            "shell_8x7": lambda: M.shell(8, 7, dtype=dtype), "trefethen": lambda: M.trefethen(dtype=dtype),
@@ -49,6 +65,7 @@ def main():
         h = pa.pangulu_init(n, len(va), cp, ri, va, nb=nb, vtype=vtype, ordering=ordering, coords=co if ordering == "nd" else None, lib=lib)
     else:
         h = pa.pangulu_init(0, 0, None, None, None, nb=nb, vtype=vtype, ordering=ordering, lib=lib)  # rank 0 broadcasts the matrix
+    stage("pangulu_init done")
     repeat = os.environ.get("PANGULU_TEST_REPEAT") == "1"
     if repeat:  # bench.py's sequence: snapshot, gstrf, reset_numeric, gstrf again
         assert lib.pangulu_amd_snapshot(h.ref) == 0
@@ -63,6 +80,7 @@ def main():
             replayed.append(int(h.info()["replayed"]))
             L2, U2 = pa.factors_as_scipy(h)
             assert abs(L1 - L2).max() <= 1e-12 * scale and abs(U1 - U2).max() <= 1e-12 * scale, "factorisation %d differs" % (again + 2)
+    stage("gstrf done")
     info = h.info()
     info["replayed_flags"] = replayed
     L, U = pa.factors_as_scipy(h)  # this rank's blocks only
@@ -82,10 +100,12 @@ def main():
                  flop=parts[0][2]["flop"], sent=[p[2]["sent_bytes"] for p in parts], recv=[p[2]["recv_bytes"] for p in parts],
                  recv_blocks=[p[2]["recv_blocks"] for p in parts], tasks=[p[2]["ntask_ssssm"] for p in parts],
                  transport=int(lib.pangulu_amd_comm_transport()), replayed=[p[2]["replayed_flags"] for p in parts])
+    stage("results gathered")
     pa.pangulu_finalize(h)
     lib.pangulu_amd_comm_finalize()
     dist.barrier()
     dist.destroy_process_group()
+    stage("end")
 
 
 if __name__ == "__main__":

@@ -62,6 +62,13 @@ def main():
             ("%.1f (%.3g MFMA f64 16x16x4)" % (mfma, c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) / 4)) if c.get("GRBM_GUI_ACTIVE") else "n/a"))
         summary[name] = {"calls": calls, "avg_us": float(r["AverageNs"]) / 1e3, "hbm_bytes_per_launch": fetch + write,
                          "fetch_bytes_per_launch_x2": fetch, "write_bytes_per_launch": write}
+        if c.get("GRBM_GUI_ACTIVE"):
+            # (bench.py's roofline.per_kernel quotes these two beside the per-launch bytes)
+            summary[name]["mfma_busy_pct"] = mfma
+            summary[name]["mfma_f64_16x16x4_per_launch"] = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) / 4 / n.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 1)
+        if wc:
+            summary[name]["waiting_pct_of_wave_cycles"] = wait
+            summary[name]["issue_stalled_pct"] = stall
     if out_json:
         # bench.py quotes these per-launch HBM bytes only for the build they were measured on
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
