@@ -66,8 +66,10 @@ profile)
     ;;
 micro)
     SRC=$1; shift
-    BIN=/tmp/$(basename "$SRC" .hip).bin
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics ${MICRO_FLAGS:-} -I pangulu_amd/csrc/platform -I include tools/microbench/$SRC -o $BIN 2>&1 | tail -5
+    BIN=/tmp/$(basename "$SRC" .hip)_$(echo "${MICRO_FLAGS:-}" | md5sum | cut -c1-8).bin
+    if [ ! -x $BIN ]; then  # (one build per source and flag set on a box: several runs of one call share it)
+        /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics ${MICRO_FLAGS:-} -I pangulu_amd/csrc/platform -I include tools/microbench/$SRC -o $BIN 2>&1 | tail -5
+    fi
     timeout ${MICRO_TIMEOUT:-300} $BIN "$@" > gpurun_out/${TAG}_micro.log 2>&1
     echo "[gpu_job micro] rc=$?"; tail -40 gpurun_out/${TAG}_micro.log
     ;;

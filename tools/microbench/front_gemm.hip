@@ -49,6 +49,7 @@ __device__ unsigned long long g_item[16];
 #include "../../pangulu_amd/csrc/platform/pg_hip_dense.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_front.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_pieces.h"
+#include "../../pangulu_amd/csrc/platform/pg_hip_stream.h"
 #include "../experiments/front_k32.h"
 #include "../experiments/front_n64.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -64,6 +65,10 @@ struct Problem
     SsssmTaskD *dT = nullptr;
     SsssmWorkD *dW = nullptr;
     size_t nwork = 0;
+    // the stream kernel (pg_hip_stream.h): work items that carry their first step slot, the builder's scratch
+    SsssmWorkD *dWs = nullptr;
+    SsssmItemInfoD *dInfo = nullptr;
+    SsssmStepD *dSteps = nullptr;
     double *A(int q, int i) { return d + (size_t)(q * P + i) * mb; }
     double *Bm(int q, int j) { return d + (size_t)(Q * P + q * P + j) * mb; }
     double *C(int i, int j) { return d + (size_t)(2 * Q * P + i * P + j) * mb; }
@@ -151,6 +156,13 @@ void build(Problem &X, int P, int Q, bool keep_host, int fill = 100)
     CK(hipMalloc(&X.dW, sizeof(SsssmWorkD) * W.size()));
     CK(hipMemcpy(X.dT, T.data(), sizeof(SsssmTaskD) * T.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(X.dW, W.data(), sizeof(SsssmWorkD) * W.size(), hipMemcpyHostToDevice));
+    // stream kernel: slot bound per item = Q tasks x 16 slabs
+    for (size_t w = 0; w < W.size(); w++)
+        W[w].pad_ = (u32)((w * (size_t)Q * 16) << 1);
+    CK(hipMalloc(&X.dWs, sizeof(SsssmWorkD) * W.size()));
+    CK(hipMemcpy(X.dWs, W.data(), sizeof(SsssmWorkD) * W.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&X.dInfo, sizeof(SsssmItemInfoD) * W.size()));
+    CK(hipMalloc(&X.dSteps, sizeof(SsssmStepD) * W.size() * (size_t)Q * 16));
 }
 
 // which: 0 = general kernel; otherwise 100 * unit_destinations + 10 * prefetch + stages
@@ -162,6 +174,23 @@ void launch(int which, Problem &X)
     if (which == 0)
     {
         hipLaunchKernelGGL(ssssm_dense_f64_kernel, dim3(grid), dim3(DG_THREADS), 0, 0, X.dT, X.nb, none, none, X.dW);
+        CK(hipGetLastError());
+        return;
+    }
+    if (which >= 60000)
+    {
+        // round 6: persistent sixteen-wavefront workgroups walking a stream of slab steps (pg_hip_stream.h); which % 1000 = workgroups (0: 256)
+        static bool allowed = false;
+        if (!allowed)
+        {
+            CK(hipFuncSetAttribute((const void *)ssssm_stream_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_BYTES));
+            allowed = true;
+        }
+        unsigned wgs = (unsigned)(which % 1000) ? (unsigned)(which % 1000) : 256u;
+        const unsigned need = (unsigned)((grid + 31) / 32 * 32);
+        if (wgs > need) wgs = need;
+        hipLaunchKernelGGL(ssssm_stream_build_kernel, dim3(grid), dim3(256), 0, 0, X.dT, X.nb, X.dWs, X.dInfo, X.dSteps);
+        hipLaunchKernelGGL(ssssm_stream_f64_kernel, dim3(wgs), dim3(SW_THREADS), SW_LDS_BYTES, 0, X.nb, X.dWs, X.dInfo, X.dSteps, grid, none);
         CK(hipGetLastError());
         return;
     }
@@ -228,6 +257,11 @@ const char *name_of(int which)
 {
     if (which == 0)
         return "round-2 kernel (pg_hip_dense.h)";
+    if (which >= 60000)
+    {
+        snprintf(name_buf, sizeof(name_buf), "stream kernel (16 wavefronts, 4 stages, persistent), %d workgroups", which % 1000 ? which % 1000 : 256);
+        return name_buf;
+    }
     if (which >= 50000)
     {
         snprintf(name_buf, sizeof(name_buf), "pieces kernel (ring of 32 piece slots, batches), XCD unit %d dest.", (which / 100) % 100);
@@ -289,7 +323,7 @@ int main(int argc, char **argv)
         build(X, 3, 2, true, cf);
         const int nb = X.nb;
         std::vector<double> ref((size_t)nb * nb), got((size_t)X.mb);
-        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102, 30100, 40100, 50102} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802, 50102, 50802};
+        std::vector<int> kinds = cf == 100 ? std::vector<int>{0, 102, 113, 104, 10102, 10103, 10104, 20102, 30100, 40100, 50102, 60000, 60032} : std::vector<int>{0, 10102, 10103, 10104, 10802, 20102, 20802, 50102, 50802, 60000, 60032};
         for (int which : kinds)
         {
             for (int i = 0; i < X.P; i++)
@@ -308,7 +342,7 @@ int main(int argc, char **argv)
                 }
             printf("check (fill %3d%%)  %-66s max |C - ref| = %.3e %s\n", cf, name_of(which), worst, worst < 1e-11 ? "ok" : "WRONG");
         }
-        CK(hipFree(X.d)); CK(hipFree(X.dT)); CK(hipFree(X.dW));
+        CK(hipFree(X.d)); CK(hipFree(X.dT)); CK(hipFree(X.dW)); CK(hipFree(X.dWs)); CK(hipFree(X.dInfo)); CK(hipFree(X.dSteps));
     }
     // ---- timing
     Problem X;
@@ -318,7 +352,7 @@ int main(int argc, char **argv)
     const double flop = 8192.0 * X.products;
     printf("front %d x %d destinations of 256 x 256, %d update(s) queued on each, %d%% fill pattern: %zu workgroups, %.3f TFLOP of live 16x16x16 products per launch (%.1f%% of dense)\n", P, P, Q,
            fill, X.nwork, flop / 1e12, 100.0 * flop / (2.0 * 256 * 256 * 256 * (double)P * P * Q));
-    std::vector<int> kinds = fill >= 100 ? std::vector<int>{112, 20102, 50102, 112, 20102, 50102} : std::vector<int>{20102, 50102, 20802, 50802, 20102, 50102, 20802, 50802};
+    std::vector<int> kinds = fill >= 100 ? std::vector<int>{112, 20102, 60000, 60224, 112, 20102, 60000, 60224} : std::vector<int>{20102, 20802, 60000, 60224, 20102, 20802, 60000, 60224};
 #ifdef TL_PROBE
     kinds = {20102, 50102, 20102, 50102};
 #endif
