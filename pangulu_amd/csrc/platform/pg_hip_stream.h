@@ -35,14 +35,17 @@
 #define SW_STAGES 4
 #define SW_LDS_BYTES (SW_STAGES * FR_STAGE_DOUBLES * 8)
 #define SW_LAST 0x80000000u // step word: last step of its item
-#define SW_ADD 0x00010000u  // step word: the product is ADDED (complex updates: the A_im B_im product on the real plane)
+#define SW_REAL 0x40000000u // (in the kernel's queue of words: a step, not the end of the stream)
+#define SW_ADD 0x01000000u  // step word: the product is ADDED (complex updates: the A_im B_im product on the real plane)
+#define SW_NIBBLE_SHIFT 20  // (in the kernel's queue of words: bits 20-23 = this wavefront's nibble of `masks`)
 
 struct SsssmStepD // one live (task, K-slab) step of one tile
 {
     unsigned long long pa; // A mirror + (k0 * nb + M0) doubles: column k of the slab at + k * nb, the tile's 128 rows from there
     unsigned long long pb; // B mirror + (N0 * nb + k0) doubles: column n of the tile at + n * nb, the slab's 16 rows from there
     u32 word;              // ab (bits 0-7: live 16-row pieces of A in the tile), bb (8-15: live 16-column pieces of B), SW_ADD, SW_LAST
-    u32 pad_[3];
+    u32 pad_;
+    unsigned long long masks; // nibble w: which of wavefront w's four pieces have a live product in this step (sw_wave_mask)
 };
 static_assert(sizeof(SsssmStepD) == 32, "one s_load_dwordx8 per step");
 
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void ssssm_stream_build_kernel(const SsssmTask
     for (int win0 = 0; win0 < ntask; win0 += 16)
     {
         unsigned v = 0;
-        unsigned long long pa_v = 0, pb_v = 0;
+        unsigned long long pa_v = 0, pb_v = 0, step_masks = 0;
         const int t_ = tid >> 4, s_ = tid & 15;
         if (win0 + t_ < ntask && s_ < nslab)
         {
@@ -124,7 +127,8 @@ __global__ __launch_bounds__(256) void ssssm_stream_build_kernel(const SsssmTask
                 pb_v = (unsigned long long)(pb_ + ((size_t)N0 * nb + s_ * FR_KS));
 #pragma unroll
                 for (unsigned w = 0; w < SW_WAVES; w++)
-                    pre |= (unsigned long long)sw_wave_mask(w, ab_, bb_) << (4 * w);
+                    step_masks |= (unsigned long long)sw_wave_mask(w, ab_, bb_) << (4 * w);
+                pre |= step_masks;
             }
         }
         const unsigned long long bal = __ballot(v != 0);
@@ -145,7 +149,8 @@ __global__ __launch_bounds__(256) void ssssm_stream_build_kernel(const SsssmTask
             r.pa = pa_v;
             r.pb = pb_v;
             r.word = v & ~0x40000000u;
-            r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+            r.pad_ = 0;
+            r.masks = step_masks;
             out[total + at] = r;
         }
         total += all;
@@ -166,7 +171,8 @@ __global__ __launch_bounds__(256) void ssssm_stream_build_kernel(const SsssmTask
             SsssmStepD r;
             r.pa = r.pb = (unsigned long long)reinterpret_cast<double *>(G.cdense);
             r.word = SW_LAST;
-            r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+            r.pad_ = 0;
+            r.masks = 0;
             out[0] = r;
             total = 1;
         }
@@ -230,30 +236,33 @@ __global__ __launch_bounds__(SW_THREADS) void ssssm_stream_f64_kernel(int nb, co
         const SsssmStepD __attribute__((address_space(4))) *R = SW_CONST(SsssmStepD, ic_ptr);
         rec_pa = R->pa;
         rec_pb = R->pb;
-        rec_w = R->word;
+        // (this wavefront's nibble of the step's masks rides in the word: what the compute side needs is one scalar register per step)
+        rec_w = R->word | (((unsigned)(R->masks >> (4 * wave)) & 0xFu) << SW_NIBBLE_SHIFT) | SW_REAL;
     };
     ic_enter(0);
     fetch_rec();
     // words of the steps in flight: q0 = the step being computed, q1..q3 = requested
     unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    auto request = [&](int stage_no) -> unsigned
+    const unsigned lds0 = (unsigned)(unsigned long long)(fr_lptr)sw_lds; // (the workgroup's dynamic LDS starts here)
+    const unsigned dma_a = lds0 + (unsigned)wave * (FR_LDA * 8u), dma_b = lds0 + (FR_KS * FR_LDA + (unsigned)wave * 128u) * 8u;
+    auto request = [&](unsigned stage_bytes) -> unsigned
     {
-        // requests the slab of the cursor's next step into `stage_no`; returns its word (0 and no request when the stream has ended)
+        // requests the slab of the cursor's next step into the stage at `stage_bytes`; returns its word (0 and no request when the
+        // stream has ended)
         if (ic_done)
             return 0u;
         const unsigned w = rec_w;
         const fr_gptr pa = (fr_gptr)rec_pa, pb = (fr_gptr)rec_pb;
-        double *stage = sw_lds + stage_no * FR_STAGE_DOUBLES;
         const unsigned ab = w & 0xFFu, bb = (w >> 8) & 0xFFu;
         {
             const bool a_live = (ab >> a_piece) & 1u;
             const unsigned off = a_live ? a_col_off + a_voff : 0u;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dg_scalar_base(pa) + off), (fr_lptr)(stage + wave * FR_LDA), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dg_scalar_base(pa) + off), (fr_lptr)(unsigned long long)(dma_a + stage_bytes), 16, 0, 0);
         }
         {
             const bool b_live = (bb >> (wave >> 1)) & 1u;
             const unsigned off = b_live ? b_grp_off + b_voff : 0u;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dg_scalar_base(pb) + off), (fr_lptr)(stage + FR_KS * FR_LDA + wave * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dg_scalar_base(pb) + off), (fr_lptr)(unsigned long long)(dma_b + stage_bytes), 16, 0, 0);
         }
         ic_ptr++;
         if (--ic_left == 0)
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(SW_THREADS) void ssssm_stream_f64_kernel(int nb, co
         }
         if (!ic_done)
             fetch_rec();
-        return w | 0x40000000u; // (bit 30: a real step)
+        return w;
     };
 
     // ---- compute side
@@ -341,10 +350,11 @@ __global__ __launch_bounds__(SW_THREADS) void ssssm_stream_f64_kernel(int nb, co
     // waits as builtins, not inline assembly: the compiler's own wait insertion sees them (s_waitcnt immediates of gfx9: vmcnt in
     // bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "no wait")
 #define SW_WAIT_VM(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 0xF) | (((n_) >> 4) << 14))
-    // ---- prologue: three slabs requested, the first one landed everywhere, its first fragments read
-    q0 = request(0);
-    q1 = request(1);
-    q2 = request(2);
+    // ---- prologue: three slabs requested, the first one landed everywhere, its fragments of the first two k-quarters read
+    const unsigned STB = (unsigned)(FR_STAGE_DOUBLES * 8);
+    q0 = request(0u);
+    q1 = request(STB);
+    q2 = request(2u * STB);
     SW_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     double fa[2][2], fb[2][2]; // [buffer][mi] / [buffer][ni]
@@ -353,98 +363,125 @@ __global__ __launch_bounds__(SW_THREADS) void ssssm_stream_f64_kernel(int nb, co
     // kernels never noticed: their waits are vmcnt(0) anyway).  The waits for these reads are SW_FRAGS_READY below; "+v" ties the
     // products behind it.
 #define SW_LDS_READ(dst_, addr_, off_) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_) : "memory")
-#define SW_READ(buf_, abase_, bbase_, kq_)                                                                                       \
-    {                                                                                                                            \
-        SW_LDS_READ(fa[buf_][0], abase_, (kq_) * 4 * FR_LDA * 8);                                                                \
-        SW_LDS_READ(fa[buf_][1], abase_, (kq_) * 4 * FR_LDA * 8 + 512);                                                          \
-        SW_LDS_READ(fb[buf_][0], (bbase_)[kq_], 0);                                                                              \
-        SW_LDS_READ(fb[buf_][1], (bbase_)[kq_], 8192);                                                                           \
-    }
-    // (LDS reads return in order: with the four reads of the NEXT k-quarter already issued, lgkmcnt(4) says this one's have arrived --
+    // (LDS reads return in order: with `newer_` reads issued behind the ones a product needs, lgkmcnt(newer_) says those have arrived --
     //  a scalar load in flight only makes the wait stricter)
 #define SW_FRAGS_READY(buf_, newer_) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[buf_][0]), "+v"(fa[buf_][1]), "+v"(fb[buf_][0]), "+v"(fb[buf_][1]) : "n"(newer_) : "memory")
     // byte addresses inside stage 0: A fragments at a_byte (+ kq * 4 columns, + 64 rows), B fragments at b_byte[kq] (+ 64 columns)
-    const unsigned a_byte = (unsigned)a_frag * 8u;
+    const unsigned a_byte = lds0 + (unsigned)a_frag * 8u;
     unsigned b_byte[4];
 #pragma unroll
     for (int kq = 0; kq < 4; kq++)
-        b_byte[kq] = (unsigned)(b_frag + 2 * ((2 * kq + (l4 >> 1)) ^ swz)) * 8u;
-    const unsigned lds0 = (unsigned)(unsigned long long)(fr_lptr)sw_lds; // (the workgroup's dynamic LDS starts here)
-    auto stage_bases = [&](int st, unsigned &ab_, unsigned (&bb_)[4])
-    {
-        const unsigned o = lds0 + (unsigned)st * (unsigned)(FR_STAGE_DOUBLES * 8);
-        ab_ = a_byte + o;
-#pragma unroll
-        for (int kq = 0; kq < 4; kq++)
-            bb_[kq] = b_byte[kq] + o;
-    };
-    unsigned fa_base, fb_base[4];
-    stage_bases(0, fa_base, fb_base);
-    SW_READ(0, fa_base, fb_base, 0)
+        b_byte[kq] = lds0 + (unsigned)(b_frag + 2 * ((2 * kq + (l4 >> 1)) ^ swz)) * 8u;
+    // all four fragments of k-quarter kq of the stage at byte offset so_ into buffer buf_
+#define SW_READ_ALL(buf_, so_, kq_)                                                 \
+    {                                                                               \
+        const unsigned aa_ = a_byte + (so_), bb_ = b_byte[kq_] + (so_);             \
+        SW_LDS_READ(fa[buf_][0], aa_, (kq_) * 4 * FR_LDA * 8);                      \
+        SW_LDS_READ(fa[buf_][1], aa_, (kq_) * 4 * FR_LDA * 8 + 512);                \
+        SW_LDS_READ(fb[buf_][0], bb_, 0);                                           \
+        SW_LDS_READ(fb[buf_][1], bb_, 8192);                                        \
+    }
     unsigned nprod = 0;
-    int skip_waits = 0; // steps behind an item boundary whose slabs had landed there
-    int stage = 0;      // stage of the step being computed
-#if PG_PLANES > 1
-#define SW_MFMA(buf_)                                                                                                                   \
-    asm volatile("" : "+s"(m4));                                                                                                        \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ni++) _Pragma("unroll") for (int mi = 0; mi < 2; mi++) if ((m4 >> (mi + 2 * ni)) & 1u)    \
-    {                                                                                                                                   \
-        if (add)                                                                                                                        \
-            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni], fa[buf_][mi], acc[ni][mi], 0, 0, 0);                       \
-        else                                                                                                                            \
-            acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni], fa[buf_][mi], acc[ni][mi], 0, 0, DG_NEG_A);                \
+#ifdef SW_PROBE // (tools/microbench/front_gemm.hip: where does a step spend its cycles?  wavefronts 0 and 5 of every workgroup)
+    unsigned long long pr_t = __builtin_readcyclecounter(), pr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SW_MARK(i)                                                  \
+    {                                                               \
+        const unsigned long long n_ = __builtin_readcyclecounter(); \
+        pr_sum[i] += n_ - pr_t;                                     \
+        pr_t = n_;                                                  \
     }
 #else
-#define SW_MFMA(buf_)                                                                                                                   \
-    asm volatile("" : "+s"(m4));                                                                                                        \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ni++) _Pragma("unroll") for (int mi = 0; mi < 2; mi++) if ((m4 >> (mi + 2 * ni)) & 1u)    \
-        acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni], fa[buf_][mi], acc[ni][mi], 0, 0, DG_NEG_A);
+#define SW_MARK(i)
 #endif
+    int skip_waits = 0;     // steps behind an item boundary whose slabs had landed there
+    unsigned so_cur = 0;    // byte offset of the stage of the step being computed
+    // The critical section of a step -- between the last product a wavefront issues and the first one of the next step, when all sixteen
+    // wavefronts do the same thing and nothing feeds the matrix pipes -- holds a wait, the barrier and a wait: the fragments of the
+    // first two k-quarters were read during the previous step, the masks are in registers, and ALL bookkeeping (the slab request, the
+    // cursor, the queue of words, stage offsets) sits between the products of the first and the second k-quarter, where the scalar
+    // instructions of one wavefront issue beside the products of the other three of its SIMD.
+#if PG_PLANES > 1
+#define SW_ONE_PRODUCT(buf_, ni_, mi_)                                                                                              \
+    if ((m4 >> ((mi_) + 2 * (ni_))) & 1u)                                                                                           \
+    {                                                                                                                               \
+        if (add)                                                                                                                    \
+            acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni_], fa[buf_][mi_], acc[ni_][mi_], 0, 0, 0);             \
+        else                                                                                                                        \
+            acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni_], fa[buf_][mi_], acc[ni_][mi_], 0, 0, DG_NEG_A);      \
+    }
+#else
+#define SW_ONE_PRODUCT(buf_, ni_, mi_)                                                                                              \
+    if ((m4 >> ((mi_) + 2 * (ni_))) & 1u)                                                                                           \
+        acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni_], fa[buf_][mi_], acc[ni_][mi_], 0, 0, DG_NEG_A);
+#endif
+#define SW_PRODUCTS(buf_)                \
+    {                                    \
+        asm volatile("" : "+s"(m4));     \
+        SW_ONE_PRODUCT(buf_, 0, 0)       \
+        SW_ONE_PRODUCT(buf_, 0, 1)       \
+        SW_ONE_PRODUCT(buf_, 1, 0)       \
+        SW_ONE_PRODUCT(buf_, 1, 1)       \
+    }
     // one item: its steps on the accumulator set `acc`; at its end the set is stored and takes the pieces of the item after the next.
     // Returns true when that was this workgroup's last item.
     auto run_item = [&](v4f64(&acc)[2][2]) -> bool
     {
         for (;;)
         {
-            // ---- top of step c: slab c + 1 has landed (this wavefront's two requests by the wait, everybody's behind the barrier);
+            // ---- top of step c: slab c has landed (this wavefront's two requests by the wait, everybody's behind the barrier);
             //      everybody has finished with slab c - 1
+            SW_MARK(5)
             if (skip_waits > 0)
                 skip_waits--;
-            else if (q2 & 0x40000000u)
+            else if (q2 & SW_REAL)
+                SW_WAIT_VM(4); // (the requests of slabs c + 1 and c + 2 may stay in flight)
+            else if (q1 & SW_REAL)
                 SW_WAIT_VM(2);
             else
                 SW_WAIT_VM(0);
+            SW_MARK(0)
             __builtin_amdgcn_s_barrier();
-            q3 = request((stage + 3) & 3); // slab c + 3 into the stage slab c - 1 was in
-            unsigned m4 = sw_wave_mask((unsigned)wave, q0 & 0xFFu, (q0 >> 8) & 0xFFu);
+            SW_MARK(1)
+            unsigned m4 = (q0 >> SW_NIBBLE_SHIFT) & 0xFu; // this wavefront's live pieces in this step
 #if PG_PLANES > 1
             const bool add = (q0 & SW_ADD) != 0;
 #endif
+            const unsigned so_this = so_cur;
+            const bool last = (q0 & SW_LAST) != 0;
             if (m4)
             {
-                nprod += (unsigned)__builtin_popcount(m4);
-                // (fa_base / fb_base: this step's stage, set behind the previous step's products)
-                SW_READ(1, fa_base, fb_base, 1)
+                SW_READ_ALL(0, so_this, 0)
+                SW_READ_ALL(1, so_this, 1)
                 SW_FRAGS_READY(0, 4);
-                SW_MFMA(0)
-                SW_READ(0, fa_base, fb_base, 2)
-                SW_FRAGS_READY(1, 4);
-                SW_MFMA(1)
-                SW_READ(1, fa_base, fb_base, 3)
-                SW_FRAGS_READY(0, 4);
-                SW_MFMA(0)
-                SW_FRAGS_READY(1, 0);
-                SW_MFMA(1)
+                SW_MARK(2)
+                SW_PRODUCTS(0)
             }
-            // the first fragments of step c + 1 (its slab landed behind this step's barrier), behind this step's products
-            stage_bases((stage + 1) & 3, fa_base, fb_base);
-            if (q1 & 0x40000000u)
-                SW_READ(0, fa_base, fb_base, 0)
-            const bool last = (q0 & SW_LAST) != 0;
-            q0 = q1;
-            q1 = q2;
-            q2 = q3;
-            stage = (stage + 1) & 3;
+            SW_MARK(3)
+            // ---- bookkeeping, in the shadow of the first products: slab c + 3 into the stage slab c - 1 was in, the queue of words
+            {
+                const unsigned so_req = so_cur == 0u ? 3u * STB : so_cur - STB;
+                q3 = request(so_req);
+                nprod += (unsigned)__builtin_popcount(m4);
+                q0 = q1;
+                q1 = q2;
+                q2 = q3;
+                so_cur = so_cur + STB == 4u * STB ? 0u : so_cur + STB;
+            }
+            SW_MARK(4)
+#ifdef SW_PROBE
+            pr_sum[7]++;
+#endif
+            if (m4)
+            {
+                SW_READ_ALL(0, so_this, 2)
+                SW_FRAGS_READY(1, 4);
+                SW_PRODUCTS(1)
+                SW_READ_ALL(1, so_this, 3)
+                SW_FRAGS_READY(0, 4);
+                SW_PRODUCTS(0)
+                SW_FRAGS_READY(1, 0);
+                SW_PRODUCTS(1)
+            }
             if (!last)
                 continue;
             // ---- item boundary: everything requested so far lands first (the newest request is a step old), then the stores
@@ -481,7 +518,7 @@ __global__ __launch_bounds__(SW_THREADS) void ssssm_stream_f64_kernel(int nb, co
                 item_fields(cm_k + 1, c_nxt, M0n, N0n, pre_n, at_n);
                 SW_LOAD_PIECES_ASYNC(acc, c_nxt, M0n, N0n, pre_n, at_n)
             }
-            skip_waits = 2;
+            skip_waits = 3; // (slabs c + 1 .. c + 3 had landed at the boundary)
             return false;
         }
     };
@@ -492,14 +529,21 @@ __global__ __launch_bounds__(SW_THREADS) void ssssm_stream_f64_kernel(int nb, co
         if (run_item(acc1))
             break;
     }
-#undef SW_READ
+#undef SW_READ_ALL
 #undef SW_LDS_READ
 #undef SW_FRAGS_READY
-#undef SW_MFMA
+#undef SW_ONE_PRODUCT
+#undef SW_PRODUCTS
 #undef SW_WAIT_VM
 #undef SW_LOAD_PIECES
 #undef SW_LOAD_PIECES_ASYNC
 #undef SW_C
     if (product_counter && lane == 0 && nprod)
         atomicAdd(product_counter, (unsigned long long)nprod);
+#ifdef SW_PROBE
+    if (lane == 0 && (wave == 0 || wave == 5))
+        for (int i_ = 0; i_ < 8; i_++)
+            atomicAdd(&g_sw_probe[i_], pr_sum[i_]);
+#endif
+#undef SW_MARK
 }

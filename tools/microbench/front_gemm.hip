@@ -49,6 +49,9 @@ __device__ unsigned long long g_item[16];
 #include "../../pangulu_amd/csrc/platform/pg_hip_dense.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_front.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_pieces.h"
+#ifdef SW_PROBE
+__device__ unsigned long long g_sw_probe[8];
+#endif
 #include "../../pangulu_amd/csrc/platform/pg_hip_stream.h"
 #include "../experiments/front_k32.h"
 #include "../experiments/front_n64.h"
@@ -375,6 +378,19 @@ int main(int argc, char **argv)
             best = fminf(best, ms);
             if (rep) sum += ms;
         }
+#ifdef SW_PROBE
+        if (which >= 60000)
+        {
+            unsigned long long pr[8];
+            CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sw_probe), sizeof(pr)));
+            const double st = (double)pr[7];
+            printf("probe  stream kernel, cycles per step and wavefront (%.0f steps sampled): wait for the slab %.0f, barrier %.0f, fragment reads + wait %.0f, first products %.0f, "
+                   "request + queue %.0f, other three quarters + loop end %.0f: %.0f in all\n",
+                   st, pr[0] / st, pr[1] / st, pr[2] / st, pr[3] / st, pr[4] / st, pr[5] / st, (pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[5]) / st);
+            unsigned long long zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sw_probe), zero8, sizeof(zero8)));
+        }
+#endif
         printf("time   %-66s best %8.3f ms = %6.2f TFLOP/s executed, mean of 4 %8.3f ms = %6.2f\n", name_of(which), best, flop / best / 1e9, sum / 4, flop / (sum / 4) / 1e9);
 #ifdef TL_PROBE
         unsigned long long pr[8];
