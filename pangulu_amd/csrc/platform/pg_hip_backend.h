@@ -85,20 +85,7 @@ struct Backend
     // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 1 / 3 / 4 = the
     // LDS-DMA pipeline with 2 / 3 / 4 stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h), 2 = its
     // two-stage form with the per-step fixed cost taken out of the chain (ssssm_tilesv_f64_kernel)
-    long long opt_tiles_stages = 2; // PANGULU_HIP_TILES_STAGES / option 16 (6: the persistent stream kernel, pg_hip_stream.h)
-    int ncu = 256;                  // compute units of the device
-    long long opt_stream_wgs = 0;   // PANGULU_HIP_STREAM_WGS: workgroups of the stream kernel (0: one per CU, rounded down to a multiple of 32)
-    // device scratch of the stream kernel's list builder: one grow-only buffer per stream the update kernels run on (launches on one
-    // stream are ordered, so consecutive launches share it); a buffer that was outgrown stays alive -- recorded launches point into it
-    struct Scratch
-    {
-        hipStream_t stream;
-        char *d;
-        size_t cap;
-    };
-    std::vector<Scratch> stream_scratch;
-    std::vector<char *> stream_scratch_retired;
-    size_t stream_scratch_bytes = 0;
+    long long opt_tiles_stages = 2; // PANGULU_HIP_TILES_STAGES / option 16
     long long opt_tiles_unit = 1;   // PANGULU_HIP_TILES_UNIT: consecutive destinations of the general launch that share an XCD
     unsigned long long front_workgroups = 0, general_workgroups = 0;
     long long opt_records_stream = 1; // PANGULU_HIP_RECORDS_STREAM=0: sparsify on the main stream as before
@@ -304,9 +291,6 @@ void ensure_ready()
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, B.device));
         const int ncu = prop.multiProcessorCount;
-        B.ncu = ncu;
-        if (const char *e = getenv("PANGULU_HIP_STREAM_WGS"))
-            B.opt_stream_wgs = atol(e);
         if (reserved > 0 && reserved < ncu / 2 && ncu % 32 == 0)
         {
             std::vector<uint32_t> mask((size_t)ncu / 32, 0xFFFFFFFFu);
@@ -378,27 +362,6 @@ void ensure_ready()
     HIP_CHECK(hipMemset(B.d_flops, 0, sizeof(unsigned long long) * PG_FLOP_WORDS));
     memset(&B.stats, 0, sizeof(B.stats));
     B.ready = true;
-}
-
-// device scratch for the launches of one stream (see Backend::stream_scratch)
-inline char *stream_scratch_for(hipStream_t st, size_t bytes)
-{
-    for (auto &sc : B.stream_scratch)
-        if (sc.stream == st)
-        {
-            if (sc.cap >= bytes)
-                return sc.d;
-            B.stream_scratch_retired.push_back(sc.d); // (launches already queued or recorded still read it)
-            sc.cap = std::max(bytes + bytes / 2, (size_t)8 << 20);
-            HIP_CHECK(hipMalloc((void **)&sc.d, sc.cap));
-            B.stream_scratch_bytes += sc.cap;
-            return sc.d;
-        }
-    Backend::Scratch sc{st, nullptr, std::max(bytes + bytes / 2, (size_t)8 << 20)};
-    HIP_CHECK(hipMalloc((void **)&sc.d, sc.cap));
-    B.stream_scratch_bytes += sc.cap;
-    B.stream_scratch.push_back(sc);
-    return sc.d;
 }
 
 // a staging segment: host pointer to fill, device pointer the kernels will read after commit()

@@ -658,6 +658,9 @@ __global__ __launch_bounds__(FR_THREADS, (STAGES <= 2 ? 4 : 2)) void ssssm_tiles
 //  * DMA instructions whose B piece is dead are not issued (every wait of a two-stage pipeline is vmcnt(0)).
 // ---------------------------------------------------------------------------------------------------------------
 #define TV_STEPS (TL_WINDOW * 16)
+#ifndef TV_PAIR_MAJOR
+#define TV_PAIR_MAJOR 1
+#endif
 __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const SsssmTaskD *__restrict__ tasks, int nb, const SsssmWorkD *__restrict__ work,
                                                                           unsigned long long *__restrict__ product_counter, unsigned unit)
 {
@@ -924,6 +927,57 @@ __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const S
         _Pragma("unroll") for (int ni = 0; ni < 2; ni++) fb[buf_][ni] = sA[b_frag[ni][0] + 2 * ((2 * (kq_) + (l4 >> 1)) ^ b_frag[ni][1])]; \
     }
             double fa[2][4], fb[2][2];
+#if TV_PAIR_MAJOR
+            // Round 6: PIECE-major inside a pair of k-quarters.  The step loop of this kernel is bound by scalar issue, not by the
+            // matrix pipes: a wavefront's step is 120 scalar instructions and 80 branches (ISA count), four wavefront-steps share a
+            // SIMD's scalar issue slot per step-pair, 4 x 120 x 4 cycles = the F = 2000 cycles "nothing overlaps" of DESIGN.md §4.2.
+            // A third of them are the guards of the conditional products -- one test per product and k-quarter.  With both k-quarters
+            // of a pair in registers a live piece takes its two products behind ONE test: 16 tests per step instead of 40.
+#define TV_PIECE2(ni_, mi_)                                                                                                            \
+    if ((m8 >> ((mi_) + 4 * (ni_))) & 1u)                                                                                              \
+    {                                                                                                                                   \
+        TV_ONE(0, ni_, mi_)                                                                                                             \
+        TV_ONE(1, ni_, mi_)                                                                                                             \
+    }
+#if PG_PLANES > 1
+#define TV_ONE(buf_, ni_, mi_)                                                                                                          \
+    if (add)                                                                                                                            \
+        acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni_], fa[buf_][mi_], acc[ni_][mi_], 0, 0, 0);                     \
+    else                                                                                                                                \
+        acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni_], fa[buf_][mi_], acc[ni_][mi_], 0, 0, DG_NEG_A);
+#else
+#define TV_ONE(buf_, ni_, mi_) acc[ni_][mi_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[buf_][ni_], fa[buf_][mi_], acc[ni_][mi_], 0, 0, DG_NEG_A);
+#endif
+#define TV_PAIR                                                                            \
+    {                                                                                      \
+        TV_PIECE2(0, 0) TV_PIECE2(0, 1) TV_PIECE2(0, 2) TV_PIECE2(0, 3)                    \
+        TV_PIECE2(1, 0) TV_PIECE2(1, 1) TV_PIECE2(1, 2) TV_PIECE2(1, 3)                    \
+    }
+            unsigned m8 = 0; // bit mi + 4 ni: this wavefront's live pieces in the step
+            if (live)
+            {
+                m8 = ((b2 & 1u) ? a4 : 0u) | ((b2 & 2u) ? (a4 << 4) : 0u);
+                nprod += (unsigned)__builtin_popcount(m8);
+                touched |= m8;
+                TV_READ(0, 0)
+                TV_READ(1, 1)
+                TV_PAIR
+            }
+            TL_MARK(2)
+            // the next slab, behind this wavefront's first products
+            if (st + 1 < T)
+                issue(wN, paN, pbN, (stage_head + st + 1) & 1);
+            TL_MARK(3)
+            if (live)
+            {
+                TV_READ(0, 2)
+                TV_READ(1, 3)
+                TV_PAIR
+            }
+#undef TV_PIECE2
+#undef TV_ONE
+#undef TV_PAIR
+#else
             if (live)
             {
                 nprod += (unsigned)(__builtin_popcount(a4) * __builtin_popcount(b2));
@@ -948,6 +1002,7 @@ __global__ __launch_bounds__(FR_THREADS, 4) void ssssm_tilesv_f64_kernel(const S
                 TV_MFMA(0)
                 TV_MFMA(1)
             }
+#endif
 #undef TV_READ
 #undef TV_MFMA
             wC = wN;

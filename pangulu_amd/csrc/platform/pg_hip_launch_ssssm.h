@@ -407,10 +407,6 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 else
                     for (size_t gi = 0; gi < gd; gi++)
                         g_order[gi] = (u32)gi;
-                // round 6: the persistent stream kernel (pg_hip_stream.h) reads step lists a kernel of its own builds in front of it: every
-                // item carries the first slot of its list (pad_ = slot << 1 | all_live), sized by the live steps the host's summaries count
-                const bool stream_on = B.opt_tiles_stages == 6 && (nb == 128 || nb == 256);
-                size_t stream_slots = 0;
                 for (size_t go = 0; go < gd; go++)
                 {
                     const size_t gi = g_order[go];
@@ -420,19 +416,6 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                         if ((Gd.live_tiles >> tl) & 1u)
                         {
                             SsssmWorkD item{Gd.cdense, Gd.task_begin, Gd.task_end, Gd.atomic, Gd.slab_mask, (u32)tl, 0u};
-                            if (stream_on && (!((all_full >> tl) & 1u) || !own_launch))
-                            {
-                                const unsigned kmask = Gd.slab_mask ? Gd.slab_mask : 0xFFFFu;
-                                size_t bound = 0;
-                                for (u32 t = Gd.task_begin; t < Gd.task_end; t++)
-                                    bound += (size_t)__builtin_popcount(live_k[(size_t)t * 4 + tl] & kmask);
-                                item.pad_ = (u32)(stream_slots << 1) | (((all_full >> tl) & 1u) ? 1u : 0u);
-                                stream_slots += std::max<size_t>(bound, 1);
-                                work[nw++] = item;
-                                if ((all_full >> tl) & 1u)
-                                    nfm++;
-                                continue;
-                            }
                             if (!((all_full >> tl) & 1u))
                                 work[nw++] = item;
                             else if (own_launch)
@@ -492,25 +475,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 if (fork_front)
                     pg_event_record(B.ev_front_join, fs);
                 LaunchTimer lk_general(nw ? 101 : 102, ds); // (102: no general launch in this call -- an empty pair, dropped at harvest)
-                if (nw && stream_on)
-                {
-                    static bool lds_allowed = false;
-                    if (!lds_allowed)
-                    {
-                        HIP_CHECK(hipFuncSetAttribute((const void *)ssssm_stream_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_BYTES));
-                        lds_allowed = true;
-                    }
-                    const size_t info_bytes = (sizeof(SsssmItemInfoD) * nw + 255) & ~(size_t)255;
-                    char *sc = stream_scratch_for(ds, info_bytes + sizeof(SsssmStepD) * stream_slots);
-                    SsssmItemInfoD *d_info = reinterpret_cast<SsssmItemInfoD *>(sc);
-                    SsssmStepD *d_steps = reinterpret_cast<SsssmStepD *>(sc + info_bytes);
-                    PG_LAUNCH(ssssm_stream_build_kernel, dim3((unsigned)nw), dim3(256), 0, ds, d_tasks_d, nb, d_work, d_info, d_steps);
-                    // one persistent workgroup per CU (a multiple of 32: the tiles of a destination stay on one XCD), fewer for a small launch
-                    unsigned wgs = (unsigned)(B.opt_stream_wgs > 0 ? B.opt_stream_wgs : B.ncu) / 32u * 32u;
-                    wgs = std::max(32u, std::min(wgs, (unsigned)((nw + 31) / 32 * 32)));
-                    PG_LAUNCH(ssssm_stream_f64_kernel, dim3(wgs), dim3(SW_THREADS), (size_t)SW_LDS_BYTES, ds, nb, d_work, d_info, d_steps, (unsigned)nw, pc);
-                }
-                else if (nw && B.opt_tiles_stages >= 2)
+                if (nw && B.opt_tiles_stages >= 2)
                 {
                     // round 3: LDS-DMA pipeline, strided piece ownership (pg_hip_front.h)
                     const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_tiles_unit);

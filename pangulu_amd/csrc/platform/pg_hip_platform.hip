@@ -517,7 +517,6 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #include "pg_hip_dense.h"
 #include "pg_hip_front.h"
 #include "pg_hip_pieces.h"
-#include "pg_hip_stream.h"
 #endif
 #if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
 #include "pg_hip_trsm_dense.h"

@@ -52,7 +52,7 @@ __device__ unsigned long long g_item[16];
 #ifdef SW_PROBE
 __device__ unsigned long long g_sw_probe[8];
 #endif
-#include "../../pangulu_amd/csrc/platform/pg_hip_stream.h"
+#include "../experiments/pg_hip_stream.h"
 #include "../experiments/front_k32.h"
 #include "../experiments/front_n64.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
