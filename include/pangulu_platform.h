@@ -260,17 +260,16 @@ extern "C"
     /*   PANGULU_HIP_OPT_FRONT_STAGES (default 2; environment PANGULU_HIP_FRONT_STAGES at start-up): (destination, 128 x 128
      *     tile) pairs whose queued updates are all dense-front products -- every 16 x 16 piece of both operands that meets
      *     the tile holds pattern entries -- need no occupancy bookkeeping.  1: they run inside the general launch on its
-     *     no-step-list path (one launch, one tail; needs TILES_STAGES >= 1); 2, 3 or 4: on the dense-front kernel of their
+     *     no-step-list path (one launch, one tail; needs TILES_STAGES != 0); 2, 3 or 4: on the dense-front kernel of their
      *     own (operand slabs by LDS-DMA, that many LDS stages) when a launch has at least PANGULU_HIP_FRONT_MIN_WGS (8192) of
      *     them, inside the general launch otherwise; 0: treated like any other tile. */
 #define PANGULU_HIP_OPT_FRONT_STAGES 15
     /*   PANGULU_HIP_OPT_TILES_STAGES (default 2; environment PANGULU_HIP_TILES_STAGES at start-up): the general MFMA update
-     *     kernel -- operand slabs by LDS-DMA, strided piece ownership of the wavefronts.  2: two LDS stages, step records
+     *     kernel.  Non-zero: operand slabs by LDS-DMA in two LDS stages, strided piece ownership of the wavefronts, step records
      *     fetched a step ahead, the DMA instructions of the next slab issued behind the first products of the current one
-     *     (ssssm_tilesv_f64_kernel); 1: two stages, DMA issue right behind the barrier; 3 or 4: that many stages
-     *     (ssssm_tiles_f64_kernel); 0: round 2's kernel (register staging, contiguous 64 x 32 sub-tiles); 5 (round 5): compacted,
-     *     piece-indexed staging -- a ring of 32 slots of one live 16 x 16 piece each, light slab steps of a queue share a batch = one
-     *     wait and one barrier (ssssm_tilesp_f64_kernel, pg_hip_pieces.h). */
+     *     (ssssm_tilesv_f64_kernel); 0: round 2's kernel (register staging, contiguous 64 x 32 sub-tiles).  The values 1, 3, 4
+     *     and 5 used to select earlier / experimental kernels (ssssm_tiles_f64_kernel<STAGES>, ssssm_tilesp_f64_kernel): those
+     *     are in tools/experiments/ since round 6 and the values now mean the default kernel. */
 #define PANGULU_HIP_OPT_TILES_STAGES 16
     /*   PANGULU_HIP_OPT_QUERY_FREE_MIB: a QUERY, nothing is set (value ignored): returns the free memory of the back-end's device in MiB
      *     (hipMemGetInfo), so that a host decides placements (pangulu_amd_snapshot) by what THIS device or partition has, not by a

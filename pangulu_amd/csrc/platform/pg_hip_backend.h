@@ -82,9 +82,9 @@ struct Backend
     long long opt_front_stages = 2; // PANGULU_HIP_FRONT_STAGES / option 15: 1 = inside the general launch (no step list), 2..4 = own kernel
     long long opt_front_min_wgs = 2048; // PANGULU_HIP_FRONT_MIN_WGS: ... from this many qualifying workgroups in a launch on (round 3 sweep, fem27(112): 842.8 / 845.0 / 849.0 ms at 8192 / 2048 / never; round 4, with the destination preloaded: 656.9 / 655.4 / 653.6 / 659.6 ms at 8192 / 2048 / 512 / 64)
     long long opt_front_unit = 1;   // PANGULU_HIP_FRONT_UNIT: consecutive destinations of the front launch that share an XCD
-    // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), 1 / 3 / 4 = the
-    // LDS-DMA pipeline with 2 / 3 / 4 stages and strided piece ownership (ssssm_tiles_f64_kernel, pg_hip_front.h), 2 = its
-    // two-stage form with the per-step fixed cost taken out of the chain (ssssm_tilesv_f64_kernel)
+    // general MFMA update kernel: 0 = round 2's (register staging, contiguous sub-tiles; pg_hip_dense.h), any other value = the
+    // two-stage LDS-DMA pipeline with strided piece ownership (ssssm_tilesv_f64_kernel, pg_hip_front.h).  (The values 1, 3, 4, 5
+    // selected round 3's ssssm_tiles_f64_kernel<STAGES> and round 5's ssssm_tilesp_f64_kernel: tools/experiments/ since round 6.)
     long long opt_tiles_stages = 2; // PANGULU_HIP_TILES_STAGES / option 16
     long long opt_tiles_unit = 1;   // PANGULU_HIP_TILES_UNIT: consecutive destinations of the general launch that share an XCD
     unsigned long long front_workgroups = 0, general_workgroups = 0;

@@ -3,7 +3,7 @@
 // nb <= 256.)  Replaces densify + cuSOLVER getrf + gather of the reference's GPU path (…0201000.cu:547-641); the
 // arithmetic is the CPU kernel's right-looking elimination without pivoting (…0100000.c:57-135) in a blocked order.
 //
-// Why: the earlier blocked kernels (getrf_blocked / getrf_lookahead above) spend ~300-360 us on a 256 x 256 block
+// Why: the earlier blocked kernels (getrf_blocked / getrf_lookahead, tools/experiments/pg_hip_getrf_blocked.h since round 6) spend ~300-360 us on a 256 x 256 block
 // whatever its fill: every panel step is a chain of L2 round trips (panel load, strip load, trailing tiles written by
 // other wavefronts and read back), 16 + 16 pivot steps with an IEEE division each, barriers in between, and an epilogue
 // that inverts the diagonal tiles.  Near the root of the elimination tree that chain IS the factorisation's critical path.
@@ -35,6 +35,32 @@
 // most one unit in the last place.  Parity: within 1e-12 of the oracle
 // (tests/test_gpu_parity*.py); the order-preserving kernel (GETRF_STRICT_ORDER) is unchanged.
 #pragma once
+// (shared with tools/experiments/pg_hip_getrf_blocked.h, where these lived until round 6)
+#ifndef GETRF_STAMP
+// index i with ptr[i] <= p < ptr[i+1] (ptr ascending, ptr[0] = 0, p < ptr[n])
+__device__ inline int owner_of(const u32 *ptr, int n, u32 p)
+{
+    int lo = 0, hi = n; // invariant: ptr[lo] <= p < ptr[hi]
+    while (hi - lo > 1)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+#define GETRF_STAMP(slot)                                                  \
+    if (dbg && tid == 0 && blockIdx.x == 0)                                \
+    {                                                                      \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+        dbg[slot] += now_ - stamp_;                                        \
+        stamp_ = now_;                                                     \
+    }
+#endif
+
 
 #define GT_THREADS 512
 #define GT_COMPUTE_WAVES 7

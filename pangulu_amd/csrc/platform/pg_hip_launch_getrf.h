@@ -5,12 +5,9 @@
 // ---- GETRF -------------------------------------------------------------------------------------------------------
 // `gs`: stream the factorisation kernels go to (the main stream, or a side stream that has already been made to wait
 // for everything these blocks depend on; the caller joins it back)
-// the tiled GETRF kernel (pg_hip_getrf_tiled.h) is the default; PANGULU_HIP_GETRF_TILED=0 selects round 1's kernels
-inline bool getrf_tiled_selected()
-{
-    static const bool on = !(getenv("PANGULU_HIP_GETRF_TILED") && atoi(getenv("PANGULU_HIP_GETRF_TILED")) == 0);
-    return on;
-}
+// (rounds 1-2's kernels -- getrf_blocked / getrf_lookahead, PANGULU_HIP_GETRF_TILED=0 -- moved to tools/experiments/ in round 6:
+//  the tiled kernel covers the same blocks (R64, nb % 16 == 0, nb <= 256) and won every comparison since round 2)
+#define GETRF_DENSE_MAX_NB 256 // dense-mode factorisation: one 16 x 16 tile grid of at most 16 x 16 tiles
 
 // round 5's kernel (pg_hip_getrf_pipe.h) for blocks factorised in their mirrors; PANGULU_HIP_GETRF_PIPE=0 keeps the tiled kernel
 inline bool getrf_pipe_selected()
@@ -37,7 +34,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
     }
     bool blocked_kernel = false;
 #if defined(PG_DENSE_PANELS)
-    blocked_kernel = !B.opt_getrf_strict && (nb % 16 == 0) && nb <= GETRF_BLOCKED_ROWS;
+    blocked_kernel = !B.opt_getrf_strict && (nb % 16 == 0) && nb <= GETRF_DENSE_MAX_NB;
 #endif
     size_t i = 0;
     while (i < n)
@@ -130,7 +127,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         }
                         lu_images.push_back(m);
                         st.lu_image = true;
-                        st.lu_map = getrf_tiled_selected();
+                        st.lu_map = true;
                         st.image_halves = 3;
                     }
                     else if (!st.sparse_current && st.mirror)
@@ -189,21 +186,7 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
 #if defined(PG_DENSE_PANELS)
             if (blocked)
             {
-                size_t lds = sizeof(double) * (2 * GETRF_PANEL * (size_t)(nb + 2) + GETRF_PANEL * GETRF_PANEL) + sizeof(u32) * 2 * (size_t)(nb + 1);
-                static size_t lds_allowed = 0;
-                if (lds > lds_allowed)
-                {
-                    HIP_CHECK(hipFuncSetAttribute((const void *)getrf_blocked_f64_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    HIP_CHECK(hipFuncSetAttribute((const void *)getrf_blocked_f64_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    lds_allowed = lds;
-                }
                 static const bool debug_stamps = getenv("PANGULU_HIP_DEBUG_GETRF") != nullptr;
-                // (measured: 64.2 ms per factorisation of the bench matrix with the 512-thread variant from 129 blocks against 64.6 ms
-                // without -- both kernels slow down when they share CUs; off by default)
-                static const long narrow_from = getenv("PANGULU_HIP_GETRF_NARROW_FROM") ? atol(getenv("PANGULU_HIP_GETRF_NARROW_FROM")) : 1 << 30;
-                static const bool lookahead_kernel = !(getenv("PANGULU_HIP_GETRF_LOOKAHEAD") && atoi(getenv("PANGULU_HIP_GETRF_LOOKAHEAD")) == 0);
-                static const bool tiled_kernel = getrf_tiled_selected();
-                if (tiled_kernel)
                 {
                     // static tile ownership + a dedicated factorisation wavefront (pg_hip_getrf_tiled.h)
                     const size_t lds_t = gt_lds_bytes(nb);
@@ -266,24 +249,6 @@ void launch_getrf(int nb, task_t **list, size_t n, hipStream_t gs, bool defer_jo
                         PG_LAUNCH(getrf_tiled_f64_kernel, dim3((unsigned)take), dim3(GT_THREADS), lds_t, ks, d_tasks, nb, B.d_flops + 1,
                                            debug_stamps ? B.d_flops + 8 : nullptr);
                 }
-                else if (lookahead_kernel)
-                {
-                    const size_t lds_la = sizeof(double) * (4 * GETRF_PANEL * (size_t)(nb + 2) + GETRF_PANEL * GETRF_PANEL) + sizeof(u32) * (2 * (size_t)(nb + 1) + 4);
-                    static size_t la_allowed = 0;
-                    if (lds_la > la_allowed)
-                    {
-                        HIP_CHECK(hipFuncSetAttribute((const void *)getrf_lookahead_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_la));
-                        la_allowed = lds_la;
-                    }
-                    PG_LAUNCH(getrf_lookahead_f64_kernel, dim3((unsigned)take), dim3(1024), lds_la, ks, d_tasks, nb, B.d_flops + 1,
-                                       debug_stamps ? B.d_flops + 8 : nullptr);
-                }
-                else if ((long)take >= narrow_from)
-                    PG_LAUNCH(getrf_blocked_f64_kernel<512>, dim3((unsigned)take), dim3(512), lds, ks, d_tasks, nb,
-                                       B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
-                else
-                    PG_LAUNCH(getrf_blocked_f64_kernel<1024>, dim3((unsigned)take), dim3(1024), lds, ks, d_tasks, nb,
-                                       B.d_flops + 1, debug_stamps ? B.d_flops + 8 : nullptr);
             }
 #endif
             if (!blocked && nsp)

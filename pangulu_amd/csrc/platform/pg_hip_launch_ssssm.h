@@ -475,26 +475,14 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 if (fork_front)
                     pg_event_record(B.ev_front_join, fs);
                 LaunchTimer lk_general(nw ? 101 : 102, ds); // (102: no general launch in this call -- an empty pair, dropped at harvest)
-                if (nw && B.opt_tiles_stages >= 2)
+                if (nw && B.opt_tiles_stages >= 1)
                 {
-                    // round 3: LDS-DMA pipeline, strided piece ownership (pg_hip_front.h)
+                    // the general MFMA update kernel: LDS-DMA pipeline of two stages, strided piece ownership, step records a step ahead,
+                    // DMA issue behind the first products (pg_hip_front.h).  (Round 3's ssssm_tiles_f64_kernel<STAGES> and round 5's
+                    // piece-indexed ssssm_tilesp_f64_kernel -- option values 1, 3, 4, 5 -- live in tools/experiments/ since round 6:
+                    // neither won an in-situ comparison, profiles/r03*, r05[a-h]_pieces_*.)
                     const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_tiles_unit);
-                    if (B.opt_tiles_stages >= 5)
-                        // round 5: compacted, piece-indexed staging -- light slab steps of a queue share a batch (pg_hip_pieces.h)
-                        PG_LAUNCH(ssssm_tilesp_f64_kernel, dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
-                    else if (B.opt_tiles_stages >= 4)
-                        PG_LAUNCH((ssssm_tiles_f64_kernel<4>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
-                    else if (B.opt_tiles_stages == 3)
-                        PG_LAUNCH((ssssm_tiles_f64_kernel<3>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
-                    else if (B.opt_tiles_stages == 2)
-                        // (the default: two stages, step records prefetched, DMA issue behind the first products)
-                        PG_LAUNCH(ssssm_tilesv_f64_kernel, dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
-                }
-                else if (nw && B.opt_tiles_stages == 1)
-                {
-                    // (the first two-stage version: DMA issue right behind the barrier)
-                    const unsigned unit = (unsigned)(tiles * tiles) * (unsigned)std::max<long long>(1, B.opt_tiles_unit);
-                    PG_LAUNCH((ssssm_tiles_f64_kernel<2>), dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
+                    PG_LAUNCH(ssssm_tilesv_f64_kernel, dim3((unsigned)nw), dim3(FR_THREADS), 0, ds, d_tasks_d, nb, d_work, pc, unit);
                 }
                 else if (nw)
                     PG_LAUNCH(ssssm_dense_f64_kernel, dim3((unsigned)nw), dim3(DG_THREADS), 0, ds, d_tasks_d, nb, pc,

@@ -516,7 +516,6 @@ __global__ __launch_bounds__(SSSSM_WAVES * 64) void ssssm_sparse_kernel(const Ss
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 #include "pg_hip_dense.h"
 #include "pg_hip_front.h"
-#include "pg_hip_pieces.h"
 #endif
 #if defined(PG_DENSE_PANELS) || defined(PG_COMPLEX_PANELS)
 #include "pg_hip_trsm_dense.h"
@@ -724,7 +723,6 @@ __global__ __launch_bounds__(GETRF_THREADS) void getrf_kernel(const GetrfTaskD *
         atomicAdd(flop_counter, ops);
 }
 
-#include "pg_hip_getrf_blocked.h"
 
 #if defined(PG_DENSE_PANELS)
 #include "pg_hip_getrf_tiled.h"

@@ -19,8 +19,6 @@ SWITCHES = [
     {"PANGULU_HIP_TRSM_RING": "0", "_matrix": "fem27"},
     {"PANGULU_HIP_GETRF_PIPE": "0"},           # round 4's tiled GETRF (trailing tiles through L2) instead of the register-resident one
     {"PANGULU_HIP_GETRF_PIPE": "0", "_matrix": "fem27"},
-    {"PANGULU_HIP_GETRF_TILED": "0"},          # round-1 GETRF with look-ahead inside the block
-    {"PANGULU_HIP_GETRF_TILED": "0", "PANGULU_HIP_GETRF_LOOKAHEAD": "0"},
     {"PANGULU_HIP_RECORDS_STREAM": "0"},       # sparsify jobs of finished blocks on the main stream
     {"PANGULU_HIP_OCCUPANCY_SUMMARIES": "0"},  # no host-side pattern summaries: maps read behind the mirrors, full work lists
     {"PANGULU_HIP_RESERVED_CUS": "8"},         # CU-masked bulk streams
@@ -49,7 +47,7 @@ SWITCHES = [
     {"PANGULU_AMD_RECORD_AT_INIT": "0"},       # schedule recorded by the first gstrf instead of a dry run at init
     {"PANGULU_AMD_FORCE_MULTI_LOOP": "1"},     # one rank through the multi-rank scheduler loop (launcher thread + markers)
     {"PG_TEST_HIP_OPTIONS": "15=0,16=0"},      # round 2's MFMA update kernel
-    {"PG_TEST_HIP_OPTIONS": "15=3,16=3"},      # LDS-DMA update kernels with three stages
+    {"PG_TEST_HIP_OPTIONS": "15=3"},           # dense-front kernel with three LDS stages
     {"PANGULU_AMD_BIND_NUMA": "0"},
     {"HSA_ENABLE_INTERRUPT": "0"},             # what bench.py sets
     # the configuration bench.py TIMES: structural flop counting of the MFMA path off (the kernel gets a null product
@@ -104,8 +102,6 @@ SWEEP_SPACE = [
     # (environment variable or back-end option number, non-default values)
     ("PANGULU_HIP_LAUNCH_CHUNK", ["8", "64"]),
     ("PANGULU_HIP_TRSM_DIRECT", ["0"]),
-    ("PANGULU_HIP_GETRF_TILED", ["0"]),
-    ("PANGULU_HIP_GETRF_LOOKAHEAD", ["0"]),
     ("PANGULU_HIP_RECORDS_STREAM", ["0"]),
     ("PANGULU_HIP_OCCUPANCY_SUMMARIES", ["0"]),
     ("PANGULU_HIP_FRONT_FORK", ["1"]),
@@ -127,7 +123,7 @@ SWEEP_SPACE = [
     (13, ["0"]),             # records stream
     (14, ["0"]),             # background updates
     (15, ["0", "3"]),        # dense-front kernel: off / three stages
-    (16, ["0", "1", "2", "3", "5"]),  # general update kernel: round 2's, the LDS-DMA ones, tilesv, the pieces kernel
+    (16, ["0"]),             # general update kernel: round 2's (the others of rounds 3-5 are in tools/experiments/)
     ("PANGULU_HIP_GETRF_PIPE", ["0"]),  # (appended: the draws before this entry keep their settings for the options above)
     ("PANGULU_AMD_LOOKAHEAD_DEFER_FROM", ["0"]),
     ("PANGULU_AMD_LOOKAHEAD_MIN_QUEUE", ["1", "2", "8", "1000"]),

@@ -19,28 +19,7 @@
 #define GETRF_PANEL 16
 #define GETRF_BLOCKED_ROWS 256 // one row thread per row: nb <= 256
 
-// index i with ptr[i] <= p < ptr[i+1] (ptr ascending, ptr[0] = 0, p < ptr[n])
-__device__ inline int owner_of(const u32 *ptr, int n, u32 p)
-{
-    int lo = 0, hi = n; // invariant: ptr[lo] <= p < ptr[hi]
-    while (hi - lo > 1)
-    {
-        const int mid = (lo + hi) >> 1;
-        if (ptr[mid] <= p)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
-#define GETRF_STAMP(slot)                                                  \
-    if (dbg && tid == 0 && blockIdx.x == 0)                                \
-    {                                                                      \
-        unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
-        dbg[slot] += now_ - stamp_;                                        \
-        stamp_ = now_;                                                     \
-    }
+// (owner_of and GETRF_STAMP: pg_hip_getrf_tiled.h, which has to be included first)
 
 // THREADS = 1024: sixteen wavefronts, the whole register file of the CU (fastest for a block on its own).
 // THREADS = 512: eight wavefronts capped at 128 registers -- half of the CU stays free, so the update and densify

@@ -48,7 +48,8 @@ __device__ unsigned long long g_item[16];
 #endif
 #include "../../pangulu_amd/csrc/platform/pg_hip_dense.h"
 #include "../../pangulu_amd/csrc/platform/pg_hip_front.h"
-#include "../../pangulu_amd/csrc/platform/pg_hip_pieces.h"
+#include "../experiments/ssssm_tiles.h"
+#include "../experiments/pg_hip_pieces.h"
 #ifdef SW_PROBE
 __device__ unsigned long long g_sw_probe[8];
 #endif
