@@ -432,17 +432,26 @@ void join_background(hipStream_t s)
     }
 }
 
-Segment acquire_segment()
+// `want`: bytes the caller is going to fill (0: unknown -- it sizes its launch by what it gets).  Only a RECORDING cares: the
+// descriptors of a recorded schedule stay for the life of the handle, in a pinned host segment while recording and in an HBM twin
+// afterwards.  Until round 5 every platform call of a single-rank recording took a segment of 8 MB of its own whatever it wrote:
+// 13.2 GB of HBM on elastic3d(77) for 2-3 GB of descriptors.  Now every recording packs: a call takes the free tail of a recorded
+// segment that has room for what it wants (an update call states its task count: it is not cut into more launches than before),
+// or a new segment just large enough, and hands back what it did not use.
+Segment acquire_segment(size_t want = 0)
 {
     Ring &r = B.ring;
     if (REC.mode != 0)
     {
-        // recording: the launches will be replayed, their descriptors have to stay -- a segment of its own, kept by the recorder
-        if (REC.pack && !REC.tails.empty())
+        const size_t min_room = want ? std::min(r.seg_bytes, (want + 4096 + 65535) & ~(size_t)65535) : ((size_t)2 << 20);
+        // recording: the launches will be replayed, their descriptors have to stay
+        for (size_t k = REC.tails.size(); k-- > 0;)
         {
-            const Recorder::Tail t = REC.tails.back();
-            REC.tails.pop_back();
+            const Recorder::Tail t = REC.tails[k];
             const Recorder::Seg &sg = REC.segs[(size_t)t.seg];
+            if (sg.cap - t.used < min_room)
+                continue;
+            REC.tails.erase(REC.tails.begin() + (long)k);
             Segment s;
             s.h = sg.h + t.used;
             s.d = sg.d + t.used;
@@ -453,18 +462,20 @@ Segment acquire_segment()
             s.rec_off = t.used;
             return s;
         }
+        // (a new segment: what is wanted, or a chunk of 4 MB whose tail serves the small calls that follow)
+        const size_t bytes = std::min(r.seg_bytes, std::max(min_room, (size_t)4 << 20));
         char *h = nullptr, *d = nullptr, *twin = nullptr;
-        HIP_CHECK(hipHostMalloc((void **)&h, r.seg_bytes, hipHostMallocNonCoherent | hipHostMallocMapped));
+        HIP_CHECK(hipHostMalloc((void **)&h, bytes, hipHostMallocNonCoherent | hipHostMallocMapped));
         HIP_CHECK(hipHostGetDevicePointer((void **)&d, h, 0));
-        HIP_CHECK(hipMalloc((void **)&twin, r.seg_bytes));
-        REC.segs.push_back(Recorder::Seg{h, d, twin, r.seg_bytes});
-        REC.descriptor_bytes += r.seg_bytes;
+        HIP_CHECK(hipMalloc((void **)&twin, bytes));
+        REC.segs.push_back(Recorder::Seg{h, d, twin, bytes});
+        REC.descriptor_bytes += bytes;
         Segment s;
         s.h = h;
         s.d = d;
-        s.cap = r.seg_bytes;
+        s.cap = bytes;
         s.used = 0;
-        s.index = REC.pack ? -2 : -1;
+        s.index = -2;
         s.rec_idx = (int)REC.segs.size() - 1;
         s.rec_off = 0;
         return s;
@@ -492,9 +503,9 @@ void commit_segment(Segment &s)
         B.ring.pending.push_back(s.index);
     else if (s.index == -2 && REC.mode != 0)
     {
-        // packed recording: what the call did not use goes back, if it is worth a call
+        // what the call did not use goes back, if it is worth a call
         const size_t used = s.rec_off + ((s.used + 255) & ~(size_t)255);
-        if (used + ((size_t)2 << 20) <= REC.segs[(size_t)s.rec_idx].cap)
+        if (used + ((size_t)64 << 10) <= REC.segs[(size_t)s.rec_idx].cap)
             REC.tails.push_back(Recorder::Tail{s.rec_idx, used});
     }
 }

@@ -42,13 +42,14 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
     {
         bool bg_hazard = false;
         const size_t chunk_begin = i;
-        Segment seg = acquire_segment();
         // worst case per task: one group + one task descriptor in each class; fill until the segment is full
         // (per update: a task descriptor in each class -- PG_PLANES^2 real products on the MFMA side --, a group in each, four
         // work items per MFMA group; the K-split of very small launches multiplies groups and work items of <= 64 tasks by four)
         const size_t per_task = sizeof(SsssmTaskD) * (1 + PG_PLANES * PG_PLANES) + sizeof(SsssmGroupD) * (1 + PG_PLANES) +
                                 sizeof(SsssmWorkD) * 8 * PG_PLANES;
-        size_t max_tasks = (seg.cap - 64 * 4 * PG_PLANES * (sizeof(SsssmGroupD) + 4 * sizeof(SsssmWorkD)) - 4096) / per_task;
+        const size_t fixed_part = 64 * 4 * PG_PLANES * (sizeof(SsssmGroupD) + 4 * sizeof(SsssmWorkD)) + 4096;
+        Segment seg = acquire_segment(std::min(n - i, launch_chunk_tasks()) * per_task + fixed_part + 65536);
+        size_t max_tasks = (seg.cap - fixed_part) / per_task;
         size_t take = std::min(n - i, std::min(max_tasks, launch_chunk_tasks()));
         SsssmTaskD *d_tasks_s, *d_tasks_d;
         SsssmGroupD *d_groups_s, *d_groups_d;

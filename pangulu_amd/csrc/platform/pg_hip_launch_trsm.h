@@ -24,8 +24,9 @@ void launch_trsm(int nb, task_t **list, size_t n)
     PEND.hold = PEND.active; // (a held factorisation waits until this call knows whether its solves can chase it)
     while (i < n)
     {
-        Segment seg = acquire_segment();
-        size_t take = std::min(n - i, seg.cap / (sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64 + 80 + 4 * sizeof(u32))); // (+80: a remote-diagonal image job per task at worst)
+        const size_t per_solve = sizeof(TrsmTaskD) + sizeof(TrsmTaskD) + 64 + 80 + 4 * sizeof(u32); // (+80: a remote-diagonal image job per task at worst)
+        Segment seg = acquire_segment(std::min(n - i, launch_chunk_tasks()) * per_solve + 65536);
+        size_t take = std::min(n - i, seg.cap / per_solve);
         take = std::min(take, launch_chunk_tasks());
         {
             // PANGULU_HIP_TRSM_CHUNK: solves per launch (0 = all).  The leaf levels of a large problem bring tens of thousands of

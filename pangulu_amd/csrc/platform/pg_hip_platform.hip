@@ -1715,7 +1715,7 @@ extern "C"
             if (B.opt_profile || B.opt_host_mirror || !B.opt_assume_independent)
                 return -1;
             REC.mode = cmd == 4 ? 2 : 1;
-            REC.pack = cmd == 5;
+            REC.pack = true; // (round 6: every recording packs its descriptor segments, see acquire_segment)
             REC.owner = owner;
             REC.signature = options_signature();
             REC.stats_before = B.stats;
