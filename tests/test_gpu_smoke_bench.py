@@ -177,7 +177,7 @@ def test_bench_gives_up_a_hanging_transport_inside_its_budget():
     env = dict(os.environ, PANGULU_BENCH_TEST_HANG_TRANSPORT="ipc")
     t0 = time.time()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "shell", "--size", "40", "40", "--steps", "2", "--warmup", "1",
-                          "--transport", "auto", "--worker-timeout", "45", "--total-budget", "400", "--cpu-sample-stride", "3", "--no-profile-pass"],
+                          "--transport", "auto", "--worker-timeout", "25", "--total-budget", "400", "--cpu-sample-stride", "3", "--no-profile-pass"],
                          capture_output=True, text=True, timeout=600, env=env)
     wall = time.time() - t0
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
@@ -185,7 +185,7 @@ def test_bench_gives_up_a_hanging_transport_inside_its_budget():
     att = line["config"]["worker_attempts"]
     # rccl: not available on one device (ends by itself) -> ipc: hangs, killed at its cap -> host: runs
     assert [a["transport"] for a in att] == ["rccl", "ipc", "host"], att
-    assert att[1]["done"] is False and 40 <= att[1]["s"] <= 70 and att[2]["done"] is True, att
+    assert att[1]["done"] is False and 20 <= att[1]["s"] <= 50 and att[2]["done"] is True, att
     assert line["config"]["transport"] == "host" and line["value"] > 0 and line["residual"] < 1e-10
     assert wall < 400 and line["bench_wall_s"] <= 400
     assert line["transport_ab"] is None  # (only behind a first attempt that succeeded)
