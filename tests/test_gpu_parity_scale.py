@@ -8,6 +8,8 @@ Tolerance: factors within 1e-12 (R64/CR64) / 1e-5 (R32) of the oracle relative t
 factor check ||L(U 1) - A 1|| / ||A 1|| (src/pangulu_numeric.c:1082-1341) and ||Ax-b||/||b|| within 1e-10 of the oracle's.
 """
 import numpy as np
+import os
+
 import pytest
 
 from pangulu_amd import _lib
@@ -87,6 +89,29 @@ def test_largest_factor_comparison_nb256():
     ref = factorize(mat, 256, oracle_library("r64"))
     _check(mat, 256, gpu, ref, res_tol=2e-12)
     assert gpu["hip_stats"]["ssssm_dense_mfma"]["launches"] > 0
+
+
+@pytest.mark.skipif(not os.environ.get("PG_LARGE_PARITY"), reason="opt-in (PG_LARGE_PARITY=1): minutes of the oracle on one core")
+def test_factor_comparison_at_eight_times_the_suite_size():
+    """Opt-in, run by the builder once per round (profiles/r06q_*): elastic3d(40) -- 192 000 unknowns of the default bench class, eight
+    times the unknowns of the largest comparison of the suite, deep enough for launches of thousands of work items on both MFMA update
+    kernels -- every entry of L and U of the HIP path against the oracle (its SSSSM on OpenBLAS dgemm like the reference,
+    ...0100000.c:317-327) at 1e-12 of the largest entry."""
+    import bench
+
+    blas = bench.find_openblas()
+    if blas:
+        os.environ["PANGULU_ORACLE_BLAS"] = blas
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    size = int(os.environ.get("PG_LARGE_PARITY_SIZE", "40"))
+    mat = M.elastic3d(size)
+    gpu = factorize(mat, 256, "hip")
+    ref = factorize(mat, 256, oracle_library("r64"), solve=False)
+    dl, du = max_rel_diff(gpu["L"], ref["L"]), max_rel_diff(gpu["U"], ref["U"])
+    print("elastic3d(%d): n = %d, flop = %.3e, max rel |dL| = %.2e, |dU| = %.2e, residual %.2e, factor check %.2e, front / general workgroups %d / %d" % (
+        size, mat[0], gpu["info"]["flop"], dl, du, gpu["residual"], gpu["factor_check"],
+        gpu["hip_stats"]["ssssm_dense_mfma"]["front_workgroups"], gpu["hip_stats"]["ssssm_dense_mfma"]["general_workgroups"]))
+    assert dl <= 1e-12 and du <= 1e-12 and gpu["residual"] <= 1e-11 and gpu["info"]["flop"] == ref["info"]["flop"]
 
 
 def test_large_getrf_batches_nb256():
