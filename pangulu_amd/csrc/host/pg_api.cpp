@@ -8,6 +8,7 @@
 #include <omp.h>
 #include <sys/time.h>
 
+#include <sys/mman.h>
 #include "pg_host.h"
 
 namespace pg
@@ -868,6 +869,19 @@ extern "C"
         return 0;
     }
 
+    // a large host buffer on transparent huge pages where the system has them (see the host arena, pg_preprocess.cpp): free() releases it
+    static char *big_host_alloc(size_t bytes)
+    {
+        void *p = nullptr;
+        if (posix_memalign(&p, bytes >= ((size_t)2 << 20) ? ((size_t)2 << 20) : 64, std::max<size_t>(bytes, 64)) != 0)
+            return nullptr;
+#ifdef MADV_HUGEPAGE
+        if (bytes >= ((size_t)2 << 20) && !getenv("PANGULU_AMD_NO_HUGEPAGES"))
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+        return (char *)p;
+    }
+
     int pangulu_amd_snapshot(void **pangulu_handle)
     {
         Solver *S = (Solver *)*pangulu_handle;
@@ -877,7 +891,7 @@ extern "C"
         if (!S->arena_snapshot)
         {
             if (plat.host_memory)
-                S->arena_snapshot = (char *)malloc(S->storage.arena_bytes);
+                S->arena_snapshot = big_host_alloc(S->storage.arena_bytes);
             else
             {
                 // Where the copy lives (PANGULU_AMD_SNAPSHOT=device|host|auto): on the device a reset is one pass over HBM, but it
@@ -903,7 +917,7 @@ extern "C"
                 }
                 S->snapshot_on_host = on_host;
                 if (on_host)
-                    S->arena_snapshot = (char *)malloc(S->storage.arena_bytes);
+                    S->arena_snapshot = big_host_alloc(S->storage.arena_bytes);
                 else
                     plat.malloc_((void **)&S->arena_snapshot, S->storage.arena_bytes);
                 if (!S->arena_snapshot)

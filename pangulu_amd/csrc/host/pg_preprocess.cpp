@@ -11,6 +11,7 @@
 #include <queue>
 #include <string>
 #include <omp.h>
+#include <sys/mman.h>
 
 #include "pg_host.h"
 
@@ -557,8 +558,16 @@ void preprocess(Solver &S, const CscMatrix &A)
     const bool analysis_only = S.analysis_only;
     if (analysis_only)
         st.arena_bytes = 64; // no records: mapping, counters and models only (PANGULU_AMD_ANALYSIS_ONLY)
-    if (posix_memalign((void **)&st.harena, 64, st.arena_bytes) != 0)
+    // (2 MB alignment + MADV_HUGEPAGE, round 6: the first touch of 87 GB in 4 KB pages -- 21 M page faults -- was most of the 12 s this
+    //  step took of a 33 s pangulu_init on the default bench matrix, with all threads zeroing; where transparent huge pages are off
+    //  the advice is ignored and nothing changes)
+    if (posix_memalign((void **)&st.harena, st.arena_bytes >= ((size_t)2 << 20) ? ((size_t)2 << 20) : 64, st.arena_bytes) != 0)
         fatal("host arena allocation of %zu bytes failed", st.arena_bytes);
+#ifdef MADV_HUGEPAGE
+    if (st.arena_bytes >= ((size_t)2 << 20) && !getenv("PANGULU_AMD_NO_HUGEPAGES"))
+        (void)madvise(st.harena, st.arena_bytes, MADV_HUGEPAGE);
+#endif
+    lap("mapping + slots");
     {
         // zeroed by all threads (first touch included): one thread took 12 of the 60 s of pangulu_init on the default bench matrix's 87 GB
         const size_t piece = (size_t)64 << 20;
@@ -567,6 +576,7 @@ void preprocess(Solver &S, const CscMatrix &A)
         for (i64 k = 0; k < npiece; k++)
             memset(st.harena + (size_t)k * piece, 0, std::min(piece, st.arena_bytes - (size_t)k * piece));
     }
+    lap("host arena zeroed");
     if (plat.host_memory || analysis_only)
     {
         st.darena = st.harena;
@@ -616,7 +626,7 @@ void preprocess(Solver &S, const CscMatrix &A)
         S.diag_lower[k] = &lo;
         S.diag_upper[k] = &up;
     }
-    lap("mapping + slots + arena");
+    lap("device arena + records bound");
     // ---- patterns: one sweep per block column over the symbolic lower pattern ------------------------
     // lower block (br, bc), br > bc, is needed by its owner (CSC + CSR view) and by the owner of the upper
     // block (bc, br), whose CSC is the transpose.
