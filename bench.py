@@ -437,7 +437,7 @@ def supervisor(args):
     order = {"auto": ["rccl", "ipc", "host"], "rccl": ["rccl"], "ipc": ["ipc"], "host": ["host"]}[args.transport] if world > 1 else ["none"]
     line, meta, attempts, ran = None, None, [], None
     for k, tr in enumerate(order):
-        cap = int(max(30, min(worker_cap, left() - reserve)))
+        cap = int(min(worker_cap, max(30, left() - reserve)))  # (an attempt always gets its own cap at most, and 30 s at least of a spent budget)
         w = run_worker(args, rank, tr, k, cap, last=(k + 1 == len(order)))
         line, meta = w["line"], w["meta"]
         attempts.append({"transport": tr, "rc": w["rc"], "done": w["done"], "s": w["s"], "cap_s": cap})
@@ -532,6 +532,23 @@ def gpu_worker_main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus and "RANK" in os.environ:
         args.gpus = world
+    fake = os.environ.get("PANGULU_BENCH_TEST_FAKE_WORKER")
+    if fake:
+        # tests/test_bench_supervisor.py (CPU): the supervisors' walk through the transports, their time budget and the transport A/B
+        # with workers that touch no GPU -- "<transport>=hang" never finishes, "<transport>=fail" exits at once, anything else prints
+        # a canned line for that transport
+        behaviour = dict(kv.split("=") for kv in fake.split(",") if "=" in kv).get(args.transport, "ok")
+        if behaviour == "hang":
+            time.sleep(10 ** 6)
+        if behaviour == "fail":
+            sys.exit(RC_TRANSPORT_UNAVAILABLE)
+        if rank == 0:
+            print(json.dumps({"metric": "numeric factorisation GFLOP/s (pangulu_gstrf, R64)", "value": 1.0, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": 1.0, "step_ms": [1.0] * args.steps, "residual": 0.0, "factor_check": 0.0, "parity_failed": False,
+                              "config": {"workload": "fake", "transport": args.transport}, "cpu_baseline": None}), flush=True)
+        print(json.dumps({"pg_worker": {"flop": 1e9, "base_port": 20000, "workload": "fake"}}), flush=True)
+        print(DONE_MARK, flush=True)
+        return
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # completion signals by polling instead of interrupts (must be set before the runtime starts): the scheduler and launcher
     # threads wait on hundreds of short events per factorisation; measured 44.2 ms (all 40 steps within 43.8-44.8) against
