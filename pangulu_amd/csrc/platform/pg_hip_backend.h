@@ -45,10 +45,13 @@ struct Backend
     // the dense-front launch of an update call on a stream of its own, beside the general launch (PANGULU_HIP_FRONT_FORK=1; see launch_ssssm)
     hipStream_t stream_front = nullptr;
     hipEvent_t ev_front_fork = nullptr, ev_front_join = nullptr;
-    // OFF by default: 0.3-0.8 % on elastic3d(48) / fem27(80, 96) (six A/B pairs on one box, profiles/r04aa_front_fork_ab.log), 1598.9 -> 1590.8 ms
-    // on the default bench matrix -- but the two launches then overlap in a kernel trace and rocprofv3's per-kernel durations no longer add
-    // up to the update class's launch time that bench.py's roofline is quoted on (profiles/r04ab_*): not worth half a per cent
-    long long opt_front_fork = 0;
+    // Round 4 measured 0.3-0.8 % for it (profiles/r04aa_front_fork_ab.log) and left it OFF because the two launches then overlap in a kernel
+    // trace and rocprofv3's per-kernel durations no longer add up to the update class's launch time.  Round 6 measured it again --
+    // elastic3d(77) 1 509.5 against 1 520.1 ms, fem27(112) 613.8 / 617.9, kkt(120) 406.0 / 408.0, shell(398) 33.6 / 33.5, two pairs each on
+    // one box (profiles/r06w_front_fork_ab.txt) -- and turned it ON: bench.py's per-kernel times come from its one-stream profile pass
+    // anyway (the fork is off there: !opt_profile), and tools/profile_recipe.sh runs the rocprofv3 passes with PANGULU_HIP_FRONT_FORK=0
+    // so that their per-kernel durations stay additive and comparable with that pass.
+    long long opt_front_fork = 1;
     bool getrf_join_pending = false;
     // Records stream: the sparse record stays the authoritative form of every finished block, but the dense kernels
     // of the following steps read mirrors and LU images only.  The sparsify jobs behind the dense solves and behind

@@ -451,7 +451,7 @@ void launch_ssssm(int nb, task_t **list, size_t n, bool background = false)
                 static const bool debug_ssssm = getenv("PANGULU_HIP_DEBUG_SSSSM") != nullptr; // (stamps share the GETRF debug slots)
                 unsigned long long *pc = B.opt_count_flops ? B.d_flops + 6 : nullptr;
                 unsigned long long *pc_front = B.opt_count_flops ? B.d_flops + 7 : nullptr; // (the dense-front kernel's products on their own)
-                // PANGULU_HIP_FRONT_FORK=1 (off by default, see Backend::opt_front_fork): the two launches of a call on two streams, so that workgroups of both are resident at once
+                // PANGULU_HIP_FRONT_FORK (on by default since round 6, see Backend::opt_front_fork): the two launches of a call on two streams, so that workgroups of both are resident at once
                 // (one bound by the matrix pipes, the other by its per-step latencies) instead of one launch behind the other's tail.
                 const bool fork_front = nf && nw && B.opt_front_fork && !B.opt_profile;
                 hipStream_t fs = ds;

@@ -28,7 +28,7 @@ SWITCHES = [
     {"PANGULU_HIP_LAUNCH_CHUNK": "8", "_matrix": "fem27"},
     {"PANGULU_HIP_LAUNCH_CHUNK": "8", "PG_TEST_HIP_OPTIONS": "2=100", "_matrix": "fem27"},  # ... with more updates on the sparse records
     {"PANGULU_HIP_LAUNCH_CHUNK": "8", "PG_TEST_HIP_OPTIONS": "2=100"},
-    {"PANGULU_HIP_FRONT_FORK": "1", "_matrix": "fem27"},  # dense-front and general update launches on two streams (default: one)
+    {"PANGULU_HIP_FRONT_FORK": "0", "_matrix": "fem27"},  # dense-front and general update launches on one stream (default since round 6: two)
     {"PANGULU_AMD_ASYNC_LAUNCH": "0"},         # platform calls on the scheduler thread
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0"},  # lazy updates: queues accumulate until the destination's own panel task
     {"PANGULU_AMD_LOOKAHEAD_MAX_GETRF": "0", "PANGULU_HIP_LAUNCH_CHUNK": "64"},
@@ -104,7 +104,7 @@ SWEEP_SPACE = [
     ("PANGULU_HIP_TRSM_DIRECT", ["0"]),
     ("PANGULU_HIP_RECORDS_STREAM", ["0"]),
     ("PANGULU_HIP_OCCUPANCY_SUMMARIES", ["0"]),
-    ("PANGULU_HIP_FRONT_FORK", ["1"]),
+    ("PANGULU_HIP_FRONT_FORK", ["0"]),
     ("PANGULU_HIP_HEAVY_FIRST", ["0", "1"]),
     ("PANGULU_HIP_EARLY_DENSIFY", ["1"]),
     ("PANGULU_HIP_SOLVE_CHUNKED", ["0"]),

@@ -6,10 +6,15 @@
 # per-launch HBM bytes of every kernel into gpurun_out/hbm_traffic.json under the workload's key (bench.workload_key).
 # Copy what you want judged into profiles/ (bench.py quotes profiles/hbm_traffic.json only for the build and workload it profiled).
 # With one rank the first factorisation of the run records the launch schedule and the others replay it: same kernels.
+# PANGULU_HIP_FRONT_FORK=0 in every pass (round 6): the timed configuration runs the dense-front launch of an update call on a stream
+# of its own beside the general launch (0.7 % faster); in a kernel trace the two then overlap and their durations are no longer additive.
+# The passes here keep them on one stream -- the configuration of bench.py's own profile pass, which is where the line's per-kernel
+# times and its roofline come from.
 set -u
 TAG=${1:-run}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+export PANGULU_HIP_FRONT_FORK=0
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --gpu-worker --no-profile-pass --no-secondary --no-sched-steps --steps 2 --warmup 1 $*"
 O=$R/gpurun_out/prof_$TAG
