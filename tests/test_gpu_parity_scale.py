@@ -104,11 +104,21 @@ def test_factor_comparison_at_eight_times_the_suite_size():
         os.environ["PANGULU_ORACLE_BLAS"] = blas
         os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
     size = int(os.environ.get("PG_LARGE_PARITY_SIZE", "40"))
-    mat = M.elastic3d(size)
-    gpu = factorize(mat, 256, "hip")
-    ref = factorize(mat, 256, oracle_library("r64"), solve=False)
+    # PG_LARGE_PARITY_CLASS: elastic3d (default, R64, nb = 256) | kkt (the quasi-definite class of BASELINE configs[3], R64, nb = 256) |
+    # cpoisson (complex-shifted Poisson of configs[4], CR64, nb = 128: the oracle's complex products are its own loops)
+    cls = os.environ.get("PG_LARGE_PARITY_CLASS", "elastic3d")
+    vtype, nb = ("cr64", 128) if cls == "cpoisson" else ("r64", 256)
+    if cls == "kkt":
+        mat = M.kkt(size)
+    elif cls == "cpoisson":
+        mat = M.poisson3d(size, dtype=np.complex128, shift=0.5j)
+    else:
+        mat = M.elastic3d(size)
+    gpu = factorize(mat, nb, "hip", vtype=vtype)
+    ref = factorize(mat, nb, oracle_library(vtype), vtype=vtype, solve=False)
     dl, du = max_rel_diff(gpu["L"], ref["L"]), max_rel_diff(gpu["U"], ref["U"])
-    print("elastic3d(%d): n = %d, flop = %.3e, max rel |dL| = %.2e, |dU| = %.2e, residual %.2e, factor check %.2e, front / general workgroups %d / %d" % (
+    print("%s:" % cls, end=" ")
+    print("size %d: n = %d, flop = %.3e, max rel |dL| = %.2e, |dU| = %.2e, residual %.2e, factor check %.2e, front / general workgroups %d / %d" % (
         size, mat[0], gpu["info"]["flop"], dl, du, gpu["residual"], gpu["factor_check"],
         gpu["hip_stats"]["ssssm_dense_mfma"]["front_workgroups"], gpu["hip_stats"]["ssssm_dense_mfma"]["general_workgroups"]))
     assert dl <= 1e-12 and du <= 1e-12 and gpu["residual"] <= 1e-11 and gpu["info"]["flop"] == ref["info"]["flop"]
