@@ -435,3 +435,36 @@ def test_rccl_transport_on_a_shared_gpu_degrades_without_hanging(tmp_path):
     n = len(z["L_ptr"]) - 1
     L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
     assert max_rel_diff(L, ref["L"]) < 1e-12 and float(z["residual"]) < 1e-13
+
+
+def test_rendezvous_survives_an_abandoned_connection():
+    """The rank handshake has three legs since round 6 (hello, acknowledgement, confirm; pg_comm_socket.h).  With two, a connector that
+    gave up on a slow peer left a connection behind whose hello was still readable: the acceptor registered that dead socket as the
+    peer and dropped the live retry as a duplicate.  Here the test itself plays the connector that gives up -- it sends rank 1's hello to
+    rank 0's listener, takes the acknowledgement and hangs up -- before the real rank 1 starts: both ranks must still meet at the barrier."""
+    import struct
+    import time
+
+    port = 20000 + (free_port() * 7) % 8000
+    worker = os.path.join(ROOT, "tests", "comm_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p0 = subprocess.Popen([sys.executable, worker, "0", "2", str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    magic = 0x50474C55
+    rogue, deadline = None, time.time() + 60
+    while time.time() < deadline:
+        try:
+            rogue = socket.create_connection(("127.0.0.1", port), timeout=2)
+            break
+        except OSError:
+            time.sleep(0.05)
+    assert rogue is not None, "rank 0 never listened"
+    rogue.sendall(struct.pack("<II", magic, 1))
+    rogue.settimeout(10)
+    ack = rogue.recv(4)
+    assert len(ack) == 4 and struct.unpack("<I", ack)[0] == magic ^ 0, ack  # (rank 0 acknowledged the hello ...)
+    rogue.close()                                                             # (... and the connector gives up here: no confirm)
+    p1 = subprocess.Popen([sys.executable, worker, "1", "2", str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    o1, _ = p1.communicate(timeout=120)
+    o0, _ = p0.communicate(timeout=120)
+    assert p0.returncode == 0 and p1.returncode == 0, (p0.returncode, o0[-1500:], p1.returncode, o1[-1500:])
+    assert "rank 0 ok" in o0 and "rank 1 ok" in o1
