@@ -105,13 +105,16 @@ def test_factor_comparison_at_eight_times_the_suite_size():
         os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
     size = int(os.environ.get("PG_LARGE_PARITY_SIZE", "40"))
     # PG_LARGE_PARITY_CLASS: elastic3d (default, R64, nb = 256) | kkt (the quasi-definite class of BASELINE configs[3], R64, nb = 256) |
-    # cpoisson (complex-shifted Poisson of configs[4], CR64, nb = 128: the oracle's complex products are its own loops)
+    # cpoisson (complex-shifted Poisson of configs[4], CR64, nb = 128: the oracle's complex products are its own loops) |
+    # shell (the ldoor class of configs[1]; size 398 is the FULL size of the bench's secondary line, n = 950 424)
     cls = os.environ.get("PG_LARGE_PARITY_CLASS", "elastic3d")
     vtype, nb = ("cr64", 128) if cls == "cpoisson" else ("r64", 256)
     if cls == "kkt":
         mat = M.kkt(size)
     elif cls == "cpoisson":
         mat = M.poisson3d(size, dtype=np.complex128, shift=0.5j)
+    elif cls == "shell":
+        mat = M.shell(size, size)
     else:
         mat = M.elastic3d(size)
     gpu = factorize(mat, nb, "hip", vtype=vtype)
