@@ -58,7 +58,9 @@ def main():
            "shell_20x16": lambda: M.shell(20, 16, dtype=dtype),
            "poisson12c": lambda: M.poisson3d(12, dtype=dtype, shift=0.5j if np.issubdtype(dtype, np.complexfloating) else 0.0),
            "kkt6": lambda: M.kkt(6, dtype=dtype), "shell_40x40": lambda: M.shell(40, 40, dtype=dtype),
-           "kkt8": lambda: M.kkt(8, dtype=dtype), "kkt10": lambda: M.kkt(10, dtype=dtype)}[spec]
+           "kkt8": lambda: M.kkt(8, dtype=dtype), "kkt10": lambda: M.kkt(10, dtype=dtype),
+           # (the opt-in at-size case of test_multirank.py: "elastic3d_<m>")
+           **({spec: lambda: M.elastic3d(int(spec.split("_")[1]))} if spec.startswith("elastic3d_") else {})}[spec]
     n, cp, ri, va, co = gen()
     ordering = "identity" if spec == "trefethen" else "nd"
     if rank == 0:

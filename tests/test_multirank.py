@@ -72,12 +72,16 @@ GENS = {"fem27_6": lambda: M.fem27(6), "poisson8": lambda: M.poisson3d(8), "shel
         "poisson12c": lambda: M.poisson3d(12, dtype=np.complex128, shift=0.5j)}
 
 
+def _matrix_of(spec):
+    return M.elastic3d(int(spec.split("_")[1])) if spec.startswith("elastic3d_") else GENS[spec]()
+
+
 def check_against_single_rank(out, spec, nb, vtype="r64", exchange=True):
     """Factors of the N-rank run (sum over the ranks' blocks) against ONE rank on the oracle: 1e-12 of the largest entry, same
     structural flop count, every update ran exactly once somewhere, bytes sent = bytes received."""
     z = np.load(out)
     n = len(z["L_ptr"]) - 1  # n_padded: a block-aligned dissection adds isolated unit rows
-    ref = factorize(GENS[spec](), nb, oracle_library(vtype), vtype=vtype, ordering="nd")
+    ref = factorize(_matrix_of(spec), nb, oracle_library(vtype), vtype=vtype, ordering="nd")
     L = sp.csc_matrix((z["L_data"], z["L_ind"], z["L_ptr"]), shape=(n, n))
     U = sp.csc_matrix((z["U_data"], z["U_ind"], z["U_ptr"]), shape=(n, n))
     assert int(z["flop"]) == ref["info"]["flop"]
@@ -241,6 +245,26 @@ def test_default_map_on_the_gpu(tmp_path, world, spec, nb, vtype, transport, dis
               extra_env={"PANGULU_AMD_DISTRIBUTE_US": distribute_us} if distribute_us is not None else None)
     z = check_against_single_rank(out, spec, nb, vtype, exchange=distribute_us is not None)
     assert int(z["transport"]) == (_lib.TRANSPORT_IPC if transport == "ipc" else _lib.TRANSPORT_HOST)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("PG_LARGE_PARITY"), reason="opt-in (PG_LARGE_PARITY=1): minutes")
+def test_eight_ranks_at_size_on_the_gpu(tmp_path):
+    """Opt-in, run by the builder (profiles/r06zm_*): eight ranks sharing the box's GPU on elastic3d(PG_LARGE_PARITY_SIZE, default 24:
+    41 472 unknowns, nb = 256), default mapping, peer copies -- every entry of the gathered L and U against ONE rank on the oracle, bytes
+    sent = received, every update once.  (The suite's 8-rank cases are 729 … 9 600 unknowns.)"""
+    import bench
+
+    blas = bench.find_openblas()  # (the oracle's SSSSM on OpenBLAS dgemm like the reference's, one thread)
+    if blas:
+        os.environ["PANGULU_ORACLE_BLAS"] = blas
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    spec = "elastic3d_%d" % int(os.environ.get("PG_LARGE_PARITY_SIZE", "24"))
+    out = str(tmp_path / "out.npz")
+    run_ranks(8, spec, 256, out, platform="hip", transport="ipc", separators=None)
+    z = check_against_single_rank(out, spec, 256, "r64")
+    print("8 ranks, %s: flop %.3e, residual %.2e, blocks received per rank %s, MB sent per rank %s, updates per rank %s" % (
+        spec, float(z["flop"]), float(z["residual"]), [int(b) for b in z["recv_blocks"]], [int(b) >> 20 for b in z["sent"]], [int(t) for t in z["tasks"]]))
 
 
 @pytest.mark.gpu
