@@ -943,9 +943,12 @@ extern "C"
     void pangulu_platform_0201001_synchronize(void)
     {
         ensure_ready();
-        flush_pending_getrf_locked();
-        join_records(B.stream);
-        join_background(B.stream);
+        {
+            std::lock_guard<std::mutex> g(B.mutex); // (the joins touch back-end state: see memcpy below)
+            flush_pending_getrf();
+            join_records(B.stream);
+            join_background(B.stream);
+        }
         HIP_CHECK(hipStreamSynchronize(B.stream));
     }
 
@@ -982,29 +985,51 @@ extern "C"
     void pangulu_platform_0201001_memcpy(void *dst, const void *src, size_t count, unsigned int kind)
     {
         ensure_ready();
-        flush_pending_getrf_locked();
-        // ordered after everything queued on the back-end stream, complete on return
-        join_records(B.stream);
-        join_background(B.stream);
-        HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), B.stream));
-        HIP_CHECK(hipStreamSynchronize(B.stream));
+        // ordered after everything queued on the back-end stream, complete on return.
+        // The host-staged transport calls this from the scheduler's thread (pg_comm_socket.h, isend_block / recv_block) while the
+        // launcher thread is inside hybrid_batched: the joins clear back-end state (bg_tiles, the record flag), so they and the
+        // enqueue happen under the back-end's mutex (round 6: eight ranks on kkt(64) over the host transport died inside
+        // bg_tiles' hash table within seconds, profiles/r06zo_*); the wait is for THIS copy only, outside the mutex.
+        hipEvent_t done;
+        HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        {
+            std::lock_guard<std::mutex> g(B.mutex);
+            flush_pending_getrf();
+            join_records(B.stream);
+            join_background(B.stream);
+            HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), B.stream));
+            HIP_CHECK(hipEventRecord(done, B.stream));
+        }
+        HIP_CHECK(hipEventSynchronize(done));
+        HIP_CHECK(hipEventDestroy(done));
     }
 
     void pangulu_platform_0201001_memcpy_async(void *dst, const void *src, size_t count, unsigned int kind, void *stream)
     {
         ensure_ready();
-        flush_pending_getrf_locked();
         // stream == NULL is what the reference host passes from its receive thread
         // (src/pangulu_communication.c:1850,1880): use the back-end stream so later kernels are ordered behind it
         hipStream_t s = stream ? (hipStream_t)stream : B.stream;
-        if (kind != 0)
-        {
-            join_records(s); // (uploads of received blocks write receive slots, which no sparsify job touches)
-            join_background(s);
-        }
-        HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), s));
+        hipEvent_t done = nullptr;
         if (!stream)
-            HIP_CHECK(hipStreamSynchronize(s)); // the source is pageable host memory the caller may reuse at once
+            HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        {
+            std::lock_guard<std::mutex> g(B.mutex); // (a receive thread beside the launcher: as in memcpy above)
+            flush_pending_getrf();
+            if (kind != 0)
+            {
+                join_records(s); // (uploads of received blocks write receive slots, which no sparsify job touches)
+                join_background(s);
+            }
+            HIP_CHECK(hipMemcpyAsync(dst, src, count, kind_of(kind), s));
+            if (done)
+                HIP_CHECK(hipEventRecord(done, s));
+        }
+        if (done)
+        {
+            HIP_CHECK(hipEventSynchronize(done)); // the source is pageable host memory the caller may reuse at once
+            HIP_CHECK(hipEventDestroy(done));
+        }
     }
 
     void pangulu_platform_0201001_free(void *devptr)

@@ -14,6 +14,14 @@ faulthandler.enable()  # a rank that dies on a signal says where (round 5 lost a
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+if os.environ.get("PANGULU_TEST_NATIVE_BACKTRACE"):  # the native frames of a crash inside the solver library (tests/native_backtrace.c)
+    import ctypes
+    import subprocess
+
+    _so = "/tmp/pg_native_backtrace_%d.so" % os.getpid()
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", _so, os.path.join(ROOT, "tests", "native_backtrace.c")])
+    ctypes.CDLL(_so).pg_test_install_native_backtrace()
+
 import numpy as np  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -59,8 +67,10 @@ def main():
            "poisson12c": lambda: M.poisson3d(12, dtype=dtype, shift=0.5j if np.issubdtype(dtype, np.complexfloating) else 0.0),
            "kkt6": lambda: M.kkt(6, dtype=dtype), "shell_40x40": lambda: M.shell(40, 40, dtype=dtype),
            "kkt8": lambda: M.kkt(8, dtype=dtype), "kkt10": lambda: M.kkt(10, dtype=dtype),
-           # (the opt-in at-size case of test_multirank.py: "elastic3d_<m>")
-           **({spec: lambda: M.elastic3d(int(spec.split("_")[1]))} if spec.startswith("elastic3d_") else {})}[spec]
+           # (the opt-in at-size cases of test_multirank.py: "elastic3d_<m>", "kkt_<m>", "cpoisson_<m>")
+           **({spec: lambda: M.elastic3d(int(spec.split("_")[1]))} if spec.startswith("elastic3d_") else {}),
+           **({spec: lambda: M.kkt(int(spec.split("_")[1]), dtype=dtype)} if spec.startswith("kkt_") else {}),
+           **({spec: lambda: M.poisson3d(int(spec.split("_")[1]), dtype=dtype, shift=0.5j)} if spec.startswith("cpoisson_") else {})}[spec]
     n, cp, ri, va, co = gen()
     ordering = "identity" if spec == "trefethen" else "nd"
     if rank == 0:
