@@ -171,7 +171,10 @@ extern "C"
     void pangulu_platform_0201001_synchronize(void);
     void pangulu_platform_0201001_memset(void *s, int c, size_t n);
     void pangulu_platform_0201001_create_stream(void **stream);
-    /* kind: 0 = host->device, 1 = device->host, 2 = device->device (…0201000.cu:82-103) */
+    /* kind: 0 = host->device, 1 = device->host, 2 = device->device (…0201000.cu:82-103).
+     * memcpy, memcpy_async and synchronize may be called from a second thread (the reference's receive thread does,
+     * src/pangulu_communication.c:1850,1880) while another is inside hybrid_batched: they order themselves behind everything queued so
+     * far under the back-end's lock; memcpy returns when ITS copy is complete. */
     void pangulu_platform_0201001_memcpy(void *dst, const void *src, size_t count, unsigned int kind);
     void pangulu_platform_0201001_memcpy_async(void *dst, const void *src, size_t count, unsigned int kind, void *stream);
     void pangulu_platform_0201001_free(void *devptr);
