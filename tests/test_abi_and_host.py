@@ -264,3 +264,28 @@ def test_lid_and_rhs_files_round_trip(tmp_path, vtype):
     x = pa.pangulu_gstrs(h, b2)
     pa.pangulu_finalize(h)
     assert M.relative_residual(n, cp, ri, va, x, b2) < (1e-12 if vtype in ("r64", "cr64") else 1e-4)
+
+
+def test_platform_entry_points_join_streams_under_the_back_end_mutex():
+    """Source check (round 6): `join_records` / `join_background` clear back-end state (the table of tiles the background stream is
+    writing, the record flag).  The platform's `memcpy` called them outside the mutex from the scheduler's thread while the launcher
+    thread was inside `hybrid_batched`: eight ranks over the host-staged transport died inside that table at kkt(64).
+    Every extern "C" entry point that calls them takes the lock first -- except the reference's per-block solve operators, which run in
+    the solve phase where one thread drives the back-end."""
+    import re
+
+    src = open(os.path.join(ROOT, "pangulu_amd", "csrc", "platform", "pg_hip_platform.hip")).read()
+    body = src[src.index('extern "C"'):]
+    single_threaded = {"spmv", "sptrsv"}
+    starts = [(m.start(), m.group(1)) for m in re.finditer(r"\n    \w[\w \*]*?pangulu_platform_0201001_(\w+)\(", body)]
+    assert len(starts) >= 21
+    offenders = []
+    for (a, name), (b, _) in zip(starts, starts[1:] + [(len(body), "")]):
+        fn = body[a:b]
+        j = min([fn.find(k) for k in ("join_records(", "join_background(") if k in fn], default=-1)
+        if j < 0 or name in single_threaded:
+            continue
+        lock = fn.find("std::lock_guard<std::mutex> g(B.mutex)")
+        if lock < 0 or lock > j:
+            offenders.append(name)
+    assert not offenders, offenders
