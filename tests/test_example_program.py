@@ -98,3 +98,21 @@ def test_example_program_on_the_gpu(tmp_path):
     general, rhs, A, b, symmetric = write_cases(tmp_path)
     assert residual_of(run(exe, "-f", general, "-n", "128", "-r", rhs)) < 1e-12
     assert residual_of(run(exe, "-f", symmetric, "-n", "64")) < 1e-12
+
+
+def test_example_program_at_two_ranks_on_the_oracle(tmp_path):
+    """RANK / WORLD_SIZE / MASTER_* in the environment (what torch.distributed.run exports): both processes call
+    pangulu_amd_comm_init, rank 0 reads the file and prints.  (The RCCL transport the program asks for falls back to host staging on a
+    host-memory platform, on both ranks together.)"""
+    from .test_multirank import free_port
+
+    exe = build(tmp_path, test_platform=True)
+    general, rhs, A, b, symmetric = write_cases(tmp_path)
+    port = free_port()
+    procs = [subprocess.Popen([exe, "-f", general, "-n", "24", "-r", rhs], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert residual_of(outs[0]) < 1e-12 and "2 rank(s)" in outs[0]
+    assert "Ax - b" not in outs[1]
