@@ -2,10 +2,12 @@
  * solve_mtx.c -- a user program against include/pangulu.h, the way a program written for the reference is
  * (the reference ships examples/example.c:282-300: init, gstrf, gstrs, finalize, then ||Ax - b|| / ||b||).
  *
- *   solve_mtx -f matrix.mtx [-n block_order] [-r rhs.txt]
+ *   solve_mtx -f matrix.mtx|matrix.lid [-n block_order] [-r rhs.txt]
  *
- * Reads a Matrix Market coordinate file (real / integer / pattern, general / symmetric / skew-symmetric), solves A x = b on the GPU of
- * this process and prints the relative residual.  Without -r the right-hand side is b = A * 1 (the reference's choice,
+ * Reads a Matrix Market coordinate file (real / integer / pattern, general / symmetric / skew-symmetric) or -- by the last letter of
+ * the name, as the reference's example chooses (examples/example.c:100-163) -- its binary .lid layout (u32 rows, u32 columns, u64
+ * entries, then the CSR arrays: u64 row pointers, u32 column indices, values), solves A x = b on the GPU of this process and prints
+ * the relative residual.  Without -r the right-hand side is b = A * 1 (the reference's choice,
  * examples/example.c:245-266); with it, a text file holding the length on the first non-comment line and one value per line.
  *
  * One process per GPU: started under a launcher that exports RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run does)
@@ -135,6 +137,52 @@ static csc_t read_matrix_market(const char *path)
     return A;
 }
 
+/* the reference's binary layout: CSR on disk, transposed into CSC here (rows stay ascending inside a column) */
+static csc_t read_lid(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        die("cannot open", path);
+    unsigned int dims[2];
+    unsigned long long entries;
+    if (fread(dims, sizeof dims[0], 2, f) != 2 || fread(&entries, sizeof entries, 1, f) != 1 || dims[0] != dims[1] || dims[0] == 0)
+        die("not a square .lid file", path);
+    const size_t n = dims[0], m = (size_t)entries;
+    unsigned long long *rowptr = malloc(sizeof *rowptr * (n + 1));
+    unsigned int *colidx = malloc(sizeof *colidx * (m ? m : 1));
+    sparse_value_t *val = malloc(sizeof *val * (m ? m : 1));
+    if (!rowptr || !colidx || !val)
+        die("out of memory", NULL);
+    if (fread(rowptr, sizeof *rowptr, n + 1, f) != n + 1 || fread(colidx, sizeof *colidx, m, f) != m || fread(val, sizeof *val, m, f) != m ||
+        rowptr[n] != entries)
+        die("the .lid file is short or inconsistent", path);
+    fclose(f);
+    csc_t A;
+    A.n = (sparse_index_t)n, A.nnz = (sparse_pointer_t)m;
+    A.colptr = calloc(n + 1, sizeof *A.colptr);
+    A.rowidx = malloc(sizeof *A.rowidx * (m ? m : 1));
+    A.value = malloc(sizeof *A.value * (m ? m : 1));
+    sparse_pointer_t *fill = malloc(sizeof *fill * n);
+    if (!A.colptr || !A.rowidx || !A.value || !fill)
+        die("out of memory", NULL);
+    for (size_t k = 0; k < m; k++)
+    {
+        if (colidx[k] >= n)
+            die("column index out of range", path);
+        A.colptr[colidx[k] + 1]++;
+    }
+    for (size_t c = 0; c < n; c++)
+        A.colptr[c + 1] += A.colptr[c], fill[c] = A.colptr[c];
+    for (size_t r = 0; r < n; r++)
+        for (unsigned long long k = rowptr[r]; k < rowptr[r + 1]; k++)
+        {
+            sparse_pointer_t at = fill[colidx[k]]++;
+            A.rowidx[at] = (sparse_index_t)r, A.value[at] = val[k];
+        }
+    free(rowptr), free(colidx), free(val), free(fill);
+    return A;
+}
+
 static void multiply(const csc_t *A, const sparse_value_t *x, sparse_value_t *y)
 {
     memset(y, 0, sizeof *y * A->n);
@@ -179,9 +227,9 @@ int main(int argc, char **argv)
         else if ((!strcmp(argv[a], "-n") || !strcmp(argv[a], "-nb")) && a + 1 < argc)
             nb = atoi(argv[++a]);
         else
-            die("usage: solve_mtx -f matrix.mtx [-n block_order] [-r rhs.txt]", NULL);
+            die("usage: solve_mtx -f matrix.mtx|matrix.lid [-n block_order] [-r rhs.txt]", NULL);
     if (!mtx || nb <= 0)
-        die("usage: solve_mtx -f matrix.mtx [-n block_order] [-r rhs.txt]", NULL);
+        die("usage: solve_mtx -f matrix.mtx|matrix.lid [-n block_order] [-r rhs.txt]", NULL);
 
     const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
     const int size = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
@@ -199,7 +247,7 @@ int main(int argc, char **argv)
     if (rank == 0)
     {
         double t = now_s();
-        A = read_matrix_market(mtx);
+        A = mtx[strlen(mtx) - 1] == 'd' ? read_lid(mtx) : read_matrix_market(mtx);
         printf("%s: n = %u, %llu entries, read in %.2f s\n", mtx, (unsigned)A.n, (unsigned long long)A.nnz, now_s() - t);
         b = malloc(sizeof *b * A.n), x = malloc(sizeof *x * A.n);
         if (!b || !x)

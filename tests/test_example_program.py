@@ -65,6 +65,7 @@ def write_cases(tmp_path):
     assert abs(S - S.T).max() == 0
     symmetric = str(tmp_path / "poisson_symmetric.mtx")
     scipy.io.mmwrite(symmetric, sp.coo_matrix(S), symmetry="symmetric")
+    M.write_lid(str(tmp_path / "shell.lid"), n, cp, ri, va)  # (the reference's binary layout of the same matrix as `general`)
     return general, rhs, A.tocsr(), b, symmetric
 
 
@@ -75,6 +76,8 @@ def test_example_program_on_the_oracle(tmp_path):
     general, rhs, A, b, symmetric = write_cases(tmp_path)
     assert residual_of(run(exe, "-f", general, "-n", "24", "-r", rhs)) < 1e-12
     assert residual_of(run(exe, "-f", symmetric, "-n", "32")) < 1e-12
+    lid = run(exe, "-f", str(tmp_path / "shell.lid"), "-n", "24", "-r", rhs)
+    assert residual_of(lid) < 1e-12 and "n = %d, %d entries" % (A.shape[0], A.nnz) in lid
     assert "usage" in run(exe, expect_rc=1)
     assert "cannot open" in run(exe, "-f", str(tmp_path / "missing.mtx"), expect_rc=1)
 
@@ -98,6 +101,7 @@ def test_example_program_on_the_gpu(tmp_path):
     general, rhs, A, b, symmetric = write_cases(tmp_path)
     assert residual_of(run(exe, "-f", general, "-n", "128", "-r", rhs)) < 1e-12
     assert residual_of(run(exe, "-f", symmetric, "-n", "64")) < 1e-12
+    assert residual_of(run(exe, "-f", str(tmp_path / "shell.lid"), "-n", "128")) < 1e-12
 
 
 def test_example_program_at_two_ranks_on_the_oracle(tmp_path):
