@@ -120,3 +120,21 @@ def test_example_program_at_two_ranks_on_the_oracle(tmp_path):
     assert [p.returncode for p in procs] == [0, 0], outs
     assert residual_of(outs[0]) < 1e-12 and "2 rank(s)" in outs[0]
     assert "Ax - b" not in outs[1]
+
+
+@pytest.mark.gpu
+def test_example_program_at_two_ranks_on_the_gpu(tmp_path):
+    """Two processes of the program sharing the box's GPU (the transport it asks for, RCCL, verifies itself at start-up and falls back
+    on both ranks together when two ranks sit on one device)."""
+    from .test_multirank import free_port
+
+    exe = build(tmp_path, test_platform=False)
+    general, rhs, A, b, symmetric = write_cases(tmp_path)
+    port = free_port()
+    procs = [subprocess.Popen([exe, "-f", general, "-n", "128", "-r", rhs], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                                       HSA_ENABLE_IPC_MODE_LEGACY="0"))
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert residual_of(outs[0]) < 1e-12 and "2 rank(s)" in outs[0]
